@@ -1,0 +1,238 @@
+/*
+ * vps_hip.h — C-ABI of libvpship.so: hand-written HIP kernels (gfx950 / MI355X) for the
+ * VPSNet FuseTrack inference hot path (PanopticFuseTrack.simple_test).
+ *
+ * Conventions
+ *   - Every entry point returns 0 on success, a negative hipError_t otherwise, -1000-x for argument
+ *     errors. Nothing throws, nothing allocates, nothing synchronises: the caller owns all device
+ *     memory (including workspaces) and passes the hipStream_t (as void*) to launch on.
+ *   - All tensors are fp32 device pointers unless stated. The internal activation layout is NHWC
+ *     with an explicit per-pixel channel stride `ld` (floats) and channel offset `coff`, so that
+ *     producers write straight into slices of concat buffers (no torch.cat on the path).
+ *   - "ref:" lines cite the interface in mcahny/vps (relative to the reference root) that the
+ *     symbol replaces.
+ */
+#ifndef VPS_HIP_H
+#define VPS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ----------------------------------------------------------------------------------------------
+ * Library info
+ * -------------------------------------------------------------------------------------------- */
+/* returns the ABI version of the library (bumped on any signature change) */
+int vps_abi_version(void);
+/* human readable build string: arch, kernels */
+const char* vps_build_info(void);
+
+/* ----------------------------------------------------------------------------------------------
+ * Dense contraction: conv / transposed conv / linear / deformable conv as implicit GEMM on MFMA
+ *   ref: every torch.nn.Conv2d / ConvTranspose2d / Linear + BatchNorm2d(eval) + ReLU/LeakyReLU on the
+ *        path (SURVEY §8a a2,a7,a8,a11-a15,a17,a19,a20), mmdet/ops/dcn/src/deform_conv_cuda.cpp:151-250
+ *        (deform_conv_forward_cuda) + deform_conv_cuda_kernel.cu:189-241 (deformable_im2col).
+ * GEMM view: out[m][co] = act( scale[co] * sum_k A[m][k] * Wp[co][k] + shift[co] + res[m][co] )
+ *   m  = (n, qy, qx) output-grid pixel,  k = (ky*KW + kx)*cin_pad + ci
+ *   A[m][k] = in[n][qy*stride - pad_y + ky][qx*stride - pad_x + kx][ci]   (0 outside the image)
+ *   deformable: A sampled bilinearly at (.. + dh, .. + dw) from `offset` (per-corner zeroing).
+ * Transposed convs are `nclass` = s*s independent convs (one per output parity class); class c
+ * (py = c / os_x, px = c % os_x) uses weight block c, pads pad_y[py], pad_x[px] and writes output pixel
+ * (qy*os_y + py, qx*os_x + px).
+ * -------------------------------------------------------------------------------------------- */
+enum { VPS_ACT_NONE = 0, VPS_ACT_RELU = 1, VPS_ACT_LEAKY = 2 };
+
+typedef struct vps_conv_desc {
+    /* input activation, NHWC */
+    const float* in;
+    int32_t N, H, W;
+    int32_t in_ld;      /* floats per pixel (multiple of 4) */
+    int32_t in_coff;    /* first channel used (multiple of 4) */
+    int32_t cin_pad;    /* channels contracted, multiple of 4; weights are zero for the pad */
+    /* packed weights [nclass][cout_pad][kpad], k contiguous; kpad multiple of 32, cout_pad of tile_n */
+    const float* w;
+    int32_t cout, cout_pad, kpad;
+    int32_t KH, KW, stride;
+    int32_t pad_y[2], pad_x[2];
+    /* output */
+    float* out;
+    int32_t Ho, Wo;     /* full output spatial size */
+    int32_t out_ld, out_coff;
+    int32_t Qh, Qw;     /* GEMM pixel grid per class (== Ho,Wo for a conv) */
+    int32_t os_y, os_x; /* 1 for conv, s for a stride-s transposed conv */
+    int32_t nclass;     /* os_y*os_x */
+    /* epilogue */
+    const float* scale; /* [cout] or NULL (=1) */
+    const float* shift; /* [cout] or NULL (=0) */
+    const float* res;   /* residual NHWC or NULL; read at (oy>>res_shift, ox>>res_shift) */
+    int32_t res_ld, res_coff, res_shift;
+    int32_t act;        /* VPS_ACT_* */
+    float slope;        /* LeakyReLU negative slope */
+    /* deformable sampling (NULL = plain conv): NHWC [N][Ho][Wo][off_ld], ch 2*(ky*KW+kx) = dh, +1 = dw */
+    const float* offset;
+    int32_t off_ld;
+    /* tiling */
+    int32_t tile_n;     /* 32, 64 or 128 */
+    int32_t ksplit;     /* >=1; >1 needs ws of ksplit*M*cout_pad floats (M = nclass*N*Qh*Qw) */
+    float* ws;
+} vps_conv_desc;
+
+int vps_conv2d(const vps_conv_desc* d, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * FlowNet2 gather / scan ops (HBM bound)
+ * All take explicit element strides (sn, sc, sh, sw) so the same kernel serves the reference's NCHW
+ * operator API and the NHWC pipeline.
+ * -------------------------------------------------------------------------------------------- */
+typedef struct vps_tensor4 {
+    float* p;
+    int64_t sn, sc, sh, sw; /* element strides */
+} vps_tensor4;
+
+/* ref: resample2d_package/resample2d.py:40-49, resample2d_kernel.cu:15-72 (kernel_size=1, bilinear,
+ * border clamp of the four tap indices). out[b,c,y,x] = bilinear(in[b,c], x+flow[b,0,y,x], y+flow[b,1,y,x]) */
+int vps_resample2d(vps_tensor4 in, vps_tensor4 flow, vps_tensor4 out,
+                   int B, int C, int H, int W, void* stream);
+
+/* ref: channelnorm_package/channelnorm.py:31-38, channelnorm_kernel.cu:18-60. out[b,0,y,x] = sqrt(sum_c in^2) */
+int vps_channelnorm(vps_tensor4 in, vps_tensor4 out, int B, int C, int H, int W, void* stream);
+
+/* ref: correlation_package/correlation.py:47-61, correlation_cuda.cc:10-87,
+ * correlation_cuda_kernel.cu:46-147 (kernel_size=1, stride1=1). Inputs NHWC (ld/coff), output channel
+ * tc = (tj+r)*(2r+1)+(ti+r), r = max_disp/stride2, written to out[.., out_coff+tc] with optional LeakyReLU.
+ * out = (1/C) * sum_c in1[y,x,c] * in2[y+tj*s2, x+ti*s2, c], zero outside. */
+int vps_correlation(const float* in1, int ld1, int coff1, const float* in2, int ld2, int coff2,
+                    float* out, int out_ld, int out_coff,
+                    int N, int H, int W, int C, int max_disp, int stride2,
+                    int act, float slope, void* stream);
+
+/* ref: flow_modules/flow_modules.py:126-148 (WarpingLayer): grid = linspace(-1,1) + flow/((W-1)/2),
+ * F.grid_sample(bilinear, zeros padding, align_corners=False). NHWC in/out, flow NHWC [N,H,W,flow_ld] (ch0=x,1=y) */
+int vps_flow_warp(const float* in, int in_ld, int in_coff, const float* flow, int flow_ld, int flow_coff,
+                  float* out, int out_ld, int out_coff, int N, int H, int W, int C, void* stream);
+
+/* layout transposes: NCHW (contiguous) <-> NHWC (ld/coff); pad channels [C, Cpad) are written as zero */
+int vps_nchw_to_nhwc(const float* in, float* out, int out_ld, int out_coff, int N, int C, int H, int W,
+                     int Cpad, void* stream);
+int vps_nhwc_to_nchw(const float* in, int in_ld, int in_coff, float* out, int N, int C, int H, int W, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Resize / pool / elementwise (NHWC)
+ * -------------------------------------------------------------------------------------------- */
+/* F.interpolate(mode=bilinear, align_corners=False) (mode 0) or nearest (mode 1); out = alpha * resized.
+ * ref: flownet2.py:143,155 (upsample1/2 bilinear x4), :167,180 (nearest x4), panoptic_fusetrack.py:140-142,
+ * upsnetFPN.py:73-80, tcea_modules.py:72 */
+int vps_resize(const float* in, int in_ld, int in_coff, int Hi, int Wi,
+               float* out, int out_ld, int out_coff, int Ho, int Wo,
+               int N, int C, int mode, float alpha, void* stream);
+/* 3x3 stride-2 pad-1 max (mode 0, -inf pad; ref resnet.py:465, tcea_modules.py:27) or avg pool
+ * (mode 1, count_include_pad=True; ref tcea_modules.py:28) */
+int vps_pool3x3s2(const float* in, int in_ld, int in_coff, int Hi, int Wi,
+                  float* out, int out_ld, int out_coff, int N, int C, int mode, void* stream);
+/* BFP gather: out = (sum_l nearest_resize(level_l)) / L at level-0 resolution; ratio[l] = H0 / H_l.
+ * ref: extra_necks/bfp_tcea.py:96-109 (refine_level = 0) */
+int vps_bfp_gather(const float* const* levels, const int* ld, const int* ratio, int nlevels,
+                   float* out, int out_ld, int out_coff, int N, int H0, int W0, int C, void* stream);
+/* BFP scatter: out = adaptive_max_pool2d(bsf, (H0/ratio, W0/ratio)) + level. ref: bfp_tcea.py:139-147 */
+int vps_bfp_scatter(const float* bsf, int bsf_ld, const float* level, int lvl_ld, float* out, int out_ld,
+                    int N, int H0, int W0, int C, int ratio, void* stream);
+/* y = x*a + b elementwise over a slice (used for flow scaling) */
+int vps_axpb(const float* in, int in_ld, int in_coff, float* out, int out_ld, int out_coff,
+             int64_t npix, int C, float a, float b, void* stream);
+
+/* FlowNet2 input prep. ref: utils/flow_utils.py:5-10 (denormalize), flownet2.py:135-139 (rgb_mean over both
+ * frames, (x-mean)/rgb_max, cat). img/ref NCHW [1,3,H,W] normalised; out NHWC [H*W][out_ld] ch0-2 img, 3-5 ref.
+ * `partial` is a caller workspace of 3*nblk doubles, `mean3` 3 floats. */
+int vps_flow_prep(const float* img, const float* ref, const float* mean3, const float* std3,
+                  float* out, int out_ld, int H, int W, double* partial, int nblk, float* rgb_mean_out,
+                  void* stream);
+/* FlowNet2 inter-stage tensor build (ref flownet2.py:142-151,154-163,166-174,179-187): given a 1/4-res
+ * 2-channel flow (NHWC, ld/coff) compute flow_full = up4(div_mode ? flow/mul : flow*mul) (up_mode 0
+ * bilinear / 1 nearest), warped = resample2d(x[3:6], flow_full), diff = x[0:3]-warped, and write any of:
+ *   x[0:3] -> out[img_off..+3], flow_full (/flow_out_div if >0) -> out[flow_off..+2],
+ *   warped -> out[warp_off..+3], ||diff||2 -> out[diffnorm_off], ||flow_full||2 -> out[flownorm_off]
+ * (offset < 0 = skip). H, W multiples of 4. */
+int vps_flow_stage(const float* x6, int x_ld, const float* flow_lo, int flo_ld, int flo_coff,
+                   int H, int W, int up_mode, float mul, int div_mode,
+                   float* out, int out_ld, int flow_off, float flow_out_div, int warp_off,
+                   int diffnorm_off, int flownorm_off, int img_off, void* stream);
+
+/* GroupNorm(G) + ReLU over NHWC (N=1): stats pass then apply pass. ref: upsnetFPN.py:39-52 (GroupNorm(32)).
+ * `stats` workspace: 2*G doubles (zeroed by the call). */
+int vps_groupnorm_relu(const float* in, int in_ld, float* out, int out_ld, int64_t npix, int C, int G,
+                       const float* gamma, const float* beta, float eps, int relu,
+                       double* stats, void* stream);
+
+/* TCEA temporal attention. ref: tcea_modules.py:50-65. emb [npix][2*C] (frame-major: tAtt_1 of both frames),
+ * emb_ref [npix][C]; fea2 [npix][2*C] (bsf | warp_bsf) -> out = fea2 * sigmoid(sum_c emb_i*emb_ref) per frame */
+int vps_tcea_temporal(const float* emb, int emb_ld, const float* emb_ref, int ref_ld,
+                      const float* fea2, int fea_ld, float* out, int out_ld, int64_t npix, int C, void* stream);
+/* out = fea * sigmoid(att) * 2 + att_add. ref: tcea_modules.py:74-77 */
+int vps_tcea_modulate(const float* fea, const float* att, const float* att_add, float* out,
+                      int64_t n, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Detection ops
+ * -------------------------------------------------------------------------------------------- */
+/* ref: mmdet/ops/roi_align/roi_align.py:59-87, src/roi_align_kernel.cu:16-124 + roi_extractors/
+ * single_level.py:54-107 (level mapping lvl = floor(log2(sqrt(w*h)/56 + 1e-6)) clamped to [0,nlvl-1]).
+ * feats: NHWC levels (ld each), spatial_scale 1/stride; rois [R][5] (b,x1,y1,x2,y2); out NHWC [R][P][P][C] */
+int vps_roi_align(const float* const* feats, const int* ld, const int* Hs, const int* Ws, const float* scales,
+                  int nlevels, float finest_scale, const float* rois, int R, int C, int P, int sample_num,
+                  float* out, void* stream);
+
+/* ref: mmdet/ops/nms/src/nms_kernel.cu:13-130 and utils/upsnet/nms/nms_kernel.cu:40-150.
+ * Batched: boxes [nbatch][nmax][5] each sorted by descending score, counts_dev[nbatch] valid boxes (device),
+ * IoU with the +1 convention, suppress if IoU > thr. mask_ws: nbatch*nmax*ceil(nmax/64) uint64.
+ * keep [nbatch][nmax] int32 (indices into the sorted list, ascending), nkeep[nbatch] (device).
+ * The greedy reduce (a host loop in the reference) runs on the device, one wavefront per batch entry. */
+int vps_nms_batched(const float* boxes, int nbatch, int nmax, const int32_t* counts_dev, float thr,
+                    uint64_t* mask_ws, int32_t* keep, int32_t* nkeep, void* stream);
+
+/* ref: core/bbox/transforms.py:34-68 (delta2bbox, means 0, stds given, clamp to img, wh_ratio_clip 16/1000).
+ * anchors [n][4], deltas [n][4] -> boxes5 [n][5] (x1,y1,x2,y2,score) */
+int vps_delta2bbox(const float* anchors, const float* deltas, const float* scores, float* boxes5, int n,
+                   float std_x, float std_y, float std_w, float std_h, float img_h, float img_w, void* stream);
+
+/* ref: core/bbox/geometry.py:4-63 (bbox_overlaps, +1 convention). a [m][4/5] lda, b [n][ldb] -> out [m][n] */
+int vps_bbox_overlaps(const float* a, int lda, int m, const float* b, int ldb, int n, float* out, void* stream);
+
+/* row softmax / log-softmax for small matrices: in [rows][cols] -> out. mode 0 softmax, 1 log_softmax */
+int vps_row_softmax(const float* in, float* out, int rows, int cols, int mode, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Panoptic head
+ * -------------------------------------------------------------------------------------------- */
+/* ref: utils/mask_removal.py:29-92, body of the per-box loop (boxes visited in descending cls_prob order by
+ * the host): resize the SxS (28x28) mask logits to the int32-truncated box (cv2.resize INTER_LINEAR on float32),
+ * binarise > 0, compare with the class occupancy plane (uint8 [H][W]).
+ *   vps_mask_count : counts[0] = #mask pixels in the clipped box, counts[1] = #mask pixels already occupied
+ *   vps_mask_commit: keep = counts[0] != 0 && !(counts[1]/counts[0] > thr) decided ON THE DEVICE;
+ *                    *flag = keep; kept masks are added to the occupancy plane. No host sync between boxes. */
+int vps_mask_count(const float* logit, int S, int bx1, int by1, int bx2, int by2, int H, int W,
+                   const uint8_t* occ, int32_t* counts, void* stream);
+int vps_mask_commit(const float* logit, int S, int bx1, int by1, int bx2, int by2, int H, int W,
+                    uint8_t* occ, const int32_t* counts, double thr, int32_t* flag, void* stream);
+
+/* one kept instance of the panoptic combine */
+typedef struct vps_pan_inst {
+    int32_t sx0, sy0, sx1, sy1;     /* SegTerm crop [x0,x1) x [y0,y1): int(b), int(round(b)+1) (unary_logits.py:102-105) */
+    int32_t seg_ch;                 /* class_mapping[cls] channel of fcn_output */
+    int32_t bx1, by1, bx2, by2;     /* MaskRemoval int32-truncated box (mask_removal.py:56-62) */
+    int32_t mask_idx;               /* row of mask_logits [*][S][S] */
+} vps_pan_inst;
+
+/* ref: upsnetFPN.py:81 (bilinear x4 of fcn_score), utils/unary_logits.py:81-108 (SegTerm),
+ * mask_removal.py:88 (paste), panoptic_fusetrack.py:588-597 (cat, softmax, argmax; argmax of fcn_output).
+ * fcn_score NHWC [Hs][Ws][score_ld]; fcn_output (x H/Hs bilinear) is recomputed per pixel, never stored.
+ * pan/sem: uint8 [H][W] (ids 0..nstuff-1 stuff, nstuff+j = j-th instance; k <= 255-nstuff). */
+int vps_panoptic_combine(const float* fcn_score, int score_ld, int Hs, int Ws, int nclass, int nstuff,
+                         const vps_pan_inst* inst, int k, const float* mask_logits, int S,
+                         uint8_t* pan, uint8_t* sem, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPS_HIP_H */

@@ -1,0 +1,443 @@
+// FlowNet2-side gather/scan kernels: resample2d, channelnorm, correlation, flow-guided feature warp,
+// layout transposes, FlowNet2 input prep and the fused inter-stage tensor builder. All HBM-bound.
+// Reference (relative to /root/reference/mmdet/models/flow_modules unless noted) is cited per kernel.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// resample2d_package/resample2d_kernel.cu:15-72 — backward warp with border-clamped taps.
+// The reference mixes double literals into the weights ((1. - alpha) etc.): reproduced literally.
+// One thread per (b,y,x): the flow is read once per pixel instead of once per channel.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float resample_tap(float v00, float v01, float v10, float v11, float alpha, float beta) {
+    float val = 0.0f;
+    val += static_cast<float>((1. - alpha) * (1. - beta) * v00);
+    val += static_cast<float>((alpha) * (1. - beta) * v01);
+    val += static_cast<float>((1. - alpha) * (beta) * v10);
+    val += static_cast<float>((alpha) * (beta) * v11);
+    return val;
+}
+
+__global__ __launch_bounds__(256)
+void resample2d_kernel(vps_tensor4 in, vps_tensor4 flow, vps_tensor4 out, int B, int C, int H, int W) {
+    const long total = (long)B * H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W);
+        const int y = (int)((idx / W) % H);
+        const int b = (int)(idx / ((long)W * H));
+        const float dx = flow.p[b * flow.sn + 0 * flow.sc + y * flow.sh + x * flow.sw];
+        const float dy = flow.p[b * flow.sn + 1 * flow.sc + y * flow.sh + x * flow.sw];
+        const float xf = (float)x + dx, yf = (float)y + dy;
+        const float alpha = xf - floorf(xf), beta = yf - floorf(yf);
+        const int xL = max(min((int)floorf(xf), W - 1), 0);
+        const int xR = max(min((int)(floorf(xf) + 1.f), W - 1), 0);
+        const int yT = max(min((int)floorf(yf), H - 1), 0);
+        const int yB = max(min((int)(floorf(yf) + 1.f), H - 1), 0);
+        const float* ib = in.p + b * in.sn;
+        for (int c = 0; c < C; ++c) {
+            const float* ic = ib + c * in.sc;
+            const float v = resample_tap(ic[yT * in.sh + xL * in.sw], ic[yT * in.sh + xR * in.sw],
+                                         ic[yB * in.sh + xL * in.sw], ic[yB * in.sh + xR * in.sw], alpha, beta);
+            out.p[b * out.sn + c * out.sc + y * out.sh + x * out.sw] = v;
+        }
+    }
+}
+
+// channelnorm_package/channelnorm_kernel.cu:18-60
+__global__ __launch_bounds__(256)
+void channelnorm_kernel(vps_tensor4 in, vps_tensor4 out, int B, int C, int H, int W) {
+    const long total = (long)B * H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W);
+        const int y = (int)((idx / W) % H);
+        const int b = (int)(idx / ((long)W * H));
+        float r = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float v = in.p[b * in.sn + c * in.sc + y * in.sh + x * in.sw];
+            r += v * v;
+        }
+        out.p[b * out.sn + y * out.sh + x * out.sw] = sqrtf(r);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// correlation_cuda_kernel.cu:46-147 (kernel_size 1, stride1 1). One 64-lane wavefront per output pixel:
+// lanes stride the channel axis with float4 loads (in1 pixel kept in registers), displacements are
+// processed 64 at a time and reduced with a transposing butterfly (63 shuffles per 64 displacements
+// instead of 6 per displacement), so lane l ends up owning displacement l and the NHWC store of the
+// 441/81 output channels is one coalesced wave store. No padded copies (the reference zero-fills and
+// writes two padded NHWC tensors first).
+// ------------------------------------------------------------------------------------------------
+template <int NC4>  // float4 chunks per lane (C <= 256*NC4)
+__global__ __launch_bounds__(256)
+void correlation_kernel(const float* __restrict__ in1, int ld1, int coff1,
+                        const float* __restrict__ in2, int ld2, int coff2,
+                        float* __restrict__ out, int out_ld, int out_coff,
+                        int N, int H, int W, int C, int r, int s2, int act, float slope) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long npix = (long)N * H * W;
+    const int D = 2 * r + 1;
+    const int ND = D * D;
+    const int c4n = C >> 2;
+    const float invC = 1.0f / (float)C;
+    for (long pix = (long)blockIdx.x * 4 + wave; pix < npix; pix += (long)gridDim.x * 4) {
+        const int x = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        const int n = (int)(pix / ((long)W * H));
+        f32x4 a[NC4];
+#pragma unroll
+        for (int q = 0; q < NC4; ++q) {
+            const int c4 = lane + 64 * q;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            a[q] = c4 < c4n ? *reinterpret_cast<const f32x4*>(in1 + (size_t)pix * ld1 + coff1 + 4 * c4) : z;
+        }
+        for (int d0 = 0; d0 < ND; d0 += 64) {
+            float v[64];
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                const int dd = d0 + i;
+                float p = 0.f;
+                if (dd < ND) {
+                    const int tj = dd / D - r, ti = dd % D - r;
+                    const int y2 = y + tj * s2, x2 = x + ti * s2;
+                    if ((unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W) {
+                        const float* p2 = in2 + ((size_t)(n * H + y2) * W + x2) * ld2 + coff2;
+#pragma unroll
+                        for (int q = 0; q < NC4; ++q) {
+                            const int c4 = lane + 64 * q;
+                            if (c4 < c4n) {
+                                const f32x4 b = *reinterpret_cast<const f32x4*>(p2 + 4 * c4);
+                                p += a[q][0] * b[0] + a[q][1] * b[1] + a[q][2] * b[2] + a[q][3] * b[3];
+                            }
+                        }
+                    }
+                }
+                v[i] = p;
+            }
+            // transposing butterfly: after the last stage lane l holds sum over lanes of v[l]
+#pragma unroll
+            for (int off = 32, nn = 64; off >= 1; off >>= 1, nn >>= 1) {
+                const bool hi = (lane & off) != 0;
+#pragma unroll
+                for (int i = 0; i < nn / 2; ++i) {
+                    const float keep = hi ? v[i + nn / 2] : v[i];
+                    const float send = hi ? v[i] : v[i + nn / 2];
+                    v[i] = keep + __shfl_xor(send, off, 64);
+                }
+            }
+            const int dd = d0 + lane;
+            if (dd < ND) out[(size_t)pix * out_ld + out_coff + dd] = vps_act(v[0] * invC, act, slope);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// flow_modules.py:126-148 WarpingLayer: grid = linspace(-1,1) + flow/((size-1)/2), then F.grid_sample with
+// its defaults (bilinear, zeros, align_corners=False) — the align_corners mismatch is reproduced, not fixed.
+// NHWC: one thread per (pixel, float4 of channels) -> 1 KiB coalesced reads per corner at C=256.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float linspace_m1_p1(int i, int n) {
+    // torch.linspace(-1, 1, n) fp32 CPU kernel: symmetric evaluation around the midpoint
+    const float step = 2.0f / (float)(n - 1);
+    return (i < n / 2) ? (-1.0f + step * (float)i) : (1.0f - step * (float)(n - 1 - i));
+}
+
+__global__ __launch_bounds__(256)
+void flow_warp_kernel(const float* __restrict__ in, int in_ld, int in_coff,
+                      const float* __restrict__ flow, int flow_ld, int flow_coff,
+                      float* __restrict__ out, int out_ld, int out_coff, int N, int H, int W, int C) {
+    const int c4n = C >> 2;
+    const long total = (long)N * H * W * c4n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        const long pix = idx / c4n;
+        const int x = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        const int n = (int)(pix / ((long)W * H));
+        const float fx = flow[(size_t)pix * flow_ld + flow_coff + 0];
+        const float fy = flow[(size_t)pix * flow_ld + flow_coff + 1];
+        const float gx = linspace_m1_p1(x, W) + fx / (((float)W - 1.0f) / 2.0f);
+        const float gy = linspace_m1_p1(y, H) + fy / (((float)H - 1.0f) / 2.0f);
+        // grid_sampler_unnormalize, align_corners=False
+        const float ix = ((gx + 1.f) * (float)W - 1.f) / 2.f;
+        const float iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+        const float ix_nw = floorf(ix), iy_nw = floorf(iy);
+        const float ix_se = ix_nw + 1.f, iy_se = iy_nw + 1.f;
+        const float nw = (ix_se - ix) * (iy_se - iy);
+        const float ne = (ix - ix_nw) * (iy_se - iy);
+        const float sw = (ix_se - ix) * (iy - iy_nw);
+        const float se = (ix - ix_nw) * (iy - iy_nw);
+        const int x0 = (int)ix_nw, y0 = (int)iy_nw, x1 = x0 + 1, y1 = y0 + 1;
+        const float* base = in + (size_t)n * H * W * in_ld + in_coff + 4 * c4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const bool xin0 = (unsigned)x0 < (unsigned)W, xin1 = (unsigned)x1 < (unsigned)W;
+        const bool yin0 = (unsigned)y0 < (unsigned)H, yin1 = (unsigned)y1 < (unsigned)H;
+        if (yin0 && xin0) acc += *reinterpret_cast<const f32x4*>(base + (size_t)(y0 * W + x0) * in_ld) * nw;
+        if (yin0 && xin1) acc += *reinterpret_cast<const f32x4*>(base + (size_t)(y0 * W + x1) * in_ld) * ne;
+        if (yin1 && xin0) acc += *reinterpret_cast<const f32x4*>(base + (size_t)(y1 * W + x0) * in_ld) * sw;
+        if (yin1 && xin1) acc += *reinterpret_cast<const f32x4*>(base + (size_t)(y1 * W + x1) * in_ld) * se;
+        *reinterpret_cast<f32x4*>(out + (size_t)pix * out_ld + out_coff + 4 * c4) = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout transposes (operator-API wrappers and tests; the pipeline itself stays NHWC)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int out_ld, int out_coff,
+                         int N, int C, int H, int W, int Cpad) {
+    __shared__ float tile[32][33];
+    // grid: x over pixel tiles of 32, y over channel tiles of 32, z over n
+    const long HW = (long)H * W;
+    const int n = blockIdx.z;
+    const long p0 = (long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j;
+        const long p = p0 + tx;
+        tile[j][tx] = (c < C && p < HW) ? in[((size_t)n * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const long p = p0 + j;
+        const int c = c0 + tx;
+        if (p < HW && c < Cpad) out[((size_t)n * HW + p) * out_ld + out_coff + c] = tile[tx][j];
+    }
+}
+
+__global__ __launch_bounds__(256)
+void nhwc_to_nchw_kernel(const float* __restrict__ in, int in_ld, int in_coff, float* __restrict__ out,
+                         int N, int C, int H, int W) {
+    __shared__ float tile[32][33];
+    const long HW = (long)H * W;
+    const int n = blockIdx.z;
+    const long p0 = (long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const long p = p0 + j;
+        const int c = c0 + tx;
+        tile[j][tx] = (p < HW && c < C) ? in[((size_t)n * HW + p) * in_ld + in_coff + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j;
+        const long p = p0 + tx;
+        if (c < C && p < HW) out[((size_t)n * C + c) * HW + p] = tile[tx][j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FlowNet2 input prep: utils/flow_utils.py:5-10 (denormalize x*std+mean, two roundings) and
+// flownet2.py:135-139 (rgb_mean jointly over both frames; (x-mean)/rgb_max; channels img|ref).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float denorm(float v, float s, float m) { return __fadd_rn(__fmul_rn(v, s), m); }
+
+__global__ __launch_bounds__(256)
+void flow_prep_sum_kernel(const float* __restrict__ img, const float* __restrict__ ref,
+                          const float* __restrict__ mean3, const float* __restrict__ std3,
+                          long HW, double* __restrict__ partial) {
+    __shared__ double red[3][4];
+    double s[3] = {0.0, 0.0, 0.0};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            s[c] += (double)denorm(img[c * HW + i], std3[c], mean3[c]);
+            s[c] += (double)denorm(ref[c * HW + i], std3[c], mean3[c]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double v = s[c];
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[c][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        partial[threadIdx.x * gridDim.x + blockIdx.x] =
+            red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+__global__ void flow_prep_mean_kernel(const double* __restrict__ partial, int nblk, long HW, float* __restrict__ rgb_mean) {
+    const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;  // 192 threads: one wave per channel
+    double v = 0.0;
+    for (int i = lane; i < nblk; i += 64) v += partial[c * nblk + i];
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) rgb_mean[c] = (float)(v / (double)(2 * HW));
+}
+
+__global__ __launch_bounds__(256)
+void flow_prep_write_kernel(const float* __restrict__ img, const float* __restrict__ ref,
+                            const float* __restrict__ mean3, const float* __restrict__ std3,
+                            const float* __restrict__ rgb_mean, float* __restrict__ out, int out_ld, long HW) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x) {
+        float* o = out + (size_t)i * out_ld;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            o[c] = (denorm(img[c * HW + i], std3[c], mean3[c]) - rgb_mean[c]) / 255.0f;
+            o[3 + c] = (denorm(ref[c * HW + i], std3[c], mean3[c]) - rgb_mean[c]) / 255.0f;
+        }
+        for (int c = 6; c < out_ld; ++c) o[c] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FlowNet2 inter-stage builder (flownet2.py:142-151, 154-163, 166-174, 179-187): x4 upsample of the
+// 1/4-res flow (bilinear align_corners=False, or nearest), Resample2d of the second image, channel norms
+// and the concat writes fused into ONE pass over the full-resolution frame (the reference runs 6-8
+// separate full-res kernels and a torch.cat per stage).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float scale_lo(float v, float mul, int div_mode) { return div_mode ? v / mul : v * mul; }
+
+__global__ __launch_bounds__(256)
+void flow_stage_kernel(const float* __restrict__ x6, int x_ld, const float* __restrict__ flo, int flo_ld, int flo_coff,
+                       int H, int W, int up_mode, float mul, int div_mode,
+                       float* __restrict__ out, int out_ld, int flow_off, float flow_out_div, int warp_off,
+                       int diffnorm_off, int flownorm_off, int img_off) {
+    const int Hl = H >> 2, Wl = W >> 2;
+    const long HW = (long)H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < HW; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W), y = (int)(idx / W);
+        float fx, fy;
+        if (up_mode == 1) {  // nearest: src = floor(dst * 0.25)
+            const float* p = flo + ((size_t)(y >> 2) * Wl + (x >> 2)) * flo_ld + flo_coff;
+            fx = scale_lo(p[0], mul, div_mode);
+            fy = scale_lo(p[1], mul, div_mode);
+        } else {  // aten upsample_bilinear2d, align_corners=False, scale 1/4
+            float sy = 0.25f * ((float)y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+            float sx = 0.25f * ((float)x + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int yp = y0 < Hl - 1 ? 1 : 0, xp = x0 < Wl - 1 ? 1 : 0;
+            const float ly = sy - (float)y0, lx = sx - (float)x0;
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            const float* p00 = flo + ((size_t)y0 * Wl + x0) * flo_ld + flo_coff;
+            const float* p01 = p00 + (size_t)xp * flo_ld;
+            const float* p10 = p00 + (size_t)yp * Wl * flo_ld;
+            const float* p11 = p10 + (size_t)xp * flo_ld;
+            fx = hy * (hx * scale_lo(p00[0], mul, div_mode) + lx * scale_lo(p01[0], mul, div_mode)) +
+                 ly * (hx * scale_lo(p10[0], mul, div_mode) + lx * scale_lo(p11[0], mul, div_mode));
+            fy = hy * (hx * scale_lo(p00[1], mul, div_mode) + lx * scale_lo(p01[1], mul, div_mode)) +
+                 ly * (hx * scale_lo(p10[1], mul, div_mode) + lx * scale_lo(p11[1], mul, div_mode));
+        }
+        float* o = out + (size_t)idx * out_ld;
+        const float* xi = x6 + (size_t)idx * x_ld;
+        if (img_off >= 0) { o[img_off] = xi[0]; o[img_off + 1] = xi[1]; o[img_off + 2] = xi[2]; }
+        if (flow_off >= 0) {
+            o[flow_off] = flow_out_div > 0.f ? fx / flow_out_div : fx;
+            o[flow_off + 1] = flow_out_div > 0.f ? fy / flow_out_div : fy;
+        }
+        if (flownorm_off >= 0) o[flownorm_off] = sqrtf(fx * fx + fy * fy);
+        if (warp_off >= 0 || diffnorm_off >= 0) {
+            const float xf = (float)x + fx, yf = (float)y + fy;
+            const float alpha = xf - floorf(xf), beta = yf - floorf(yf);
+            const int xL = max(min((int)floorf(xf), W - 1), 0);
+            const int xR = max(min((int)(floorf(xf) + 1.f), W - 1), 0);
+            const int yT = max(min((int)floorf(yf), H - 1), 0);
+            const int yB = max(min((int)(floorf(yf) + 1.f), H - 1), 0);
+            const float* tl = x6 + ((size_t)yT * W + xL) * x_ld + 3;
+            const float* tr = x6 + ((size_t)yT * W + xR) * x_ld + 3;
+            const float* bl = x6 + ((size_t)yB * W + xL) * x_ld + 3;
+            const float* br = x6 + ((size_t)yB * W + xR) * x_ld + 3;
+            float nrm = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float wv = resample_tap(tl[c], tr[c], bl[c], br[c], alpha, beta);
+                if (warp_off >= 0) o[warp_off + c] = wv;
+                const float df = xi[c] - wv;
+                nrm += df * df;
+            }
+            if (diffnorm_off >= 0) o[diffnorm_off] = sqrtf(nrm);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vps_resample2d(vps_tensor4 in, vps_tensor4 flow, vps_tensor4 out, int B, int C, int H, int W, void* stream) {
+    if (!in.p || !flow.p || !out.p || B <= 0 || C <= 0 || H <= 0 || W <= 0) return VPS_EARG(1);
+    hipLaunchKernelGGL(resample2d_kernel, dim3(stream_grid((long)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream,
+                       in, flow, out, B, C, H, W);
+    return vps_launch_status();
+}
+
+extern "C" int vps_channelnorm(vps_tensor4 in, vps_tensor4 out, int B, int C, int H, int W, void* stream) {
+    if (!in.p || !out.p || B <= 0 || C <= 0 || H <= 0 || W <= 0) return VPS_EARG(1);
+    hipLaunchKernelGGL(channelnorm_kernel, dim3(stream_grid((long)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream,
+                       in, out, B, C, H, W);
+    return vps_launch_status();
+}
+
+extern "C" int vps_correlation(const float* in1, int ld1, int coff1, const float* in2, int ld2, int coff2,
+                               float* out, int out_ld, int out_coff, int N, int H, int W, int C,
+                               int max_disp, int stride2, int act, float slope, void* stream) {
+    if (!in1 || !in2 || !out || N <= 0 || H <= 0 || W <= 0) return VPS_EARG(1);
+    if (C <= 0 || (C & 3) || C > 1024 || (ld1 & 3) || (ld2 & 3) || (coff1 & 3) || (coff2 & 3)) return VPS_EARG(2);
+    if (stride2 <= 0 || max_disp < 0) return VPS_EARG(3);
+    const int r = max_disp / stride2;
+    const long npix = (long)N * H * W;
+    long g = (npix + 3) / 4; if (g > 65536) g = 65536;
+    hipStream_t s = (hipStream_t)stream;
+#define CORR_LAUNCH(NC4)                                                                                        \
+    hipLaunchKernelGGL((correlation_kernel<NC4>), dim3((unsigned)g), dim3(256), 0, s, in1, ld1, coff1, in2, ld2, \
+                       coff2, out, out_ld, out_coff, N, H, W, C, r, stride2, act, slope)
+    if (C <= 256) CORR_LAUNCH(1);
+    else if (C <= 512) CORR_LAUNCH(2);
+    else CORR_LAUNCH(4);
+#undef CORR_LAUNCH
+    return vps_launch_status();
+}
+
+extern "C" int vps_flow_warp(const float* in, int in_ld, int in_coff, const float* flow, int flow_ld, int flow_coff,
+                             float* out, int out_ld, int out_coff, int N, int H, int W, int C, void* stream) {
+    if (!in || !flow || !out || N <= 0 || H <= 1 || W <= 1) return VPS_EARG(1);
+    if (C <= 0 || (C & 3) || (in_ld & 3) || (in_coff & 3) || (out_ld & 3) || (out_coff & 3)) return VPS_EARG(2);
+    hipLaunchKernelGGL(flow_warp_kernel, dim3(stream_grid((long)N * H * W * (C >> 2), 256)), dim3(256), 0,
+                       (hipStream_t)stream, in, in_ld, in_coff, flow, flow_ld, flow_coff, out, out_ld, out_coff, N, H, W, C);
+    return vps_launch_status();
+}
+
+extern "C" int vps_nchw_to_nhwc(const float* in, float* out, int out_ld, int out_coff, int N, int C, int H, int W,
+                                int Cpad, void* stream) {
+    if (!in || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || Cpad < C) return VPS_EARG(1);
+    dim3 grid(cdiv((long)H * W, 32), cdiv(Cpad, 32), N);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, out_ld, out_coff, N, C, H, W, Cpad);
+    return vps_launch_status();
+}
+
+extern "C" int vps_nhwc_to_nchw(const float* in, int in_ld, int in_coff, float* out, int N, int C, int H, int W, void* stream) {
+    if (!in || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0) return VPS_EARG(1);
+    dim3 grid(cdiv((long)H * W, 32), cdiv(C, 32), N);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, in_ld, in_coff, out, N, C, H, W);
+    return vps_launch_status();
+}
+
+extern "C" int vps_flow_prep(const float* img, const float* ref, const float* mean3, const float* std3,
+                             float* out, int out_ld, int H, int W, double* partial, int nblk, float* rgb_mean_out,
+                             void* stream) {
+    if (!img || !ref || !mean3 || !std3 || !out || !partial || !rgb_mean_out) return VPS_EARG(1);
+    if (out_ld < 6 || nblk <= 0 || nblk > 2048 || H <= 0 || W <= 0) return VPS_EARG(2);
+    hipStream_t s = (hipStream_t)stream;
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(flow_prep_sum_kernel, dim3(nblk), dim3(256), 0, s, img, ref, mean3, std3, HW, partial);
+    hipLaunchKernelGGL(flow_prep_mean_kernel, dim3(1), dim3(192), 0, s, partial, nblk, HW, rgb_mean_out);
+    hipLaunchKernelGGL(flow_prep_write_kernel, dim3(stream_grid(HW, 256)), dim3(256), 0, s, img, ref, mean3, std3,
+                       rgb_mean_out, out, out_ld, HW);
+    return vps_launch_status();
+}
+
+extern "C" int vps_flow_stage(const float* x6, int x_ld, const float* flow_lo, int flo_ld, int flo_coff,
+                              int H, int W, int up_mode, float mul, int div_mode,
+                              float* out, int out_ld, int flow_off, float flow_out_div, int warp_off,
+                              int diffnorm_off, int flownorm_off, int img_off, void* stream) {
+    if (!x6 || !flow_lo || !out || H <= 0 || W <= 0 || (H & 3) || (W & 3)) return VPS_EARG(1);
+    hipLaunchKernelGGL(flow_stage_kernel, dim3(stream_grid((long)H * W, 256)), dim3(256), 0, (hipStream_t)stream,
+                       x6, x_ld, flow_lo, flo_ld, flo_coff, H, W, up_mode, mul, div_mode, out, out_ld, flow_off,
+                       flow_out_div, warp_off, diffnorm_off, flownorm_off, img_off);
+    return vps_launch_status();
+}

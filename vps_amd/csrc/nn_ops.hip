@@ -1,0 +1,325 @@
+// NHWC resize / pool / pyramid gather-scatter / GroupNorm / TCEA attention kernels (all HBM-bound).
+// Reference files are cited relative to /root/reference/mmdet/models.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// F.interpolate bilinear (align_corners=False) / nearest, as ATen's upsample_*2d CPU kernels compute them.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void resize_kernel(const float* __restrict__ in, int in_ld, int in_coff, int Hi, int Wi,
+                   float* __restrict__ out, int out_ld, int out_coff, int Ho, int Wo,
+                   int N, int C, int mode, float alpha, float sh, float sw) {
+    const long total = (long)N * Ho * Wo * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        const long pix = idx / C;
+        const int x = (int)(pix % Wo);
+        const int y = (int)((pix / Wo) % Ho);
+        const int n = (int)(pix / ((long)Wo * Ho));
+        const float* ib = in + (size_t)n * Hi * Wi * in_ld + in_coff + c;
+        float v;
+        if (mode == 1) {
+            const int ys = min((int)floorf((float)y * sh), Hi - 1);
+            const int xs = min((int)floorf((float)x * sw), Wi - 1);
+            v = ib[((size_t)ys * Wi + xs) * in_ld];
+        } else {
+            float sy = sh * ((float)y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+            float sx = sw * ((float)x + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+            const int y0 = min((int)sy, Hi - 1), x0 = min((int)sx, Wi - 1);
+            const int yp = y0 < Hi - 1 ? 1 : 0, xp = x0 < Wi - 1 ? 1 : 0;
+            const float ly = sy - (float)y0, lx = sx - (float)x0;
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            const float p00 = ib[((size_t)y0 * Wi + x0) * in_ld];
+            const float p01 = ib[((size_t)y0 * Wi + x0 + xp) * in_ld];
+            const float p10 = ib[((size_t)(y0 + yp) * Wi + x0) * in_ld];
+            const float p11 = ib[((size_t)(y0 + yp) * Wi + x0 + xp) * in_ld];
+            v = hy * (hx * p00 + lx * p01) + ly * (hx * p10 + lx * p11);
+        }
+        out[(size_t)pix * out_ld + out_coff + c] = v * alpha;
+    }
+}
+
+// 3x3 stride 2 pad 1 max / avg (count_include_pad) pooling
+__global__ __launch_bounds__(256)
+void pool3x3s2_kernel(const float* __restrict__ in, int in_ld, int in_coff, int Hi, int Wi,
+                      float* __restrict__ out, int out_ld, int out_coff, int Ho, int Wo, int N, int C, int mode) {
+    const long total = (long)N * Ho * Wo * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        const long pix = idx / C;
+        const int x = (int)(pix % Wo);
+        const int y = (int)((pix / Wo) % Ho);
+        const int n = (int)(pix / ((long)Wo * Ho));
+        const float* ib = in + (size_t)n * Hi * Wi * in_ld + in_coff + c;
+        float m = -INFINITY, s = 0.f;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = 2 * y + dy;
+            if ((unsigned)yy >= (unsigned)Hi) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = 2 * x + dx;
+                if ((unsigned)xx >= (unsigned)Wi) continue;
+                const float v = ib[((size_t)yy * Wi + xx) * in_ld];
+                m = fmaxf(m, v);
+                s += v;
+            }
+        }
+        out[(size_t)pix * out_ld + out_coff + c] = mode == 0 ? m : s / 9.0f;
+    }
+}
+
+// extra_necks/bfp_tcea.py:96-109 with refine_level=0: every level is nearest-resized to level-0 size,
+// summed in level order and divided by the level count. One pass, float4 over channels.
+struct GatherArgs {
+    const float* lv[5];
+    int ld[5];
+    int ratio[5];  // H0 / H_l
+    int n;
+};
+
+__global__ __launch_bounds__(256)
+void bfp_gather_kernel(GatherArgs a, float* __restrict__ out, int out_ld, int out_coff, int N, int H0, int W0, int C) {
+    const int c4n = C >> 2;
+    const long total = (long)N * H0 * W0 * c4n;
+    const float div = (float)a.n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        const long pix = idx / c4n;
+        const int x = (int)(pix % W0);
+        const int y = (int)((pix / W0) % H0);
+        const int n = (int)(pix / ((long)W0 * H0));
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int l = 0; l < 5; ++l) {
+            if (l < a.n) {
+                const int r = a.ratio[l];
+                const int Hl = H0 / r, Wl = W0 / r;
+                const float* p = a.lv[l] + (((size_t)n * Hl + y / r) * Wl + x / r) * a.ld[l] + 4 * c4;
+                s += *reinterpret_cast<const f32x4*>(p);
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)pix * out_ld + out_coff + 4 * c4) = s / div;
+    }
+}
+
+// extra_necks/bfp_tcea.py:139-147 with refine_level=0: adaptive_max_pool2d(bsf, size_l) (exact 2^l windows) + inputs[l]
+__global__ __launch_bounds__(256)
+void bfp_scatter_kernel(const float* __restrict__ bsf, int bsf_ld, const float* __restrict__ level, int lvl_ld,
+                        float* __restrict__ out, int out_ld, int N, int H0, int W0, int C, int r) {
+    const int c4n = C >> 2;
+    const int Hl = H0 / r, Wl = W0 / r;
+    const long total = (long)N * Hl * Wl * c4n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        const long pix = idx / c4n;
+        const int x = (int)(pix % Wl);
+        const int y = (int)((pix / Wl) % Hl);
+        const int n = (int)(pix / ((long)Wl * Hl));
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int dy = 0; dy < r; ++dy)
+            for (int dx = 0; dx < r; ++dx) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(
+                    bsf + (((size_t)n * H0 + y * r + dy) * W0 + x * r + dx) * bsf_ld + 4 * c4);
+                m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+            }
+        const f32x4 lv = *reinterpret_cast<const f32x4*>(level + (size_t)pix * lvl_ld + 4 * c4);
+        *reinterpret_cast<f32x4*>(out + (size_t)pix * out_ld + 4 * c4) = m + lv;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void axpb_kernel(const float* __restrict__ in, int in_ld, int in_coff, float* __restrict__ out, int out_ld, int out_coff,
+                 long npix, int C, float a, float b) {
+    const long total = npix * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        const long pix = idx / C;
+        out[(size_t)pix * out_ld + out_coff + c] = in[(size_t)pix * in_ld + in_coff + c] * a + b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm(G)+ReLU, N=1 (panoptic/upsnetFPN.py:39-52). Pass 1: per-group sum / sum of squares in fp64
+// (block partials -> one fp64 atomic per group per block). Pass 2: normalise, affine, ReLU.
+// Requires C <= 256 and 256 % C == 0 (C = 256 or 128 here).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void groupnorm_stats_kernel(const float* __restrict__ in, int in_ld, long npix, int C, int G, double* __restrict__ stats) {
+    __shared__ double ssum[256], ssq[256];
+    const int t = threadIdx.x;
+    const int c = t % C;
+    const int ppb = 256 / C;   // pixels handled per block iteration
+    const int sub = t / C;
+    double s = 0.0, q = 0.0;
+    for (long p = (long)blockIdx.x * ppb + sub; p < npix; p += (long)gridDim.x * ppb) {
+        const float v = in[(size_t)p * in_ld + c];
+        s += (double)v;
+        q += (double)v * (double)v;
+    }
+    ssum[t] = s; ssq[t] = q;
+    __syncthreads();
+    const int cpg = C / G;
+    if (t < G) {
+        double gs = 0.0, gq = 0.0;
+        for (int k = 0; k < ppb; ++k)
+            for (int j = 0; j < cpg; ++j) {
+                gs += ssum[k * C + t * cpg + j];
+                gq += ssq[k * C + t * cpg + j];
+            }
+        atomicAdd(&stats[2 * t], gs);
+        atomicAdd(&stats[2 * t + 1], gq);
+    }
+}
+
+__global__ __launch_bounds__(256)
+void groupnorm_apply_kernel(const float* __restrict__ in, int in_ld, float* __restrict__ out, int out_ld, long npix,
+                            int C, int G, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                            int relu, const double* __restrict__ stats) {
+    const long total = npix * C;
+    const int cpg = C / G;
+    const double cnt = (double)npix * cpg;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        const long pix = idx / C;
+        const int g = c / cpg;
+        const double mean = stats[2 * g] / cnt;
+        double var = stats[2 * g + 1] / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = rstd * gamma[c];
+        const float bi = -sc * (float)mean + beta[c];
+        float v = in[(size_t)pix * in_ld + c] * sc + bi;
+        if (relu) v = v > 0.f ? v : 0.f;
+        out[(size_t)pix * out_ld + c] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// utils/tcea_modules.py:50-65 temporal attention for N=2 frames, center frame 0. One wavefront per pixel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void tcea_temporal_kernel(const float* __restrict__ emb, int emb_ld, const float* __restrict__ emb_ref, int ref_ld,
+                          const float* __restrict__ fea2, int fea_ld, float* __restrict__ out, int out_ld, long npix, int C) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4n = C >> 2;
+    for (long pix = (long)blockIdx.x * 4 + wave; pix < npix; pix += (long)gridDim.x * 4) {
+        float cor0 = 0.f, cor1 = 0.f;
+        for (int c4 = lane; c4 < c4n; c4 += 64) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(emb_ref + (size_t)pix * ref_ld + 4 * c4);
+            const f32x4 e0 = *reinterpret_cast<const f32x4*>(emb + (size_t)pix * emb_ld + 4 * c4);
+            const f32x4 e1 = *reinterpret_cast<const f32x4*>(emb + (size_t)pix * emb_ld + C + 4 * c4);
+            cor0 += e0[0] * r[0] + e0[1] * r[1] + e0[2] * r[2] + e0[3] * r[3];
+            cor1 += e1[0] * r[0] + e1[1] * r[1] + e1[2] * r[2] + e1[3] * r[3];
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            cor0 += __shfl_xor(cor0, off, 64);
+            cor1 += __shfl_xor(cor1, off, 64);
+        }
+        const float p0 = 1.f / (1.f + expf(-cor0));
+        const float p1 = 1.f / (1.f + expf(-cor1));
+        for (int c4 = lane; c4 < c4n; c4 += 64) {
+            const f32x4 f0 = *reinterpret_cast<const f32x4*>(fea2 + (size_t)pix * fea_ld + 4 * c4);
+            const f32x4 f1 = *reinterpret_cast<const f32x4*>(fea2 + (size_t)pix * fea_ld + C + 4 * c4);
+            *reinterpret_cast<f32x4*>(out + (size_t)pix * out_ld + 4 * c4) = f0 * p0;
+            *reinterpret_cast<f32x4*>(out + (size_t)pix * out_ld + C + 4 * c4) = f1 * p1;
+        }
+    }
+}
+
+// utils/tcea_modules.py:74-77: fea * sigmoid(att) * 2 + att_add
+__global__ __launch_bounds__(256)
+void tcea_modulate_kernel(const float* __restrict__ fea, const float* __restrict__ att, const float* __restrict__ att_add,
+                          float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float s = 1.f / (1.f + expf(-att[i]));
+        out[i] = fea[i] * s * 2.f + att_add[i];
+    }
+}
+
+}  // namespace
+
+extern "C" int vps_resize(const float* in, int in_ld, int in_coff, int Hi, int Wi, float* out, int out_ld, int out_coff,
+                          int Ho, int Wo, int N, int C, int mode, float alpha, void* stream) {
+    if (!in || !out || N <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return VPS_EARG(1);
+    const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+    hipLaunchKernelGGL(resize_kernel, dim3(stream_grid((long)N * Ho * Wo * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       in, in_ld, in_coff, Hi, Wi, out, out_ld, out_coff, Ho, Wo, N, C, mode, alpha, sh, sw);
+    return vps_launch_status();
+}
+
+extern "C" int vps_pool3x3s2(const float* in, int in_ld, int in_coff, int Hi, int Wi, float* out, int out_ld, int out_coff,
+                             int N, int C, int mode, void* stream) {
+    if (!in || !out || N <= 0 || C <= 0 || Hi <= 0 || Wi <= 0) return VPS_EARG(1);
+    const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(pool3x3s2_kernel, dim3(stream_grid((long)N * Ho * Wo * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       in, in_ld, in_coff, Hi, Wi, out, out_ld, out_coff, Ho, Wo, N, C, mode);
+    return vps_launch_status();
+}
+
+extern "C" int vps_bfp_gather(const float* const* levels, const int* ld, const int* ratio, int nlevels,
+                              float* out, int out_ld, int out_coff, int N, int H0, int W0, int C, void* stream) {
+    if (!levels || !ld || !ratio || !out || nlevels < 1 || nlevels > 5 || (C & 3) || (out_ld & 3) || (out_coff & 3)) return VPS_EARG(1);
+    GatherArgs a;
+    a.n = nlevels;
+    for (int l = 0; l < 5; ++l) {
+        a.lv[l] = l < nlevels ? levels[l] : nullptr;
+        a.ld[l] = l < nlevels ? ld[l] : 0;
+        a.ratio[l] = l < nlevels ? ratio[l] : 1;
+        if (l < nlevels && (!levels[l] || (ld[l] & 3) || ratio[l] < 1 || H0 % ratio[l] || W0 % ratio[l])) return VPS_EARG(2);
+    }
+    hipLaunchKernelGGL(bfp_gather_kernel, dim3(stream_grid((long)N * H0 * W0 * (C >> 2), 256)), dim3(256), 0,
+                       (hipStream_t)stream, a, out, out_ld, out_coff, N, H0, W0, C);
+    return vps_launch_status();
+}
+
+extern "C" int vps_bfp_scatter(const float* bsf, int bsf_ld, const float* level, int lvl_ld, float* out, int out_ld,
+                               int N, int H0, int W0, int C, int ratio, void* stream) {
+    if (!bsf || !level || !out || (C & 3) || (bsf_ld & 3) || (lvl_ld & 3) || (out_ld & 3) || ratio < 1 || H0 % ratio || W0 % ratio)
+        return VPS_EARG(1);
+    hipLaunchKernelGGL(bfp_scatter_kernel, dim3(stream_grid((long)N * (H0 / ratio) * (W0 / ratio) * (C >> 2), 256)),
+                       dim3(256), 0, (hipStream_t)stream, bsf, bsf_ld, level, lvl_ld, out, out_ld, N, H0, W0, C, ratio);
+    return vps_launch_status();
+}
+
+extern "C" int vps_axpb(const float* in, int in_ld, int in_coff, float* out, int out_ld, int out_coff, int64_t npix, int C,
+                        float a, float b, void* stream) {
+    if (!in || !out || npix <= 0 || C <= 0) return VPS_EARG(1);
+    hipLaunchKernelGGL(axpb_kernel, dim3(stream_grid((long)npix * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       in, in_ld, in_coff, out, out_ld, out_coff, (long)npix, C, a, b);
+    return vps_launch_status();
+}
+
+extern "C" int vps_groupnorm_relu(const float* in, int in_ld, float* out, int out_ld, int64_t npix, int C, int G,
+                                  const float* gamma, const float* beta, float eps, int relu, double* stats, void* stream) {
+    if (!in || !out || !gamma || !beta || !stats || npix <= 0) return VPS_EARG(1);
+    if (C <= 0 || C > 256 || 256 % C || G <= 0 || C % G || G > 256) return VPS_EARG(2);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * G, s);
+    if (e != hipSuccess) return -(int)e;
+    const int ppb = 256 / C;
+    long g = (npix + ppb - 1) / ppb; if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3((unsigned)g), dim3(256), 0, s, in, in_ld, (long)npix, C, G, stats);
+    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(stream_grid((long)npix * C, 256)), dim3(256), 0, s, in, in_ld, out, out_ld,
+                       (long)npix, C, G, gamma, beta, eps, relu, stats);
+    return vps_launch_status();
+}
+
+extern "C" int vps_tcea_temporal(const float* emb, int emb_ld, const float* emb_ref, int ref_ld, const float* fea2, int fea_ld,
+                                 float* out, int out_ld, int64_t npix, int C, void* stream) {
+    if (!emb || !emb_ref || !fea2 || !out || npix <= 0 || C <= 0 || (C & 3)) return VPS_EARG(1);
+    if ((emb_ld & 3) || (ref_ld & 3) || (fea_ld & 3) || (out_ld & 3)) return VPS_EARG(2);
+    long g = (npix + 3) / 4; if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(tcea_temporal_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, emb, emb_ld, emb_ref, ref_ld,
+                       fea2, fea_ld, out, out_ld, (long)npix, C);
+    return vps_launch_status();
+}
+
+extern "C" int vps_tcea_modulate(const float* fea, const float* att, const float* att_add, float* out, int64_t n, void* stream) {
+    if (!fea || !att || !att_add || !out || n <= 0) return VPS_EARG(1);
+    hipLaunchKernelGGL(tcea_modulate_kernel, dim3(stream_grid((long)n, 256)), dim3(256), 0, (hipStream_t)stream, fea, att,
+                       att_add, out, (long)n);
+    return vps_launch_status();
+}

@@ -1,0 +1,170 @@
+// Panoptic head kernels: MaskRemoval (per-box overlap test on the device) and the fused
+// "upsample fcn_score x4 + SegTerm crop + mask-logit paste + argmax" combine.
+// Reference (relative to /root/reference/mmdet/models): utils/mask_removal.py:29-92,
+// utils/unary_logits.py:81-108, panoptic/upsnetFPN.py:81, detectors/panoptic_fusetrack.py:585-597.
+#include "common.h"
+
+namespace {
+
+// cv2.resize(src 28x28 float32, (w,h), INTER_LINEAR): half-pixel centres, source coordinate computed in
+// double then cast to float, edge taps clamped with zero weight, horizontal pass then vertical pass.
+__device__ __forceinline__ void cv_lin_coord(int d, int dst, int src, int& s0, int& s1, float& f) {
+    const double scale = (double)src / (double)dst;
+    float fx = (float)(((double)d + 0.5) * scale - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= src - 1) { fx = 0.f; sx = src - 1; }
+    s0 = sx;
+    s1 = min(sx + 1, src - 1);
+    f = fx;
+}
+
+__device__ __forceinline__ float resized_logit(const float* __restrict__ m28, int S, int dx, int dy, int w, int h) {
+    int x0, x1, y0, y1; float fx, fy;
+    cv_lin_coord(dx, w, S, x0, x1, fx);
+    cv_lin_coord(dy, h, S, y0, y1, fy);
+    const float r0 = m28[y0 * S + x0] * (1.f - fx) + m28[y0 * S + x1] * fx;
+    const float r1 = m28[y1 * S + x0] * (1.f - fx) + m28[y1 * S + x1] * fx;
+    return r0 * (1.f - fy) + r1 * fy;
+}
+
+struct BoxGeom {
+    int bx1, by1, w, h;      // int32-truncated box origin and resize target size
+    int x0, y0, x1, y1;      // clipped paste region [x0,x1) x [y0,y1)
+};
+
+__device__ __forceinline__ BoxGeom box_geom(int bx1, int by1, int bx2, int by2, int H, int W) {
+    BoxGeom g;
+    g.bx1 = bx1; g.by1 = by1;
+    g.w = max(bx2 - bx1 + 1, 1);
+    g.h = max(by2 - by1 + 1, 1);
+    g.x0 = max(bx1, 0); g.x1 = min(bx2 + 1, W);
+    g.y0 = max(by1, 0); g.y1 = min(by2 + 1, H);
+    return g;
+}
+
+// counts[0] += #(logit>0) inside the clipped box, counts[1] += #(logit>0 and occupancy>=1)
+__global__ __launch_bounds__(256)
+void mask_count_kernel(const float* __restrict__ logit, int S, int bx1, int by1, int bx2, int by2, int H, int W,
+                       const uint8_t* __restrict__ occ, int* __restrict__ counts) {
+    const BoxGeom g = box_geom(bx1, by1, bx2, by2, H, W);
+    const int rw = g.x1 - g.x0, rh = g.y1 - g.y0;
+    int ms = 0, ov = 0;
+    if (rw > 0 && rh > 0) {
+        const long total = (long)rw * rh;
+        for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+            const int xx = g.x0 + (int)(idx % rw), yy = g.y0 + (int)(idx / rw);
+            const float v = resized_logit(logit, S, xx - g.bx1, yy - g.by1, g.w, g.h);
+            if (v > 0.f) {
+                ++ms;
+                if (occ[(size_t)yy * W + xx] >= 1) ++ov;
+            }
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) { ms += __shfl_xor(ms, off, 64); ov += __shfl_xor(ov, off, 64); }
+    if ((threadIdx.x & 63) == 0 && (ms | ov)) { atomicAdd(&counts[0], ms); atomicAdd(&counts[1], ov); }
+}
+
+// keep iff mask_sum != 0 and overlap/mask_sum <= thr; kept boxes add their binary mask to the occupancy plane
+__global__ __launch_bounds__(256)
+void mask_commit_kernel(const float* __restrict__ logit, int S, int bx1, int by1, int bx2, int by2, int H, int W,
+                        uint8_t* __restrict__ occ, const int* __restrict__ counts, double thr, int* __restrict__ flag) {
+    const int ms = counts[0], ov = counts[1];
+    const bool keep = ms != 0 && !((double)ov / (double)ms > thr);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *flag = keep ? 1 : 0;
+    if (!keep) return;
+    const BoxGeom g = box_geom(bx1, by1, bx2, by2, H, W);
+    const int rw = g.x1 - g.x0, rh = g.y1 - g.y0;
+    if (rw <= 0 || rh <= 0) return;
+    const long total = (long)rw * rh;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int xx = g.x0 + (int)(idx % rw), yy = g.y0 + (int)(idx / rw);
+        const float v = resized_logit(logit, S, xx - g.bx1, yy - g.by1, g.w, g.h);
+        if (v > 0.f) occ[(size_t)yy * W + xx] += 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused panoptic combine. For every full-resolution pixel:
+//   fcn_output[c] = bilinear x4 (align_corners=False) of fcn_score[c]           (upsnetFPN.py:81)
+//   sem = argmax_c fcn_output[c]                                                 (panoptic_fusetrack.py:593)
+//   stuff logits = fcn_output[0:nstuff]; instance j logit = SegTerm crop + pasted mask logit
+//   pan = argmax over [stuff..., inst_0, inst_1, ...]  (softmax is monotone -> skipped; first max wins)
+// Nothing of size [k,H,W] is materialised (reference: three such fp32 tensors + a 159 MB fcn_output).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void panoptic_combine_kernel(const float* __restrict__ score, int score_ld, int Hs, int Ws, int nclass, int nstuff,
+                             const vps_pan_inst* __restrict__ inst, int k, const float* __restrict__ mask_logits, int S,
+                             uint8_t* __restrict__ pan, uint8_t* __restrict__ sem, int H, int W, int up) {
+    const long HW = (long)H * W;
+    const float rs = 1.0f / (float)up;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < HW; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W), y = (int)(idx / W);
+        float sy = rs * ((float)y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+        float sx = rs * ((float)x + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+        const int y0 = min((int)sy, Hs - 1), x0 = min((int)sx, Ws - 1);
+        const int yp = y0 < Hs - 1 ? 1 : 0, xp = x0 < Ws - 1 ? 1 : 0;
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float* p00 = score + ((size_t)y0 * Ws + x0) * score_ld;
+        const float* p01 = p00 + (size_t)xp * score_ld;
+        const float* p10 = p00 + (size_t)yp * Ws * score_ld;
+        const float* p11 = p10 + (size_t)xp * score_ld;
+        float best_sem = -INFINITY, best_pan = -INFINITY;
+        int i_sem = 0, i_pan = 0;
+        for (int c = 0; c < nclass; ++c) {
+            const float v = hy * (hx * p00[c] + lx * p01[c]) + ly * (hx * p10[c] + lx * p11[c]);
+            if (v > best_sem) { best_sem = v; i_sem = c; }
+            if (c < nstuff && v > best_pan) { best_pan = v; i_pan = c; }
+        }
+        for (int j = 0; j < k; ++j) {
+            const vps_pan_inst in = inst[j];
+            float v = 0.f;
+            if (x >= in.sx0 && x < in.sx1 && y >= in.sy0 && y < in.sy1) {
+                const int c = in.seg_ch;
+                v = hy * (hx * p00[c] + lx * p01[c]) + ly * (hx * p10[c] + lx * p11[c]);
+            }
+            const BoxGeom g = box_geom(in.bx1, in.by1, in.bx2, in.by2, H, W);
+            if (x >= g.x0 && x < g.x1 && y >= g.y0 && y < g.y1)
+                v += resized_logit(mask_logits + (size_t)in.mask_idx * S * S, S, x - g.bx1, y - g.by1, g.w, g.h);
+            if (v > best_pan) { best_pan = v; i_pan = nstuff + j; }
+        }
+        pan[idx] = (uint8_t)i_pan;
+        sem[idx] = (uint8_t)i_sem;
+    }
+}
+
+}  // namespace
+
+extern "C" int vps_mask_count(const float* logit, int S, int bx1, int by1, int bx2, int by2, int H, int W,
+                              const uint8_t* occ, int32_t* counts, void* stream) {
+    if (!logit || !occ || !counts || S < 2 || H <= 0 || W <= 0) return VPS_EARG(1);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), s);
+    if (e != hipSuccess) return -(int)e;
+    const long area = (long)max(min(bx2 + 1, W) - max(bx1, 0), 0) * max(min(by2 + 1, H) - max(by1, 0), 0);
+    hipLaunchKernelGGL(mask_count_kernel, dim3(stream_grid(area > 0 ? area : 1, 256)), dim3(256), 0, s, logit, S, bx1, by1,
+                       bx2, by2, H, W, occ, counts);
+    return vps_launch_status();
+}
+
+extern "C" int vps_mask_commit(const float* logit, int S, int bx1, int by1, int bx2, int by2, int H, int W, uint8_t* occ,
+                               const int32_t* counts, double thr, int32_t* flag, void* stream) {
+    if (!logit || !occ || !counts || !flag || S < 2 || H <= 0 || W <= 0) return VPS_EARG(1);
+    const long area = (long)max(min(bx2 + 1, W) - max(bx1, 0), 0) * max(min(by2 + 1, H) - max(by1, 0), 0);
+    hipLaunchKernelGGL(mask_commit_kernel, dim3(stream_grid(area > 0 ? area : 1, 256)), dim3(256), 0, (hipStream_t)stream,
+                       logit, S, bx1, by1, bx2, by2, H, W, occ, counts, thr, flag);
+    return vps_launch_status();
+}
+
+extern "C" int vps_panoptic_combine(const float* fcn_score, int score_ld, int Hs, int Ws, int nclass, int nstuff,
+                                    const vps_pan_inst* inst, int k, const float* mask_logits, int S,
+                                    uint8_t* pan, uint8_t* sem, int H, int W, void* stream) {
+    if (!fcn_score || !pan || !sem || Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0) return VPS_EARG(1);
+    if (k < 0 || k > 255 - nstuff || (k > 0 && (!inst || !mask_logits)) || nclass < nstuff || nstuff < 0) return VPS_EARG(2);
+    if (H % Hs || W % Ws || H / Hs != W / Ws) return VPS_EARG(3);
+    hipLaunchKernelGGL(panoptic_combine_kernel, dim3(stream_grid((long)H * W, 256)), dim3(256), 0, (hipStream_t)stream,
+                       fcn_score, score_ld, Hs, Ws, nclass, nstuff, inst, k, mask_logits, S, pan, sem, H, W, H / Hs);
+    return vps_launch_status();
+}
