@@ -1,0 +1,69 @@
+"""CPU-side checks of the drop-in boundary: libvpship.so loads and exports every symbol include/vps_hip.h
+declares; the ctypes structs match the C layout; the product fails loudly without a device."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+from vps_amd import hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'vps_hip.h')
+
+
+def _declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(vps_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = hip.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for s in declared:
+        assert hasattr(lib, s), 'libvpship.so does not export %s' % s
+    assert sorted(hip.SYMBOLS) == declared
+
+
+def test_abi_version_and_info():
+    lib = hip.load()
+    assert lib.vps_abi_version() == hip.ABI_VERSION
+    assert 'gfx950' in hip.build_info()
+
+
+def test_struct_layout_matches_c(tmp_path):
+    """compile a tiny C program against the header and compare sizeof/offsetof with the ctypes mirrors"""
+    src = tmp_path / 'layout.c'
+    src.write_text('''
+#include <stdio.h>
+#include <stddef.h>
+#include "vps_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(vps_conv_desc), offsetof(vps_conv_desc, w), offsetof(vps_conv_desc, out),
+         offsetof(vps_conv_desc, scale), offsetof(vps_conv_desc, offset), offsetof(vps_conv_desc, ws), offsetof(vps_conv_desc, tile_n));
+  printf("%zu %zu\\n", sizeof(vps_tensor4), sizeof(vps_pan_inst));
+  return 0; }
+''')
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    D = hip.ConvDesc
+    want = [ctypes.sizeof(D), D.w.offset, D.out.offset, D.scale.offset, D.offset.offset, D.ws.offset, D.tile_n.offset,
+            ctypes.sizeof(hip.Tensor4), ctypes.sizeof(hip.PanInst)]
+    assert [int(v) for v in out] == want
+
+
+def test_cpu_tensor_is_rejected_loudly():
+    with pytest.raises(hip.VpsHipError):
+        hip.ptr(torch.zeros(4))
+
+
+def test_bad_arguments_return_error_codes_without_a_gpu():
+    lib = hip.load()
+    d = hip.ConvDesc()
+    assert lib.vps_conv2d(ctypes.byref(d), None) <= -1000      # null pointers are rejected before any launch
+    assert lib.vps_conv2d(None, None) <= -1000

@@ -1,0 +1,308 @@
+"""GPU parity tests of the individual libvpship kernels (called through the C-ABI) against the CPU oracle
+(`oracle/`, the restatement of the reference operators) or, for the dense fp32 contraction, plain PyTorch-CPU fp32.
+
+Tolerances: the conv kernel is exact-fp32 MFMA (an fmaf chain) — it differs from the CPU only by summation
+order: |err| <= 2e-5 * (1 + |ref|) scaled by sqrt(K)-ish magnitudes is ample; gather kernels 1e-5 abs.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ops as O
+from oracle import fusetrack as OF
+from vps_amd import hip, nhwc
+
+pytestmark = pytest.mark.gpu
+
+
+def _cmp(got, ref, rtol=2e-5, atol=2e-5, what=''):
+    got = got.detach().cpu().double(); ref = ref.detach().cpu().double()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    assert not bad.any(), '%s: %d/%d bad, max abs err %.3e (ref max %.3e)' % (
+        what, int(bad.sum()), bad.numel(), float(err.max()), float(ref.abs().max()))
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------------ conv family
+CONV_CASES = [
+    # cin, cout, k, stride, pad, H, W, act, bn, res
+    (3, 64, 7, 2, 3, 64, 96, 'relu', True, False),      # ResNet stem / FlowNet conv1-like
+    (64, 64, 1, 1, 0, 32, 48, 'relu', True, False),
+    (64, 256, 1, 1, 0, 32, 48, 'relu', True, True),     # bottleneck conv3 + residual
+    (64, 64, 3, 1, 1, 33, 47, 'relu', True, False),     # ragged M
+    (128, 128, 3, 2, 1, 32, 48, 'relu', True, False),
+    (256, 512, 1, 2, 0, 16, 24, 'none', True, False),   # downsample
+    (6, 64, 3, 1, 1, 40, 56, 'leaky', False, False),    # FlowNetSD conv0 (cin pad 8)
+    (11, 64, 3, 1, 1, 40, 56, 'leaky', False, False),   # Fusion conv0 (cin pad 12)
+    (12, 64, 7, 2, 3, 64, 64, 'leaky', False, False),   # FlowNetS conv1
+    (64, 128, 5, 2, 2, 32, 32, 'leaky', False, False),
+    (194, 2, 3, 1, 1, 16, 24, 'none', False, False),    # predict_flow2 (cin not multiple of 4, cout 2)
+    (256, 18, 3, 1, 1, 16, 24, 'none', False, False),   # DCN offset conv
+    (512, 19, 1, 1, 0, 16, 24, 'none', False, False),   # conv_pred
+    (339, 64, 3, 1, 1, 16, 24, 'leaky', False, False),  # LiteFlowNet estimator input
+    (1024, 1024, 3, 1, 1, 4, 8, 'leaky', False, False), # conv6_1: deep, tiny M -> split-K
+    (512, 512, 3, 2, 1, 16, 16, 'leaky', False, False), # split-K, stride 2
+    (256, 36, 1, 1, 0, 7, 9, 'none', False, False),     # tile_n 64, tiny M
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'ci%d_co%d_k%d_s%d' % c[:4])
+def test_conv2d_matches_torch_cpu(dev, case):
+    cin, cout, k, stride, pad, H, W, act, bn, res = case
+    x = _rand(1, cin, H, W, seed=1)
+    w = _rand(cout, cin, k, k, seed=2, scale=(2.0 / (cin * k * k)) ** 0.5)
+    b = None if bn else _rand(cout, seed=3, scale=0.1)
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    bnd = None
+    if bn:
+        bnd = dict(weight=torch.rand(cout) + 0.5, bias=_rand(cout, seed=4, scale=0.1),
+                   running_mean=_rand(cout, seed=5, scale=0.1), running_var=torch.rand(cout) + 0.5, eps=1e-5)
+        ref = F.batch_norm(ref, bnd['running_mean'], bnd['running_var'], bnd['weight'], bnd['bias'], False, 0., 1e-5)
+    r = None
+    if res:
+        r = _rand(*ref.shape, seed=6)
+        ref = ref + r
+    a = {'none': hip.ACT_NONE, 'relu': hip.ACT_RELU, 'leaky': hip.ACT_LEAKY}[act]
+    ref = {'none': lambda t: t, 'relu': F.relu, 'leaky': lambda t: F.leaky_relu(t, 0.1)}[act](ref)
+    pc = nhwc.PackedConv(w, b, bnd, stride=stride, padding=pad, act=a, slope=0.1, device=dev)
+    ws = nhwc.Workspace(dev)
+    xm = nhwc.from_nchw(x.to(dev))
+    rm = nhwc.from_nchw(r.to(dev)) if res else None
+    out = pc(xm, ws=ws, name='out', res=rm)
+    torch.cuda.synchronize()
+    _cmp(out.to_nchw(), ref, what='conv %s' % (case,))
+
+
+def test_conv_writes_into_concat_window_and_reads_padded_window(dev):
+    """producer writes channels [128,192) of a 194(+2 pad)-wide concat buffer; a consumer reads all 194."""
+    H, W = 12, 20
+    ws = nhwc.Workspace(dev)
+    cat = ws.fmap('cat', 1, H, W, 194, ld=196)
+    a = _rand(1, 128, H, W, seed=1); b_in = _rand(1, 32, H, W, seed=2); c = _rand(1, 2, H, W, seed=3)
+    w = _rand(64, 32, 3, 3, seed=4, scale=0.1)
+    pc = nhwc.PackedConv(w, None, None, 1, 1, device=dev)
+    # fill windows 0..128 and 192..194 through the transpose kernel
+    lib = hip.load()
+    for t, off in ((a, 0), (c, 192)):
+        td = t.to(dev).contiguous()
+        hip.check(lib.vps_nchw_to_nhwc(hip.ptr(td), cat.ptr(), cat.ld, off, 1, t.shape[1], H, W, t.shape[1], hip.stream_ptr()), 't')
+    pc(nhwc.from_nchw(b_in.to(dev)), out=cat.window(128, 64))
+    full = torch.cat([a, F.conv2d(b_in, w, padding=1), c], 1)
+    _cmp(cat.to_nchw(), full, what='concat buffer')
+    w2 = _rand(2, 194, 3, 3, seed=5, scale=0.05)
+    p2 = nhwc.PackedConv(w2, _rand(2, seed=6), None, 1, 1, device=dev)
+    out = p2(cat, ws=ws, name='flow')
+    _cmp(out.to_nchw(), F.conv2d(full, w2, p2.shift.cpu(), padding=1), what='predict_flow on concat')
+
+
+@pytest.mark.parametrize('cin,cout,k,pad,H,W', [(1024, 512, 4, 1, 4, 8), (386, 64, 4, 1, 16, 24), (2, 2, 4, 1, 8, 12),
+                                                (256, 256, 2, 0, 14, 14), (162, 16, 4, 1, 20, 28)])
+def test_conv_transpose_matches_torch_cpu(dev, cin, cout, k, pad, H, W):
+    x = _rand(2 if k == 2 else 1, cin, H, W, seed=1)
+    w = _rand(cin, cout, k, k, seed=2, scale=(1.0 / (cin * k)) ** 0.5)
+    b = _rand(cout, seed=3, scale=0.1)
+    ref = F.leaky_relu(F.conv_transpose2d(x, w, b, stride=2, padding=pad), 0.1)
+    pc = nhwc.PackedConv(w, b, None, stride=2, padding=pad, act=hip.ACT_LEAKY, transposed=True, device=dev)
+    out = pc(nhwc.from_nchw(x.to(dev)), ws=nhwc.Workspace(dev), name='o')
+    _cmp(out.to_nchw(), ref, what='deconv')
+
+
+def test_fpn_topdown_residual_upsample(dev):
+    """lateral conv + nearest x2 upsample-add fused through res_shift=1 (necks/fpn.py:108-111)"""
+    x = _rand(1, 64, 16, 24, seed=1); top = _rand(1, 32, 8, 12, seed=2)
+    w = _rand(32, 64, 1, 1, seed=3, scale=0.1); b = _rand(32, seed=4)
+    ref = F.conv2d(x, w, b) + F.interpolate(top, scale_factor=2, mode='nearest')
+    pc = nhwc.PackedConv(w, b, None, 1, 0, device=dev)
+    out = pc(nhwc.from_nchw(x.to(dev)), ws=nhwc.Workspace(dev), name='o', res=nhwc.from_nchw(top.to(dev)), res_shift=1)
+    _cmp(out.to_nchw(), ref, what='fpn lateral')
+
+
+def test_linear_as_conv_with_nhwc_flatten(dev):
+    R, C, S = 37, 16, 49
+    feats_nchw = _rand(R, C, 7, 7, seed=1)
+    w = _rand(24, C * S, seed=2, scale=0.05); b = _rand(24, seed=3)
+    ref = F.relu(F.linear(feats_nchw.view(R, -1), w, b))
+    pl = nhwc.pack_linear(w, b, act=hip.ACT_RELU, device=dev, chw=(C, S))
+    nh = feats_nchw.permute(0, 2, 3, 1).contiguous().view(1, 1, R, S * C).to(dev)
+    out = pl(nhwc.FMap(nh), ws=nhwc.Workspace(dev), name='fc')
+    _cmp(out.t.view(R, 24), ref, what='linear')
+
+
+@pytest.mark.parametrize('cin,cout,H,W', [(256, 256, 12, 20), (256, 128, 9, 13), (128, 128, 16, 16)])
+def test_deform_conv_matches_oracle(dev, cin, cout, H, W):
+    x = _rand(1, cin, H, W, seed=1)
+    off = _rand(1, 18, H, W, seed=2, scale=1.5)
+    w = _rand(cout, cin, 3, 3, seed=3, scale=(2.0 / (cin * 9)) ** 0.5)
+    ref = O.deform_conv(x, off, w, 1, 1)
+    pc = nhwc.PackedConv(w, None, None, 1, 1, device=dev, deform=True)
+    out = pc(nhwc.from_nchw(x.to(dev)), ws=nhwc.Workspace(dev), name='o', offset=nhwc.from_nchw(off.to(dev)))
+    _cmp(out.to_nchw(), ref, what='deform conv')
+
+
+# ------------------------------------------------------------------------------------------------ flow ops
+@pytest.mark.parametrize('H,W,mag', [(32, 48, 3.0), (17, 23, 40.0)])
+def test_resample2d_nchw_api(dev, H, W, mag):
+    img = _rand(2, 3, H, W, seed=1); flow = _rand(2, 2, H, W, seed=2, scale=mag)
+    ref = O.resample2d(img, flow)
+    a, f = img.to(dev), flow.to(dev)
+    out = torch.empty_like(a)
+    hip.check(hip.load().vps_resample2d(hip.tensor4_nchw(a), hip.tensor4_nchw(f), hip.tensor4_nchw(out), 2, 3, H, W,
+                                        hip.stream_ptr()), 'resample2d')
+    _cmp(out, ref, rtol=1e-6, atol=1e-6, what='resample2d')
+
+
+def test_channelnorm(dev):
+    x = _rand(2, 3, 20, 28, seed=1)
+    a = x.to(dev); out = torch.empty(2, 1, 20, 28, device=dev)
+    hip.check(hip.load().vps_channelnorm(hip.tensor4_nchw(a), hip.tensor4_nchw(out), 2, 3, 20, 28, hip.stream_ptr()), 'cn')
+    _cmp(out, O.channelnorm(x), rtol=1e-6, atol=1e-7, what='channelnorm')
+
+
+@pytest.mark.parametrize('C,H,W,md,s2', [(256, 12, 20, 20, 2), (256, 16, 24, 4, 1), (64, 9, 11, 4, 1)])
+def test_correlation_matches_oracle(dev, C, H, W, md, s2):
+    a = _rand(1, C, H, W, seed=1); b = _rand(1, C, H, W, seed=2)
+    ref = F.leaky_relu(O.correlation(a, b, md, 1, md, 1, s2), 0.1)
+    D = (2 * (md // s2) + 1) ** 2
+    ws = nhwc.Workspace(dev)
+    out = ws.fmap('corr', 1, H, W, D)
+    nhwc.correlation(nhwc.from_nchw(a.to(dev)), nhwc.from_nchw(b.to(dev)), out, md, s2, hip.ACT_LEAKY, 0.1)
+    _cmp(out.to_nchw(), ref, rtol=1e-5, atol=1e-5, what='correlation')
+
+
+def test_flow_warp_matches_grid_sample(dev):
+    x = _rand(1, 64, 24, 40, seed=1); flow = _rand(1, 2, 24, 40, seed=2, scale=4.0)
+    ref = OF.warping_layer(x, flow)
+    ws = nhwc.Workspace(dev)
+    out = nhwc.flow_warp(nhwc.from_nchw(x.to(dev)), nhwc.from_nchw(flow.to(dev)), ws.fmap('w', 1, 24, 40, 64))
+    _cmp(out.to_nchw(), ref, rtol=1e-4, atol=1e-4, what='flow warp')
+
+
+# ------------------------------------------------------------------------------------------------ nn ops
+@pytest.mark.parametrize('mode,Hi,Wi,Ho,Wo', [('bilinear', 8, 12, 32, 48), ('nearest', 8, 12, 32, 48), ('bilinear', 32, 48, 8, 12),
+                                               ('bilinear', 6, 10, 12, 20), ('nearest', 16, 24, 8, 12)])
+def test_resize(dev, mode, Hi, Wi, Ho, Wo):
+    x = _rand(1, 19, Hi, Wi, seed=1)
+    ref = F.interpolate(x, size=(Ho, Wo), mode=mode, **({'align_corners': False} if mode == 'bilinear' else {})) * 0.25
+    ws = nhwc.Workspace(dev)
+    out = nhwc.resize(nhwc.from_nchw(x.to(dev)), ws.fmap('r', 1, Ho, Wo, 19), mode, 0.25)
+    _cmp(out.to_nchw(), ref, rtol=1e-6, atol=1e-6, what='resize')
+
+
+@pytest.mark.parametrize('mode', ['max', 'avg'])
+def test_pool3x3s2(dev, mode):
+    x = _rand(1, 64, 18, 26, seed=1)
+    ref = F.max_pool2d(x, 3, 2, 1) if mode == 'max' else F.avg_pool2d(x, 3, 2, 1)
+    ws = nhwc.Workspace(dev)
+    out = nhwc.pool3x3s2(nhwc.from_nchw(x.to(dev)), ws.fmap('p', 1, 9, 13, 64), mode)
+    _cmp(out.to_nchw(), ref, rtol=1e-6, atol=1e-6, what='pool')
+
+
+def test_bfp_gather_scatter(dev):
+    lv = [_rand(1, 32, 32 >> i, 64 >> i, seed=i) for i in range(5)]
+    ref = OF.bfp_gather(lv)
+    ws = nhwc.Workspace(dev)
+    maps = [nhwc.from_nchw(t.to(dev)) for t in lv]
+    out = nhwc.bfp_gather(maps, ws.fmap('g', 1, 32, 64, 32))
+    _cmp(out.to_nchw(), ref, rtol=1e-6, atol=1e-6, what='gather')
+    for i in range(5):
+        r = F.adaptive_max_pool2d(ref, lv[i].shape[2:]) + lv[i]
+        o = nhwc.bfp_scatter(out, maps[i], ws.fmap('s%d' % i, 1, 32 >> i, 64 >> i, 32))
+        _cmp(o.to_nchw(), r, rtol=1e-6, atol=1e-6, what='scatter %d' % i)
+
+
+@pytest.mark.parametrize('C', [256, 128])
+def test_groupnorm_relu(dev, C):
+    x = _rand(1, C, 20, 28, seed=1, scale=2.0) + 0.5
+    g = torch.rand(C) + 0.5; b = _rand(C, seed=2, scale=0.2)
+    ref = F.relu(F.group_norm(x, 32, g, b, 1e-5))
+    ws = nhwc.Workspace(dev)
+    stats = ws.get('st', (64,), dtype=torch.float64)
+    out = nhwc.groupnorm_relu(nhwc.from_nchw(x.to(dev)), ws.fmap('o', 1, 20, 28, C), 32, g.to(dev), b.to(dev), 1e-5, stats)
+    _cmp(out.to_nchw(), ref, rtol=1e-5, atol=1e-5, what='groupnorm')
+
+
+# ------------------------------------------------------------------------------------------------ detection ops
+def _rand_rois(n, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    cx = torch.rand(n, generator=g) * W; cy = torch.rand(n, generator=g) * H
+    s = torch.exp(torch.rand(n, generator=g) * math_log(16, 512))
+    ar = torch.exp((torch.rand(n, generator=g) - 0.5))
+    w = s * ar; h = s / ar
+    b = torch.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
+    b[:, 0::2] = b[:, 0::2].clamp(0, W - 1); b[:, 1::2] = b[:, 1::2].clamp(0, H - 1)
+    return torch.cat([torch.zeros(n, 1), b], 1)
+
+
+def math_log(lo, hi):
+    import math
+    return math.log(hi / lo)
+
+
+@pytest.mark.parametrize('P', [7, 14])
+def test_roi_align_multilevel(dev, P):
+    H, W = 256, 512
+    feats = [_rand(1, 32, H // s, W // s, seed=s) for s in (4, 8, 16, 32)]
+    rois = _rand_rois(200, H, W, seed=3)
+    ref = OF.roi_extract(feats, rois, P)
+    maps = [nhwc.from_nchw(f.to(dev)) for f in feats]
+    out = nhwc.roi_align(maps, [4, 8, 16, 32], rois.to(dev), P)
+    _cmp(out.permute(0, 3, 1, 2), ref, rtol=5e-5, atol=5e-5, what='roi align')
+
+
+def test_nms_batched_matches_oracle(dev):
+    lib = hip.load()
+    nb, nmax = 3, 700
+    counts = [700, 333, 64]
+    boxes = torch.zeros(nb, nmax, 5)
+    keeps_ref = []
+    for i, n in enumerate(counts):
+        r = _rand_rois(n, 300, 500, seed=10 + i)[:, 1:]
+        sc = torch.rand(n, generator=torch.Generator().manual_seed(20 + i))
+        sc, order = torch.sort(sc, descending=True)
+        d = torch.cat([r[order], sc[:, None]], 1)
+        boxes[i, :n] = d
+        keeps_ref.append(O._greedy_nms_sorted(d[:, :4].numpy(), 0.5))
+    bd = boxes.to(dev)
+    cd = torch.tensor(counts, dtype=torch.int32, device=dev)
+    cb = (nmax + 63) // 64
+    mask = torch.empty(nb * nmax * cb, dtype=torch.int64, device=dev)
+    keep = torch.full((nb, nmax), -1, dtype=torch.int32, device=dev)
+    nkeep = torch.zeros(nb, dtype=torch.int32, device=dev)
+    hip.check(lib.vps_nms_batched(hip.ptr(bd), nb, nmax, hip.ptr(cd), 0.5, hip.ptr(mask), hip.ptr(keep), hip.ptr(nkeep),
+                                  hip.stream_ptr()), 'nms')
+    nk = nkeep.cpu().numpy(); kp = keep.cpu().numpy()
+    for i in range(nb):
+        assert nk[i] == len(keeps_ref[i])
+        assert np.array_equal(kp[i, :nk[i]], keeps_ref[i])
+
+
+def test_delta2bbox_overlaps_softmax(dev):
+    lib = hip.load()
+    n = 500
+    anchors = _rand_rois(n, 256, 512, seed=1)[:, 1:]
+    deltas = _rand(n, 4, seed=2, scale=0.5); scores = torch.rand(n)
+    ref = torch.cat([OF.delta2bbox(anchors, deltas, (0, 0, 0, 0), (1, 1, 1, 1), (256, 512)), scores[:, None]], 1)
+    out = torch.empty(n, 5, device=dev)
+    ad, dd, sd_ = anchors.to(dev), deltas.to(dev), scores.to(dev)   # keep the device tensors alive across the launch
+    hip.check(lib.vps_delta2bbox(hip.ptr(ad), hip.ptr(dd), hip.ptr(sd_), hip.ptr(out), n,
+                                 1., 1., 1., 1., 256., 512., hip.stream_ptr()), 'd2b')
+    _cmp(out, ref, rtol=1e-5, atol=1e-4, what='delta2bbox')
+    a = _rand_rois(40, 256, 512, seed=3)[:, 1:]; b = _rand_rois(70, 256, 512, seed=4)[:, 1:]
+    o = torch.empty(40, 70, device=dev)
+    a_d, b_d = a.to(dev), b.to(dev)
+    hip.check(lib.vps_bbox_overlaps(hip.ptr(a_d), 4, 40, hip.ptr(b_d), 4, 70, hip.ptr(o), hip.stream_ptr()), 'iou')
+    _cmp(o, OF.bbox_overlaps(a, b), rtol=1e-6, atol=1e-7, what='iou')
+    x = _rand(300, 9, seed=5, scale=3.0)
+    for mode, fn in ((0, F.softmax), (1, F.log_softmax)):
+        o = torch.empty(300, 9, device=dev)
+        xd = x.to(dev)
+        hip.check(lib.vps_row_softmax(hip.ptr(xd), hip.ptr(o), 300, 9, mode, hip.stream_ptr()), 'sm')
+        _cmp(o, fn(x, dim=1), rtol=1e-5, atol=1e-6, what='softmax')

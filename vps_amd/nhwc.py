@@ -1,0 +1,326 @@
+"""NHWC activation maps, persistent device workspace and packed convolution weights for libvpship.
+
+Layout: every activation is a device tensor [N, H, W, ld] fp32; a feature map (`FMap`) is a channel window
+[coff, coff+C) of it. Producers write directly into windows of concat buffers, so the reference's torch.cat calls
+(FlowNet2 decoders, LiteFlowNet input, TCEA stack, UPSNet head) never materialise. Pad channels of a buffer are
+zero (buffers come from `Workspace.get(..., zero=True)` once and pads are never written).
+"""
+import ctypes
+import math
+from ctypes import c_float, c_int, c_void_p
+
+import torch
+
+from . import hip
+
+
+def _ceil(a, b):
+    return (a + b - 1) // b * b
+
+
+class FMap:
+    __slots__ = ('t', 'C', 'coff')
+
+    def __init__(self, t, C=None, coff=0):
+        assert t.dim() == 4 and t.dtype == torch.float32 and t.is_contiguous()
+        self.t = t
+        self.C = t.shape[3] if C is None else C
+        self.coff = coff
+        assert self.coff + self.C <= t.shape[3]
+
+    N = property(lambda s: s.t.shape[0])
+    H = property(lambda s: s.t.shape[1])
+    W = property(lambda s: s.t.shape[2])
+    ld = property(lambda s: s.t.shape[3])
+    npix = property(lambda s: s.t.shape[0] * s.t.shape[1] * s.t.shape[2])
+
+    def window(self, coff, C):
+        return FMap(self.t, C, self.coff + coff)
+
+    def ptr(self):
+        return hip.ptr(self.t)
+
+    def to_nchw(self):
+        """[N,C,H,W] contiguous copy through the HIP transpose kernel (API boundary / tests)."""
+        out = torch.empty(self.N, self.C, self.H, self.W, dtype=torch.float32, device=self.t.device)
+        hip.check(hip.load().vps_nhwc_to_nchw(self.ptr(), self.ld, self.coff, hip.ptr(out), self.N, self.C, self.H, self.W,
+                                              hip.stream_ptr()), 'vps_nhwc_to_nchw')
+        return out
+
+
+class Workspace:
+    """Named persistent device buffers (one per activation of the frame graph). Reused across frames: the path is a
+    single in-order stream, so reuse is safe, the allocator is never on the critical path, and pad lanes stay zero."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.bufs = {}
+
+    def get(self, name, shape, dtype=torch.float32, zero=True):
+        key = name
+        t = self.bufs.get(key)
+        shape = tuple(int(s) for s in shape)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self.bufs[key] = t
+        return t
+
+    def fmap(self, name, N, H, W, C, ld=None):
+        ld = _ceil(C, 4) if ld is None else ld
+        return FMap(self.get(name, (N, H, W, ld)), C, 0)
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+
+def from_nchw(x, ws=None, name=None, Cpad=None):
+    """NCHW device tensor -> FMap (HIP transpose, pads zeroed)."""
+    N, C, H, W = x.shape
+    ld = _ceil(C, 4) if Cpad is None else Cpad
+    x = x.contiguous()
+    t = ws.get(name, (N, H, W, ld)) if ws is not None else torch.zeros(N, H, W, ld, dtype=torch.float32, device=x.device)
+    hip.check(hip.load().vps_nchw_to_nhwc(hip.ptr(x), hip.ptr(t), ld, 0, N, C, H, W, ld, hip.stream_ptr()), 'vps_nchw_to_nhwc')
+    return FMap(t, C, 0)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# packed convolution
+# ------------------------------------------------------------------------------------------------------------
+def _tile_n(cout):
+    return 32 if cout <= 32 else (64 if cout <= 64 else 128)
+
+
+class PackedConv:
+    """One conv / transposed conv / linear / deformable conv of the path, packed for vps_conv2d.
+
+    weight: Conv2d [O,I,kh,kw] (transposed=False) or ConvTranspose2d [I,O,kh,kw] (transposed=True, stride 2).
+    bn: optional dict(weight,bias,running_mean,running_var,eps) folded into the epilogue (eval BatchNorm).
+    """
+
+    def __init__(self, weight, bias=None, bn=None, stride=1, padding=0, act=hip.ACT_NONE, slope=0.1,
+                 transposed=False, deform=False, device='cuda'):
+        w = weight.detach().float().cpu()
+        self.stride = stride
+        self.act, self.slope = act, float(slope)
+        self.deform = deform
+        self.transposed = transposed
+        if not transposed:
+            O, I, kh, kw = w.shape
+            self.nclass, self.os = 1, 1
+            self.KH, self.KW = kh, kw
+            self.pad_y = (padding, padding)
+            self.pad_x = (padding, padding)
+            cin_pad = _ceil(I, 4)
+            wp = torch.zeros(O, kh, kw, cin_pad)
+            wp[..., :I] = w.permute(0, 2, 3, 1)
+            blocks = [wp.reshape(O, kh * kw * cin_pad)]
+        else:
+            I, O, kh, kw = w.shape
+            assert stride == 2 and kh == kw and kh % 2 == 0, 'only stride-2 even-kernel transposed convs are on the path'
+            self.nclass, self.os = 4, 2
+            self.stride = 1
+            kc = kh // 2
+            self.KH = self.KW = kc
+            cin_pad = _ceil(I, 4)
+            pads, taps = [], []
+            for par in range(2):
+                r = (par + padding) & 1
+                d = (par + padding - r) // 2
+                pads.append((kc - 1) - d)
+                taps.append([r + 2 * ((kc - 1) - u) for u in range(kc)])  # kernel index used by tap u
+            self.pad_y = tuple(pads)
+            self.pad_x = tuple(pads)
+            blocks = []
+            for py in range(2):
+                for px in range(2):
+                    wp = torch.zeros(O, kc, kc, cin_pad)
+                    for uy in range(kc):
+                        for ux in range(kc):
+                            wp[:, uy, ux, :I] = w[:, :, taps[py][uy], taps[px][ux]].t()
+                    blocks.append(wp.reshape(O, kc * kc * cin_pad))
+        self.cin, self.cin_pad, self.cout = I, cin_pad, O
+        self.tile_n = _tile_n(O)
+        self.cout_pad = _ceil(O, self.tile_n)
+        K = self.KH * self.KW * cin_pad
+        self.kpad = _ceil(K, 32)
+        packed = torch.zeros(self.nclass, self.cout_pad, self.kpad)
+        for c, b in enumerate(blocks):
+            packed[c, :O, :K] = b
+        self.w = packed.to(device)
+        # epilogue: y = acc*scale + shift
+        scale = torch.ones(O)
+        shift = torch.zeros(O) if bias is None else bias.detach().float().cpu().clone()
+        if bn is not None:
+            g = bn['weight'].detach().float().cpu(); b = bn['bias'].detach().float().cpu()
+            m = bn['running_mean'].detach().float().cpu(); v = bn['running_var'].detach().float().cpu()
+            s = g / torch.sqrt(v + bn.get('eps', 1e-5))
+            shift = (shift - m) * s + b
+            scale = s
+            self.has_scale = True
+        else:
+            self.has_scale = False
+        self.scale = scale.to(device) if self.has_scale else None
+        self.shift = shift.to(device) if (bias is not None or bn is not None) else None
+
+    def out_hw(self, H, W):
+        if self.transposed:
+            return 2 * H, 2 * W
+        p = self.pad_y[0]
+        return (H + 2 * p - self.KH) // self.stride + 1, (W + 2 * p - self.KW) // self.stride + 1
+
+    def __call__(self, x, out=None, ws=None, name=None, res=None, res_shift=0, offset=None, act=None):
+        """x: FMap. out: FMap window to write (allocated from `ws` under `name` if None)."""
+        assert x.C == self.cin or (x.C >= self.cin and x.C <= self.cin_pad), (x.C, self.cin)
+        assert x.coff % 4 == 0 and x.ld % 4 == 0 and x.coff + self.cin_pad <= x.ld, (x.coff, x.ld, self.cin_pad)
+        Ho, Wo = self.out_hw(x.H, x.W)
+        if out is None:
+            out = ws.fmap(name, x.N, Ho, Wo, self.cout)
+        assert (out.N, out.H, out.W) == (x.N, Ho, Wo) and out.C == self.cout, ((out.N, out.H, out.W, out.C), (x.N, Ho, Wo, self.cout))
+        d = hip.ConvDesc()
+        d.inp = x.t.data_ptr(); d.N, d.H, d.W = x.N, x.H, x.W
+        d.in_ld, d.in_coff, d.cin_pad = x.ld, x.coff, self.cin_pad
+        d.w = self.w.data_ptr(); d.cout, d.cout_pad, d.kpad = self.cout, self.cout_pad, self.kpad
+        d.KH, d.KW, d.stride = self.KH, self.KW, self.stride
+        d.pad_y[0], d.pad_y[1] = self.pad_y; d.pad_x[0], d.pad_x[1] = self.pad_x
+        d.out = out.t.data_ptr(); d.Ho, d.Wo, d.out_ld, d.out_coff = Ho, Wo, out.ld, out.coff
+        if self.transposed:
+            d.Qh, d.Qw, d.os_y, d.os_x, d.nclass = x.H, x.W, 2, 2, 4
+        else:
+            d.Qh, d.Qw, d.os_y, d.os_x, d.nclass = Ho, Wo, 1, 1, 1
+        d.scale = self.scale.data_ptr() if self.scale is not None else None
+        d.shift = self.shift.data_ptr() if self.shift is not None else None
+        if res is not None:
+            d.res = res.t.data_ptr(); d.res_ld, d.res_coff, d.res_shift = res.ld, res.coff, res_shift
+            assert res.C == self.cout and res.H == (Ho >> res_shift) and res.W == (Wo >> res_shift)
+        d.act = self.act if act is None else act
+        d.slope = self.slope
+        if self.deform:
+            assert offset is not None and offset.coff == 0 and offset.C >= 2 * self.KH * self.KW
+            d.offset = offset.t.data_ptr(); d.off_ld = offset.ld
+        d.tile_n = self.tile_n
+        # split-K for launches that cannot fill 256 CUs
+        M = x.N * d.Qh * d.Qw
+        tiles = ((M + 127) // 128) * (self.cout_pad // self.tile_n) * d.nclass
+        ksteps = self.kpad // 32
+        ksplit = 1
+        if tiles < 256 and ksteps >= 8:
+            ksplit = max(1, min((512 + tiles - 1) // tiles, ksteps // 4, 32))
+            per = (ksteps + ksplit - 1) // ksplit
+            ksplit = (ksteps + per - 1) // per
+        d.ksplit = ksplit
+        if ksplit > 1:
+            need = ksplit * d.nclass * M * self.cout_pad
+            if ws is not None:
+                wsb = ws.bufs.get('__splitk_ws')
+                if wsb is None or wsb.numel() < need:
+                    wsb = torch.empty(max(need, 1 << 24), dtype=torch.float32, device=x.t.device)
+                    ws.bufs['__splitk_ws'] = wsb
+            else:
+                wsb = torch.empty(need, dtype=torch.float32, device=x.t.device)
+            d.ws = wsb.data_ptr()
+            self._last_ws = wsb  # keep alive until the next call
+        hip.conv2d(d)
+        return out
+
+    def flops(self, x_N, x_H, x_W):
+        """algorithmic FLOPs (2*MACs, unpadded) of one call on an input of that size."""
+        if self.transposed:
+            return 2.0 * x_N * x_H * x_W * 4 * self.cout * self.cin * self.KH * self.KW
+        Ho, Wo = self.out_hw(x_H, x_W)
+        return 2.0 * x_N * Ho * Wo * self.cout * self.cin * self.KH * self.KW
+
+
+def pack_conv_module(m, bn=None, act=hip.ACT_NONE, slope=0.1, device='cuda', deform=False):
+    """torch.nn.Conv2d / ConvTranspose2d (used purely as a parameter container) -> PackedConv."""
+    import torch.nn as nn
+    bnd = None
+    if bn is not None:
+        bnd = dict(weight=bn.weight, bias=bn.bias, running_mean=bn.running_mean, running_var=bn.running_var, eps=bn.eps)
+    if isinstance(m, nn.ConvTranspose2d):
+        return PackedConv(m.weight, m.bias, bnd, stride=m.stride[0], padding=m.padding[0], act=act, slope=slope,
+                          transposed=True, device=device)
+    return PackedConv(m.weight, m.bias, bnd, stride=m.stride[0], padding=m.padding[0], act=act, slope=slope,
+                      device=device, deform=deform)
+
+
+def pack_linear(weight, bias, act=hip.ACT_NONE, device='cuda', chw=None):
+    """nn.Linear as a 1x1 conv over `rows` pixels. chw=(C,S): the reference flattens NCHW [C, S=h*w] while the NHWC
+    RoI features flatten as [S, C] -> permute the weight columns once at pack time."""
+    w = weight.detach().float().cpu()
+    if chw is not None:
+        C, S = chw
+        w = w.view(w.shape[0], C, S).permute(0, 2, 1).reshape(w.shape[0], C * S)
+    return PackedConv(w.view(w.shape[0], w.shape[1], 1, 1), bias, None, 1, 0, act=act, device=device)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# thin FMap-level wrappers of the other kernels
+# ------------------------------------------------------------------------------------------------------------
+def resize(x, out, mode='bilinear', alpha=1.0):
+    hip.check(hip.load().vps_resize(x.ptr(), x.ld, x.coff, x.H, x.W, out.ptr(), out.ld, out.coff, out.H, out.W,
+                                    x.N, x.C, 0 if mode == 'bilinear' else 1, float(alpha), hip.stream_ptr()), 'vps_resize')
+    return out
+
+
+def pool3x3s2(x, out, mode='max'):
+    hip.check(hip.load().vps_pool3x3s2(x.ptr(), x.ld, x.coff, x.H, x.W, out.ptr(), out.ld, out.coff, x.N, x.C,
+                                       0 if mode == 'max' else 1, hip.stream_ptr()), 'vps_pool3x3s2')
+    return out
+
+
+def correlation(x1, x2, out, max_disp, stride2, act=hip.ACT_NONE, slope=0.1):
+    assert x1.C == x2.C
+    hip.check(hip.load().vps_correlation(x1.ptr(), x1.ld, x1.coff, x2.ptr(), x2.ld, x2.coff, out.ptr(), out.ld, out.coff,
+                                         x1.N, x1.H, x1.W, x1.C, max_disp, stride2, act, float(slope), hip.stream_ptr()),
+              'vps_correlation')
+    return out
+
+
+def flow_warp(x, flow, out):
+    hip.check(hip.load().vps_flow_warp(x.ptr(), x.ld, x.coff, flow.ptr(), flow.ld, flow.coff, out.ptr(), out.ld, out.coff,
+                                       x.N, x.H, x.W, x.C, hip.stream_ptr()), 'vps_flow_warp')
+    return out
+
+
+def bfp_gather(levels, out):
+    n = len(levels)
+    ptrs = (c_void_p * n)(*[l.t.data_ptr() for l in levels])
+    lds = (c_int * n)(*[l.ld for l in levels])
+    ratios = (c_int * n)(*[levels[0].H // l.H for l in levels])
+    for l in levels:
+        assert l.coff == 0
+    hip.check(hip.load().vps_bfp_gather(ptrs, lds, ratios, n, out.ptr(), out.ld, out.coff, out.N, out.H, out.W, out.C,
+                                        hip.stream_ptr()), 'vps_bfp_gather')
+    return out
+
+
+def bfp_scatter(bsf, level, out):
+    assert bsf.coff == 0 and level.coff == 0 and out.coff == 0
+    hip.check(hip.load().vps_bfp_scatter(bsf.ptr(), bsf.ld, level.ptr(), level.ld, out.ptr(), out.ld, bsf.N, bsf.H, bsf.W,
+                                         bsf.C, bsf.H // level.H, hip.stream_ptr()), 'vps_bfp_scatter')
+    return out
+
+
+def groupnorm_relu(x, out, G, gamma, beta, eps, stats, relu=True):
+    assert x.coff == 0 and out.coff == 0 and x.N == 1
+    hip.check(hip.load().vps_groupnorm_relu(x.ptr(), x.ld, out.ptr(), out.ld, x.npix, x.C, G, hip.ptr(gamma), hip.ptr(beta),
+                                            float(eps), 1 if relu else 0, hip.ptr(stats), hip.stream_ptr()), 'vps_groupnorm_relu')
+    return out
+
+
+def roi_align(levels, strides, rois, P, sample_num=2, finest_scale=56.0, out=None):
+    """levels: list of FMap (coff 0); rois: device [R,5] -> device tensor [R,P,P,C] (NHWC)."""
+    n = len(levels)
+    R = rois.shape[0]
+    C = levels[0].C
+    if out is None:
+        out = torch.empty(R, P, P, C, dtype=torch.float32, device=rois.device)
+    ptrs = (c_void_p * n)(*[l.t.data_ptr() for l in levels])
+    lds = (c_int * n)(*[l.ld for l in levels])
+    Hs = (c_int * n)(*[l.H for l in levels])
+    Ws = (c_int * n)(*[l.W for l in levels])
+    sc = (c_float * n)(*[1.0 / s for s in strides])
+    rois = rois.contiguous()
+    hip.check(hip.load().vps_roi_align(ptrs, lds, Hs, Ws, sc, n, float(finest_scale), hip.ptr(rois), R, C, P, sample_num,
+                                       hip.ptr(out), hip.stream_ptr()), 'vps_roi_align')
+    return out
