@@ -160,15 +160,18 @@ int vps_flow_stage(const float* x6, int x_ld, const float* flow_lo, int flo_ld, 
                    int diffnorm_off, int flownorm_off, int img_off, void* stream);
 
 /* GroupNorm(G) + ReLU over NHWC (N=1): stats pass then apply pass. ref: upsnetFPN.py:39-52 (GroupNorm(32)).
- * `stats` workspace: 2*G doubles (zeroed by the call). */
-int vps_groupnorm_relu(const float* in, int in_ld, float* out, int out_ld, int64_t npix, int C, int G,
+ * in is a coff-0 buffer, the result goes to out[.., out_coff + c]. `stats` workspace: 2*G doubles (zeroed by the call). */
+int vps_groupnorm_relu(const float* in, int in_ld, float* out, int out_ld, int out_coff, int64_t npix, int C, int G,
                        const float* gamma, const float* beta, float eps, int relu,
                        double* stats, void* stream);
 
-/* TCEA temporal attention. ref: tcea_modules.py:50-65. emb [npix][2*C] (frame-major: tAtt_1 of both frames),
- * emb_ref [npix][C]; fea2 [npix][2*C] (bsf | warp_bsf) -> out = fea2 * sigmoid(sum_c emb_i*emb_ref) per frame */
+/* TCEA temporal attention, N=2 frames, center 0. ref: utils/tcea_modules.py:50-65.
+ * emb [npix][>=2C] holds tAtt_1(frame0) in channels [0,C) and tAtt_1(frame1) in [C,2C); emb_ref = tAtt_2(frame0);
+ * fea0/fea1 are the two aligned frames (pointers already offset to their first channel, 16B aligned).
+ * out[npix][2C] = [fea0 * sigmoid(<emb0,emb_ref>) | fea1 * sigmoid(<emb1,emb_ref>)] (frame-major channels). */
 int vps_tcea_temporal(const float* emb, int emb_ld, const float* emb_ref, int ref_ld,
-                      const float* fea2, int fea_ld, float* out, int out_ld, int64_t npix, int C, void* stream);
+                      const float* fea0, int f0_ld, const float* fea1, int f1_ld,
+                      float* out, int out_ld, int64_t npix, int C, void* stream);
 /* out = fea * sigmoid(att) * 2 + att_add. ref: tcea_modules.py:74-77 */
 int vps_tcea_modulate(const float* fea, const float* att, const float* att_add, float* out,
                       int64_t n, void* stream);

@@ -482,6 +482,7 @@ class FuseTrackOracle:
         rgbs = torch.stack([denorm(img), denorm(ref_img)], dim=2)
         assert rgbs.size(-2) % 64 == 0 and rgbs.size(-1) % 64 == 0
         flow = flownet2(self.sd, 'flownet2.', rgbs)
+        self.last_flow_full = flow
         return F.interpolate(flow, scale_factor=scale_factor, mode='bilinear', align_corners=False) * scale_factor
 
     def extract_feat(self, img):
@@ -565,5 +566,5 @@ class FuseTrackOracle:
         det = self.detect(x, tuple(img.shape[2:]), is_first, inject)
         pano = self.panoptic(x, fcn_output, det, inject)
         if return_aux:
-            pano.update(flow=flow, feats=x, pre_neck=pre_neck, fcn_score=fcn_score, det=det)
+            pano.update(flow=flow, flow_full=self.last_flow_full, feats=x, pre_neck=pre_neck, fcn_score=fcn_score, det=det)
         return pano

@@ -1,0 +1,122 @@
+"""Generate the golden vectors of tests/golden/*.npz by running the REAL reference detector code
+(/root/reference/mmdet/models/detectors/panoptic_fusetrack.py and everything it builds) on the CPU of the build
+container, with the import shims of ref_shims.py (third-party stubs + oracle-backed stand-ins for the CUDA-only ops).
+
+    python tests/golden/make_golden.py            # needs /root/reference; writes tests/golden/fusetrack_clip.npz etc.
+
+The reference cannot travel to the GPU box; the vectors do. tests/test_oracle_golden.py checks the oracle against them
+(CPU), tests/test_fusetrack_gpu.py checks the HIP path against the oracle and against these vectors (GPU).
+Weights: vps_amd.synth.synth_state_dict (per-key seeded, no checkpoint exists offline). Inputs: vps_amd.synth.synth_clip.
+"""
+import os
+import sys
+import tempfile
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+warnings.simplefilter('ignore')
+
+H, W, NFRAMES, SEED = 128, 256, 3, 0
+
+
+def main():
+    import ref_shims
+    mods = ref_shims.install()
+    from vps_amd import synth
+    from vps_amd.registry import Config, ConfigDict
+    import vps_amd
+
+    cfg = Config.fromfile('/root/reference/configs/cityscapes/fusetrack.py')
+    # --- shapes of every parameter, from OUR containers; the reference model must expose exactly the same keys ---
+    ours = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    shapes = {k: tuple(v.shape) for k, v in ours.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, SEED)
+
+    # --- the reference detector; its __init__ loads FlowNet2 from cwd/work_dirs/flownet/FlowNet2_checkpoint.pth.tar ---
+    tmp = tempfile.mkdtemp(prefix='vps_golden_')
+    os.makedirs(os.path.join(tmp, 'work_dirs', 'flownet'))
+    torch.save({'state_dict': {k[len('flownet2.'):]: v for k, v in sd.items() if k.startswith('flownet2.')}},
+               os.path.join(tmp, 'work_dirs', 'flownet', 'FlowNet2_checkpoint.pth.tar'))
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        builder = sys.modules['mmdet.models.builder']
+        model_cfg = ConfigDict.wrap(dict(cfg.model))
+        model_cfg['pretrained'] = None
+        ref = builder.build_detector(model_cfg, train_cfg=None, test_cfg=cfg.test_cfg)
+    finally:
+        os.chdir(cwd)
+    ref.eval()
+    ref_shapes = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    missing = sorted(set(ref_shapes) - set(shapes)); extra = sorted(set(shapes) - set(ref_shapes))
+    assert not missing and not extra, ('state_dict key mismatch', missing[:10], extra[:10])
+    bad = [k for k in shapes if shapes[k] != ref_shapes[k]]
+    assert not bad, ('shape mismatch', bad[:10])
+    print('state_dict: %d keys identical to the reference module tree' % len(shapes))
+    ref.load_state_dict(sd)
+
+    # --- hooks on the stage boundaries ---
+    cap = {}
+
+    def hook(name):
+        def f(mod, inp, out):
+            cap.setdefault(name, []).append(out)
+        return f
+    ref.flownet2.register_forward_hook(hook('flownet2'))
+    ref.extra_neck.register_forward_hook(hook('extra_neck'))
+    ref.panopticFPN.register_forward_hook(hook('panopticFPN'))
+    ref.bbox_head.register_forward_hook(hook('bbox_head'))
+    ref.mask_head.register_forward_hook(hook('mask_head'))
+    ref.neck.register_forward_hook(hook('neck'))
+    orig_rpn = ref.simple_test_rpn
+
+    def rpn_wrap(*a, **k):
+        r = orig_rpn(*a, **k)
+        cap.setdefault('proposals', []).append(r[0])
+        return r
+    ref.simple_test_rpn = rpn_wrap
+
+    frames = synth.synth_clip(H, W, NFRAMES, SEED)
+    out = {}
+    with torch.no_grad():
+        for t in range(NFRAMES):
+            img = frames[t]
+            ref_img = frames[t - 1] if t > 0 else frames[0]
+            meta = synth.img_meta(H, W, 10000 + t + 1)
+            cap.clear()
+            bbox_res, mask_res, pano = ref(return_loss=False, rescale=True, img=[img], img_meta=[[meta]], ref_img=[ref_img])
+            p = 'f%d.' % t
+            out[p + 'fcn_outputs'] = pano['fcn_outputs'].numpy().astype(np.uint8)
+            out[p + 'panoptic_outputs'] = pano['panoptic_outputs'].numpy().astype(np.uint8)
+            out[p + 'panoptic_cls_inds'] = pano['panoptic_cls_inds'].numpy()
+            out[p + 'panoptic_cls_prob'] = pano['panoptic_cls_prob'].numpy()
+            out[p + 'panoptic_det_labels'] = pano['panoptic_det_labels'].numpy()
+            out[p + 'panoptic_det_obj_ids'] = np.asarray(pano['panoptic_det_obj_ids'].numpy())
+            out[p + 'bbox_ids'] = np.array(sorted(int(k) for k in bbox_res.keys()), dtype=np.int64)
+            out[p + 'flow_full'] = cap['flownet2'][0][0][:, ::2, ::2].numpy()   # stride-2 subsample
+            # neck is called twice (img, ref_img): first call = target frame
+            out[p + 'fpn_p2'] = cap['neck'][0][0][0, :8].numpy()          # first 8 channels of P2
+            out[p + 'fpn_p5'] = cap['neck'][0][3][0].numpy()
+            out[p + 'neck_out_p2'] = cap['extra_neck'][0][0][0, :8].numpy()
+            out[p + 'neck_out_p6'] = cap['extra_neck'][0][4][0].numpy()
+            out[p + 'fcn_score'] = cap['panopticFPN'][0][1][0].numpy()
+            out[p + 'proposals'] = cap['proposals'][0].numpy()
+            out[p + 'cls_score'] = cap['bbox_head'][0][0].numpy()
+            out[p + 'bbox_pred'] = cap['bbox_head'][0][1].numpy()
+            out[p + 'mask_pred'] = cap['mask_head'][0][:8].numpy()          # first 8 detections
+            print('frame %d: K=%d kept=%d ids=%s' % (t, cap['mask_head'][0].shape[0], len(out[p + 'panoptic_cls_inds']),
+                                                    out[p + 'panoptic_det_obj_ids'][:8]))
+    out['meta'] = np.array([H, W, NFRAMES, SEED], dtype=np.int64)
+    path = os.path.join(HERE, 'fusetrack_clip.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path) / 1e6, 'MB')
+
+
+if __name__ == '__main__':
+    main()

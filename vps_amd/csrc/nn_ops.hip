@@ -175,7 +175,7 @@ void groupnorm_stats_kernel(const float* __restrict__ in, int in_ld, long npix, 
 }
 
 __global__ __launch_bounds__(256)
-void groupnorm_apply_kernel(const float* __restrict__ in, int in_ld, float* __restrict__ out, int out_ld, long npix,
+void groupnorm_apply_kernel(const float* __restrict__ in, int in_ld, float* __restrict__ out, int out_ld, int out_coff, long npix,
                             int C, int G, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                             int relu, const double* __restrict__ stats) {
     const long total = npix * C;
@@ -202,7 +202,8 @@ void groupnorm_apply_kernel(const float* __restrict__ in, int in_ld, float* __re
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
 void tcea_temporal_kernel(const float* __restrict__ emb, int emb_ld, const float* __restrict__ emb_ref, int ref_ld,
-                          const float* __restrict__ fea2, int fea_ld, float* __restrict__ out, int out_ld, long npix, int C) {
+                          const float* __restrict__ fea0, int f0_ld, const float* __restrict__ fea1, int f1_ld,
+                          float* __restrict__ out, int out_ld, long npix, int C) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c4n = C >> 2;
     for (long pix = (long)blockIdx.x * 4 + wave; pix < npix; pix += (long)gridDim.x * 4) {
@@ -221,8 +222,8 @@ void tcea_temporal_kernel(const float* __restrict__ emb, int emb_ld, const float
         const float p0 = 1.f / (1.f + expf(-cor0));
         const float p1 = 1.f / (1.f + expf(-cor1));
         for (int c4 = lane; c4 < c4n; c4 += 64) {
-            const f32x4 f0 = *reinterpret_cast<const f32x4*>(fea2 + (size_t)pix * fea_ld + 4 * c4);
-            const f32x4 f1 = *reinterpret_cast<const f32x4*>(fea2 + (size_t)pix * fea_ld + C + 4 * c4);
+            const f32x4 f0 = *reinterpret_cast<const f32x4*>(fea0 + (size_t)pix * f0_ld + 4 * c4);
+            const f32x4 f1 = *reinterpret_cast<const f32x4*>(fea1 + (size_t)pix * f1_ld + 4 * c4);
             *reinterpret_cast<f32x4*>(out + (size_t)pix * out_ld + 4 * c4) = f0 * p0;
             *reinterpret_cast<f32x4*>(out + (size_t)pix * out_ld + C + 4 * c4) = f1 * p1;
         }
@@ -292,7 +293,7 @@ extern "C" int vps_axpb(const float* in, int in_ld, int in_coff, float* out, int
     return vps_launch_status();
 }
 
-extern "C" int vps_groupnorm_relu(const float* in, int in_ld, float* out, int out_ld, int64_t npix, int C, int G,
+extern "C" int vps_groupnorm_relu(const float* in, int in_ld, float* out, int out_ld, int out_coff, int64_t npix, int C, int G,
                                   const float* gamma, const float* beta, float eps, int relu, double* stats, void* stream) {
     if (!in || !out || !gamma || !beta || !stats || npix <= 0) return VPS_EARG(1);
     if (C <= 0 || C > 256 || 256 % C || G <= 0 || C % G || G > 256) return VPS_EARG(2);
@@ -303,17 +304,19 @@ extern "C" int vps_groupnorm_relu(const float* in, int in_ld, float* out, int ou
     long g = (npix + ppb - 1) / ppb; if (g > 1024) g = 1024;
     hipLaunchKernelGGL(groupnorm_stats_kernel, dim3((unsigned)g), dim3(256), 0, s, in, in_ld, (long)npix, C, G, stats);
     hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(stream_grid((long)npix * C, 256)), dim3(256), 0, s, in, in_ld, out, out_ld,
-                       (long)npix, C, G, gamma, beta, eps, relu, stats);
+                       out_coff, (long)npix, C, G, gamma, beta, eps, relu, stats);
     return vps_launch_status();
 }
 
-extern "C" int vps_tcea_temporal(const float* emb, int emb_ld, const float* emb_ref, int ref_ld, const float* fea2, int fea_ld,
+extern "C" int vps_tcea_temporal(const float* emb, int emb_ld, const float* emb_ref, int ref_ld,
+                                 const float* fea0, int f0_ld, const float* fea1, int f1_ld,
                                  float* out, int out_ld, int64_t npix, int C, void* stream) {
-    if (!emb || !emb_ref || !fea2 || !out || npix <= 0 || C <= 0 || (C & 3)) return VPS_EARG(1);
-    if ((emb_ld & 3) || (ref_ld & 3) || (fea_ld & 3) || (out_ld & 3)) return VPS_EARG(2);
+    if (!emb || !emb_ref || !fea0 || !fea1 || !out || npix <= 0 || C <= 0 || (C & 3)) return VPS_EARG(1);
+    if ((emb_ld & 3) || (ref_ld & 3) || (f0_ld & 3) || (f1_ld & 3) || (out_ld & 3)) return VPS_EARG(2);
+    if (((uintptr_t)emb | (uintptr_t)emb_ref | (uintptr_t)fea0 | (uintptr_t)fea1 | (uintptr_t)out) & 15) return VPS_EARG(3);
     long g = (npix + 3) / 4; if (g > 16384) g = 16384;
     hipLaunchKernelGGL(tcea_temporal_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, emb, emb_ld, emb_ref, ref_ld,
-                       fea2, fea_ld, out, out_ld, (long)npix, C);
+                       fea0, f0_ld, fea1, f1_ld, out, out_ld, (long)npix, C);
     return vps_launch_status();
 }
 

@@ -1,0 +1,328 @@
+"""PanopticFuseTrack on libvpship — the drop-in for mmdet/models/detectors/panoptic_fusetrack.py (inference path).
+
+Same registry name, constructor kwargs (configs/cityscapes/fusetrack.py model dict), `state_dict` key families,
+call signature `model(return_loss=False, rescale=True, img=[T], img_meta=[[meta]], ref_img=[T])` and return
+structure `(bbox_results, mask_results, pano_results)` as the reference, so tools/test_vpq.py:129-149,46-63 runs
+unchanged. Everything below the Python glue is a HIP kernel call through the C-ABI; there is no torch.nn compute
+and no CPU fallback.
+
+MI355X-first differences (results identical by construction):
+  * activations are NHWC slices of persistent concat buffers; BN/bias/activation/residual fused into the convs;
+  * the reference-frame features are NOT recomputed: frame t's gathered pre-neck feature is frame t-1's (cached);
+  * fcn_output [1,19,H,W], mask_energy/seg_inst/panoptic_logits [1,k,H,W] are never materialised;
+  * track-memory embeddings are cached instead of re-running the track FCs on all stored RoI features each frame.
+"""
+import os
+import os.path as osp
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip, nhwc
+from . import registry as R
+from .base import HipModule
+from .flownet2 import FlowNet2
+from .panoptic_ops import MaskRemoval, MaskROI, panoptic_combine
+
+
+def bbox2result_with_id(bboxes, labels, obj_ids, num_classes):
+    """core/bbox/transforms.py:159-180"""
+    if bboxes.shape[0] == 0:
+        return dict()
+    bboxes = bboxes.cpu().numpy(); labels = labels.cpu().numpy()
+    return {obj_id: {'bbox': bbox, 'label': label} for bbox, label, obj_id in zip(bboxes, labels, obj_ids) if obj_id >= 0}
+
+
+@R.DETECTORS.register_module
+class PanopticFuseTrack(HipModule):
+    def __init__(self, backbone, rpn_head, bbox_roi_extractor, bbox_head, mask_roi_extractor, mask_head, train_cfg,
+                 test_cfg, neck=None, extra_neck=None, panoptic=None, track_head=None, shared_head=None, pretrained=None,
+                 flownet_checkpoint=None):
+        super().__init__()
+        assert shared_head is None
+        # attribute names follow two_stage.py:31-64 (they are the state_dict prefixes)
+        self.backbone = R.build_backbone(backbone)
+        self.neck = R.build_neck(neck)
+        self.extra_neck = R.build_extra_neck(extra_neck)
+        self.panopticFPN = R.build_panoptic(panoptic)
+        self.rpn_head = R.build_head(rpn_head)
+        self.bbox_roi_extractor = R.build_roi_extractor(bbox_roi_extractor)
+        self.bbox_head = R.build_head(bbox_head)
+        self.track_head = R.build_head(track_head)
+        self.mask_roi_extractor = R.build_roi_extractor(mask_roi_extractor)
+        self.mask_head = R.build_head(mask_head)
+        self.train_cfg = R.ConfigDict.wrap(train_cfg) if train_cfg is not None else None
+        self.test_cfg = R.ConfigDict.wrap(test_cfg) if test_cfg is not None else None
+        if self.train_cfg is not None and hasattr(self.train_cfg, 'class_mapping'):
+            self.class_mapping = self.train_cfg['class_mapping']
+        elif self.test_cfg is not None and hasattr(self.test_cfg, 'class_mapping'):
+            self.class_mapping = self.test_cfg['class_mapping']
+        else:
+            self.class_mapping = {1: 11, 2: 12, 3: 13, 4: 14, 5: 15, 6: 16, 7: 17, 8: 18}
+        self.class_mapping = {int(k): int(v) for k, v in dict(self.class_mapping).items()}
+        self.mask_roi_panoptic = MaskROI(clip_boxes=True, bbox_class_agnostic=False, top_n=100,
+                                         num_classes=self.panopticFPN.num_things_classes + 1, nms_thresh=0.5,
+                                         class_agnostic=True, score_thresh=0.6)
+        self.mask_removal = MaskRemoval(fraction_threshold=0.3)
+        has_flow = (self.train_cfg is not None and hasattr(self.train_cfg, 'flownet2')) or \
+                   (self.test_cfg is not None and hasattr(self.test_cfg, 'flownet2'))
+        assert has_flow, 'Feature flow must be implemented.'
+        self.mean = [123.675, 116.28, 103.53]
+        self.std = [58.395, 57.12, 57.375]
+
+        class _Args(object):
+            rgb_max = 255.0
+            fp16 = False
+        self.flownet2 = FlowNet2(_Args())
+        # panoptic_fusetrack.py:100-106: FlowNet2 weights come from a separate cwd-relative file, loaded in __init__;
+        # load_checkpoint(model, latest.pth) afterwards may overwrite flownet2.* keys (kept: same order).
+        ck = flownet_checkpoint or osp.join(os.getcwd(), 'work_dirs', 'flownet', 'FlowNet2_checkpoint.pth.tar')
+        if osp.exists(ck):
+            self.flownet2.load_state_dict(torch.load(ck, map_location='cpu')['state_dict'])
+        else:
+            warnings.warn('FlowNet2 checkpoint %s not found: flownet2.* keeps its initial weights until a state_dict is loaded' % ck)
+        self.CLASSES = None
+        # options
+        self.reuse_ref_features = True     # False: recompute extract_feat(ref_img) every frame like the reference
+        self.int64_outputs = False         # True: panoptic/semantic maps as int64 like the reference (uint8 values otherwise)
+        self.profile = None                # set to {} to collect per-stage hip events
+        self._ws = None
+        self._flip = 0
+        self._cache = None
+        self.reset_tracker()
+
+    # ------------------------------------------------------------------------------------------------------
+    def reset_tracker(self):
+        self.prev_bboxes = None
+        self.prev_emb = None
+        self.prev_det_labels = None
+
+    def pack(self, device):
+        for m in (self.backbone, self.neck, self.extra_neck, self.panopticFPN, self.rpn_head, self.bbox_head,
+                  self.track_head, self.mask_head, self.flownet2):
+            m.ensure_packed(device)
+        self._mean_t = torch.tensor(self.mean, dtype=torch.float32, device=device)
+        self._std_t = torch.tensor(self.std, dtype=torch.float32, device=device)
+
+    def _mark(self, name):
+        if self.profile is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.profile.setdefault('events', []).append((name, ev))
+
+    def stage_times_ms(self):
+        """after a frame with self.profile = {}: [(stage, ms)] from the hip events (caller must synchronize first)"""
+        ev = self.profile.get('events', [])
+        return [(ev[i + 1][0], ev[i][1].elapsed_time(ev[i + 1][1])) for i in range(len(ev) - 1)]
+
+    # ------------------------------------------------------------------------------------------------------
+    def extract_feat(self, img):
+        """reference API (NCHW in, tuple of NCHW FPN levels out)"""
+        ws = nhwc.Workspace(img.device)
+        lv = self.neck.run(self.backbone.run(nhwc.from_nchw(img), ws, 'bb.'), ws, 'fpn.')
+        return tuple(l.to_nchw() for l in lv)
+
+    def compute_flow(self, img, ref_img, scale_factor=1):
+        """panoptic_fusetrack.py:117-143 (NCHW API). Returns (flow [1,2,h,w], None)."""
+        ws = nhwc.Workspace(img.device)
+        self.ensure_packed(img.device)
+        flow = self.flownet2.run(img, ref_img, self._mean_t, self._std_t, ws)
+        if scale_factor != 1:
+            Ho, Wo = int(flow.H * scale_factor), int(flow.W * scale_factor)
+            flow = nhwc.resize(flow, ws.fmap('flow_s', 1, Ho, Wo, 2), 'bilinear', scale_factor)
+        return flow.to_nchw(), None
+
+    # ------------------------------------------------------------------------------------------------------
+    def forward(self, img, img_meta, return_loss=True, **kwargs):
+        if return_loss:
+            raise NotImplementedError('vps_amd implements the inference path (return_loss=False) only')
+        return self.forward_test(img, img_meta, **kwargs)
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        """base.py:79-97: single-scale, batch 1"""
+        for var, name in [(imgs, 'imgs'), (img_metas, 'img_metas')]:
+            if not isinstance(var, list):
+                raise TypeError('{} must be a list, but got {}'.format(name, type(var)))
+        if len(imgs) != len(img_metas) or len(imgs) != 1:
+            raise ValueError('only single-scale testing (1 augmentation) is on the path')
+        assert imgs[0].size(0) == 1
+        return self.simple_test(imgs[0], img_metas[0], **kwargs)
+
+    @torch.no_grad()
+    def simple_test(self, img, img_meta, proposals=None, rescale=False, ref_img=None, inject=None):
+        """panoptic_fusetrack.py:502-606. `inject` (tests/bench only): dict overriding head inputs at the operator
+        boundaries of SURVEY §8d config 2 (fcn_score, proposals, cls_score, bbox_pred, mask_score)."""
+        assert proposals is None
+        if not img.is_cuda:
+            raise hip.VpsHipError('PanopticFuseTrack runs on the device only (no CPU path)')
+        dev = img.device
+        self.ensure_packed(dev)
+        if self._ws is None or self._ws.device != dev:
+            self._ws = nhwc.Workspace(dev)
+        ws = self._ws
+        if self.profile is not None:
+            self.profile['events'] = []
+        self._mark('start')
+        if ref_img is not None and isinstance(ref_img, (list, tuple)):
+            ref_img = ref_img[0]
+        meta = img_meta[0]
+        assert 'city' in meta['filename'] and 'iid' in meta
+        iid = meta['iid']
+        is_first = (iid % 10000) == 1
+        _, _, H, W = img.shape
+        im_info = np.array([[float(H), float(W), 1.0]])
+
+        # (1) flow ---------------------------------------------------------------------------------------------
+        flow = self.flownet2.run(img, ref_img, self._mean_t, self._std_t, ws)
+        self._mark('flownet2')
+        # (2) backbone + FPN of the target frame -----------------------------------------------------------------
+        self._flip ^= 1
+        tag = 'AB'[self._flip]
+        levels = self.neck.run(self.backbone.run(nhwc.from_nchw(img, ws, 'img_nhwc'), ws, 'bb.'), ws, 'fpn.')
+        cat = self.extra_neck.gather(levels, ws, 'neck.cat' + tag)
+        C = self.extra_neck.in_channels
+        # flowR2T = F.interpolate(flow, 0.25, bilinear) * 0.25 written straight into the LiteFlowNet input buffer
+        nhwc.resize(flow, cat.window(C + 81, 2), 'bilinear', 0.25)
+        self._mark('backbone_fpn')
+        # reference-frame gathered feature: cached from the previous call when the frames are consecutive
+        cache = self._cache
+        if self.reuse_ref_features and cache is not None and cache['iid'] + 1 == iid and not is_first and cache['shape'] == (H, W):
+            ref_bsf = cache['cat'].window(0, C)
+        elif self.reuse_ref_features and is_first:
+            ref_bsf = cat.window(0, C)        # datasets/cityscapes_vps.py:137-148: the first frame's ref is itself
+        else:
+            rl = self.neck.run(self.backbone.run(nhwc.from_nchw(ref_img, ws, 'ref_nhwc'), ws, 'rbb.'), ws, 'rfpn.')
+            ref_bsf = self.extra_neck.gather(rl, ws, 'neck.refcat').window(0, C)
+            self._mark('ref_backbone_fpn')
+        self._cache = dict(iid=iid, cat=cat, shape=(H, W))
+        # (3) temporal fusion neck -------------------------------------------------------------------------------
+        x, aux = self.extra_neck.run(levels, cat, ref_bsf, ws, 'neck.')
+        self._mark('extra_neck')
+        # (4) semantic head --------------------------------------------------------------------------------------
+        fcn_score = self.panopticFPN.run(x[0:self.panopticFPN.num_levels], ws)
+        if inject is not None and 'fcn_score' in inject:
+            fcn_score = nhwc.from_nchw(inject['fcn_score'].to(dev), ws, 'inj.fcn_score')
+        self._mark('semantic_head')
+        # (5) RPN ------------------------------------------------------------------------------------------------
+        if inject is not None and 'proposals' in inject:
+            proposals = inject['proposals'].to(dev)
+        else:
+            proposals = self.rpn_head.run(x, ws, meta['img_shape'], self.test_cfg.rpn)
+        self._mark('rpn')
+        # (6) bbox head + MaskROI + tracking ---------------------------------------------------------------------
+        det = self.simple_test_bboxes(x, meta, proposals, im_info, is_first, ws, inject)
+        self._mark('bbox_track')
+        det_bboxes, det_labels, det_obj_ids = det['det_bboxes'], det['det_labels'], det['det_obj_ids']
+        cls_prob, mask_rois, cls_idx = det['cls_prob'], det['det_rois'], det['cls_idx']
+        bbox_results = bbox2result_with_id(det_bboxes, det_labels, det_obj_ids, self.bbox_head.num_classes)
+        mask_results = [[] for _ in range(self.mask_head.num_classes - 1)]       # simple_test_mask: `or True` stub
+        # (8) mask head ------------------------------------------------------------------------------------------
+        mask_feats = self.mask_roi_extractor.run(x, mask_rois)
+        logits = self.mask_head.run(mask_feats, ws)
+        nc = self.mask_head.num_classes
+        if inject is not None and 'mask_score' in inject:
+            all_scores = inject['mask_score'].to(dev).permute(0, 2, 3, 1).contiguous()       # [K,28,28,nc]
+        else:
+            all_scores = logits.t[..., :nc]
+        S = all_scores.shape[1]
+        mask_score = all_scores.gather(3, cls_idx.view(-1, 1, 1, 1).expand(-1, S, S, 1)).squeeze(3).contiguous()
+        self._mark('mask_head')
+        # (9)-(11) MaskRemoval + SegTerm + combine ---------------------------------------------------------------
+        keep_inds, ref_boxes, masks_valid = self.mask_removal(mask_rois[:, 1:], cls_prob, mask_score, cls_idx, (H, W), ws)
+        rois_np = mask_rois[:, 1:].cpu().numpy()
+        cls_np = cls_idx.cpu().numpy()
+        pan, sem = panoptic_combine(fcn_score, rois_np, cls_np, ref_boxes, keep_inds, mask_score, self.class_mapping,
+                                    self.panopticFPN.num_stuff_classes, self.panopticFPN.num_classes, (H, W), ws, masks_valid)
+        keep_t = torch.from_numpy(keep_inds).to(dev)
+        h0, w0 = meta['img_shape'][0], meta['img_shape'][1]
+        pan = pan[:, 0:h0, 0:w0]; sem = sem[:, 0:h0, 0:w0]
+        if self.int64_outputs:
+            pan, sem = pan.long(), sem.long()
+        self._mark('panoptic_combine')
+        pano_results = {
+            'fcn_outputs': sem,
+            'panoptic_cls_inds': cls_idx[keep_t],
+            'panoptic_cls_prob': cls_prob[keep_t],
+            'panoptic_det_labels': det_labels[keep_t],
+            'panoptic_det_obj_ids': torch.from_numpy(np.asarray(det_obj_ids).astype(np.int64)).to(dev)[keep_t],
+            'panoptic_outputs': pan,
+        }
+        self._aux = dict(flow=flow, levels=levels, cat=cat, neck_out=x, neck_aux=aux, fcn_score=fcn_score, det=det,
+                         mask_score=mask_score, keep_inds=keep_inds, proposals=proposals)
+        return bbox_results, mask_results, pano_results
+
+    # ------------------------------------------------------------------------------------------------------
+    def simple_test_bboxes(self, x, meta, proposals, im_info, is_first, ws, inject=None):
+        """panoptic_fusetrack.py:358-471"""
+        lib = hip.load()
+        dev = proposals.device
+        rois = torch.cat([proposals.new_zeros(proposals.size(0), 1), proposals[:, :4]], dim=-1).contiguous()   # bbox2roi
+        roi_feats = self.bbox_roi_extractor.run(x, rois)
+        cls_score, bbox_pred = self.bbox_head.run(roi_feats, ws)
+        if inject is not None and 'cls_score' in inject:
+            cls_score, bbox_pred = inject['cls_score'].to(dev).contiguous(), inject['bbox_pred'].to(dev).contiguous()
+        cls_prob_all = torch.empty_like(cls_score)
+        hip.check(lib.vps_row_softmax(hip.ptr(cls_score), hip.ptr(cls_prob_all), cls_score.shape[0], cls_score.shape[1], 0,
+                                      hip.stream_ptr()), 'vps_row_softmax')
+        cls_prob, det_rois, cls_idx = self.mask_roi_panoptic(rois, bbox_pred, cls_prob_all, im_info, ws)
+        det_labels = cls_idx - 1
+        det_rois = det_rois.contiguous()
+        det_roi_feats = self.bbox_roi_extractor.run(x, det_rois)
+        det_bboxes = det_rois[:, 1:]
+        K = det_bboxes.size(0)
+        emb = self.track_head.embed(det_roi_feats, ws)
+        comp_scores = None
+        if is_first or self.prev_bboxes is None:
+            det_obj_ids = np.arange(K)
+            self.prev_bboxes = det_bboxes.clone(); self.prev_emb = emb; self.prev_det_labels = det_labels.clone()
+        else:
+            M = self.prev_bboxes.size(0)
+            match_score = self.track_head.match_scores(emb, self.prev_emb, ws).contiguous()
+            match_logprob = torch.empty_like(match_score)
+            hip.check(lib.vps_row_softmax(hip.ptr(match_score), hip.ptr(match_logprob), K, M + 1, 1, hip.stream_ptr()), 'log_softmax')
+            label_delta = (self.prev_det_labels == det_labels.view(-1, 1)).float()
+            db = det_bboxes.contiguous(); pb = self.prev_bboxes.contiguous()
+            bbox_ious = torch.empty(K, M, device=dev)
+            hip.check(lib.vps_bbox_overlaps(hip.ptr(db), db.shape[1], K, hip.ptr(pb), pb.shape[1], M, hip.ptr(bbox_ious),
+                                            hip.stream_ptr()), 'vps_bbox_overlaps')
+            comp_scores = self.track_head.compute_comp_scores(match_logprob, cls_prob.view(-1, 1), bbox_ious, label_delta,
+                                                              add_bbox_dummy=True)
+            match_likelihood, match_ids = torch.max(comp_scores, dim=1)
+            match_likelihood = match_likelihood.cpu().numpy()
+            match_ids = match_ids.cpu().numpy().astype(np.int32)
+            det_obj_ids = np.ones((K), dtype=np.int32) * (-1)
+            best_match_scores = np.ones((M)) * (-100)
+            best_match_ids = np.ones((M), dtype=np.int32) * (-1)
+            mem = M
+            adds, sets = [], {}
+            for idx, match_id in enumerate(match_ids):          # panoptic_fusetrack.py:434-459
+                if match_id == 0:
+                    det_obj_ids[idx] = mem; mem += 1; adds.append(idx)
+                else:
+                    obj_id = match_id - 1
+                    if match_likelihood[idx] > best_match_scores[obj_id]:
+                        det_obj_ids[idx] = obj_id
+                        if best_match_ids[obj_id] >= 0:
+                            det_obj_ids[best_match_ids[obj_id]] = -1
+                        best_match_scores[obj_id] = match_likelihood[idx]
+                        best_match_ids[obj_id] = idx
+                        sets[obj_id] = idx                   # the last assignment wins, as in the in-place updates
+            for idx, oid in enumerate(det_obj_ids):              # :463-469
+                if oid >= 0:
+                    continue
+                det_obj_ids[idx] = mem; mem += 1; adds.append(idx)
+            # apply the memory updates in one batch (same final state as the reference's sequential torch.cat's)
+            if sets:
+                oid = torch.tensor(list(sets.keys()), dtype=torch.long, device=dev)
+                src = torch.tensor(list(sets.values()), dtype=torch.long, device=dev)
+                self.prev_emb[oid] = emb[src]; self.prev_bboxes[oid] = det_bboxes[src]
+            if adds:
+                a = torch.tensor(adds, dtype=torch.long, device=dev)
+                self.prev_emb = torch.cat((self.prev_emb, emb[a]), dim=0)
+                self.prev_bboxes = torch.cat((self.prev_bboxes, det_bboxes[a]), dim=0)
+                self.prev_det_labels = torch.cat((self.prev_det_labels, det_labels[a]), dim=0)
+        return dict(det_bboxes=det_bboxes, det_labels=det_labels, det_obj_ids=det_obj_ids, cls_score=cls_score,
+                    bbox_pred=bbox_pred, cls_prob=cls_prob, det_rois=det_rois, cls_idx=cls_idx, comp_scores=comp_scores,
+                    det_roi_feats=det_roi_feats, emb=emb)

@@ -101,10 +101,10 @@ def load():
                                   c_int, c_void_p, c_void_p]
     lib.vps_flow_stage.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
                                    c_void_p, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_void_p]
-    lib.vps_groupnorm_relu.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p,
+    lib.vps_groupnorm_relu.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_void_p,
                                        c_float, c_int, c_void_p, c_void_p]
-    lib.vps_tcea_temporal.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64,
-                                      c_int, c_void_p]
+    lib.vps_tcea_temporal.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                      c_int64, c_int, c_void_p]
     lib.vps_tcea_modulate.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
     lib.vps_roi_align.argtypes = [POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_float),
                                   c_int, c_float, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]

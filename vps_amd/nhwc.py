@@ -162,6 +162,24 @@ class PackedConv:
         self.scale = scale.to(device) if self.has_scale else None
         self.shift = shift.to(device) if (bias is not None or bn is not None) else None
 
+    @classmethod
+    def from_matrix(cls, mat):
+        """GEMM against a device matrix mat [M, D] (rows = output channels) without a host round trip: out = x @ mat^T."""
+        M, D = mat.shape
+        assert D % 32 == 0 and mat.is_cuda
+        self = cls.__new__(cls)
+        self.stride, self.act, self.slope, self.deform, self.transposed = 1, hip.ACT_NONE, 0.1, False, False
+        self.nclass, self.os, self.KH, self.KW = 1, 1, 1, 1
+        self.pad_y = self.pad_x = (0, 0)
+        self.cin = self.cin_pad = self.kpad = D
+        self.cout = M
+        self.tile_n = _tile_n(M)
+        self.cout_pad = _ceil(M, self.tile_n)
+        w = torch.zeros(1, self.cout_pad, D, dtype=torch.float32, device=mat.device)
+        w[0, :M] = mat
+        self.w, self.scale, self.shift, self.has_scale = w, None, None, False
+        return self
+
     def out_hw(self, H, W):
         if self.transposed:
             return 2 * H, 2 * W
@@ -302,8 +320,8 @@ def bfp_scatter(bsf, level, out):
 
 
 def groupnorm_relu(x, out, G, gamma, beta, eps, stats, relu=True):
-    assert x.coff == 0 and out.coff == 0 and x.N == 1
-    hip.check(hip.load().vps_groupnorm_relu(x.ptr(), x.ld, out.ptr(), out.ld, x.npix, x.C, G, hip.ptr(gamma), hip.ptr(beta),
+    assert x.coff == 0 and x.N == 1
+    hip.check(hip.load().vps_groupnorm_relu(x.ptr(), x.ld, out.ptr(), out.ld, out.coff, x.npix, x.C, G, hip.ptr(gamma), hip.ptr(beta),
                                             float(eps), 1 if relu else 0, hip.ptr(stats), hip.stream_ptr()), 'vps_groupnorm_relu')
     return out
 
@@ -323,4 +341,23 @@ def roi_align(levels, strides, rois, P, sample_num=2, finest_scale=56.0, out=Non
     rois = rois.contiguous()
     hip.check(hip.load().vps_roi_align(ptrs, lds, Hs, Ws, sc, n, float(finest_scale), hip.ptr(rois), R, C, P, sample_num,
                                        hip.ptr(out), hip.stream_ptr()), 'vps_roi_align')
+    return out
+
+
+def tcea_temporal(emb, emb_ref, fea0, fea1, out):
+    C = fea0.C
+    assert emb.C == 2 * C and emb.coff == 0 and emb_ref.coff == 0 and out.coff == 0 and out.C == 2 * C
+    assert fea0.coff % 4 == 0 and fea1.coff % 4 == 0
+    p0 = c_void_p(fea0.t.data_ptr() + 4 * fea0.coff)
+    p1 = c_void_p(fea1.t.data_ptr() + 4 * fea1.coff)
+    hip.check(hip.load().vps_tcea_temporal(emb.ptr(), emb.ld, emb_ref.ptr(), emb_ref.ld, p0, fea0.ld, p1, fea1.ld,
+                                           out.ptr(), out.ld, out.npix, C, hip.stream_ptr()), 'vps_tcea_temporal')
+    return out
+
+
+def tcea_modulate(fea, att, att_add, out):
+    for m in (fea, att, att_add, out):
+        assert m.coff == 0 and m.C == m.ld
+    hip.check(hip.load().vps_tcea_modulate(fea.ptr(), att.ptr(), att_add.ptr(), out.ptr(), out.t.numel(), hip.stream_ptr()),
+              'vps_tcea_modulate')
     return out
