@@ -1,0 +1,155 @@
+"""bench.py — FuseTrack inference throughput on synthetic 1024x2048 clips (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one frame of PanopticFuseTrack.simple_test (target frame + previous frame: FlowNet2, ResNet-50-FPN, BFP-TCEA
+fusion, UPSNet semantic head, RPN, RoIAlign, bbox / track / mask heads, MaskRemoval, panoptic combine) with inputs
+already resident in HBM. Weights are synthetic (vps_amd.synth; no checkpoints offline) and scaled so the heads emit the
+configured maximum of ~100 detections per frame. One process per GPU; each rank runs its own contiguous shard of the clip
+(weak scaling, no data-path collective inside a shard; the shard-boundary feature hand-off is in vps_amd/clip_shard.py).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+warnings.simplefilter('ignore')
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+H, W = 1024, 2048
+
+
+def cpu_baseline(seed):
+    """the oracle (CPU restatement of the reference path) on a bounded sample of the same workload, rank 0 only"""
+    from oracle.fusetrack import FuseTrackOracle
+    import vps_amd
+    from vps_amd import synth
+    h, w = 256, 512
+    cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', 'fusetrack.py'))
+    model = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    sd = synth.synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, seed)
+    o = FuseTrackOracle(sd)
+    frames = synth.synth_clip(h, w, 2, seed)
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        o.simple_test(frames[0], frames[0], True)                 # warm-up (first frame of the clip)
+        t0 = time.perf_counter()
+        o.simple_test(frames[1], frames[0], False)
+        dt = time.perf_counter() - t0
+    frac = (h * w) / float(H * W)
+    return dict(value=round(frac / dt, 5), unit='frames/s', cores=cores, kind='port',
+                sample='1 FuseTrack frame pair at %dx%d (=%.4f of the %dx%d frame, scaled by pixel count), oracle/ on '
+                       'PyTorch-CPU fp32, %.1f s' % (h, w, frac, H, W, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--height', type=int, default=H)
+    ap.add_argument('--width', type=int, default=W)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, 'launch with --nproc-per-node == --gpus'
+    assert torch.cuda.is_available(), 'bench.py measures the HIP path and needs the MI355X (no CPU fallback)'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    import vps_amd
+    from vps_amd import nhwc, synth
+    Hh, Ww = args.height, args.width
+    cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', 'fusetrack.py'))
+    model = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    synth.load_synth(model, args.seed)
+
+    # this rank's shard of the synthetic clip: warmup + steps consecutive frames, resident in HBM before timing
+    nfr = args.warmup + args.steps + 1
+    base = rank * 100
+    frames = [f.to(dev) for f in synth.synth_clip(Hh, Ww, min(nfr, 8), args.seed + rank)]
+    metas = [synth.img_meta(Hh, Ww, 10000 * (rank + 1) + t + 1) for t in range(nfr)]
+
+    def step(t):
+        img = frames[t % len(frames)]
+        ref = frames[(t - 1) % len(frames)] if t else frames[0]
+        return model(return_loss=False, rescale=True, img=[img], img_meta=[[metas[t]]], ref_img=[ref])
+
+    t = 0
+    for _ in range(args.warmup):
+        step(t); t += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ndet = 0
+    for _ in range(args.steps):
+        out = step(t); t += 1
+        ndet += int(out[2]['panoptic_cls_inds'].numel())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- instrumented extra frame (outside the timed region): per-stage and per-conv-launch HIP events ----------
+    roof, stages = None, None
+    if rank == 0:
+        model.profile = {}
+        nhwc.CONV_TRACE = []
+        step(t)
+        torch.cuda.synchronize()
+        stages = {k: round(v, 3) for k, v in model.stage_times_ms()}
+        fl = sum(c[0] for c in nhwc.CONV_TRACE)
+        ms = sum(c[1].elapsed_time(c[2]) for c in nhwc.CONV_TRACE)
+        nl = len(nhwc.CONV_TRACE)
+        nhwc.CONV_TRACE = None
+        model.profile = None
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = dict(bound='mfma', kernel='conv_mfma_f32_kernel', achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS,
+                    unit='TFLOP/s', frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                    launches_per_frame=nl, gflop_per_frame=round(fl / 1e9, 1), conv_ms_per_frame=round(ms, 3))
+
+    if rank == 0:
+        fps = world * args.steps / dt
+        line = {
+            'metric': 'frames/sec FuseTrack 1024x2048', 'value': round(fps, 3), 'unit': 'frames/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '2-frame pair FuseTrack (FlowNet2 + ResNet50-FPN + BFP-TCEA + UPSNet panoptic + track head), '
+                                   'synthetic %dx%d clip, batch 1, one clip shard per GPU' % (Hh, Ww),
+                       'weights': 'synthetic (vps_amd.synth seed %d)' % args.seed,
+                       'detections_per_frame': round(ndet / max(args.steps, 1), 1),
+                       'parallelism': 'clip-shard x%d' % world},
+            'roofline': roof, 'stage_ms': stages,
+        }
+        if not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args.seed)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -18,6 +18,11 @@ def _ceil(a, b):
     return (a + b - 1) // b * b
 
 
+# bench.py sets this to a list to time every vps_conv2d launch with HIP events on the launch stream:
+# entries (algorithmic_flops, start_event, end_event). None = no instrumentation (the default).
+CONV_TRACE = None
+
+
 class FMap:
     __slots__ = ('t', 'C', 'coff')
 
@@ -166,7 +171,7 @@ class PackedConv:
     def from_matrix(cls, mat):
         """GEMM against a device matrix mat [M, D] (rows = output channels) without a host round trip: out = x @ mat^T."""
         M, D = mat.shape
-        assert D % 32 == 0 and mat.is_cuda
+        assert D % 32 == 0
         self = cls.__new__(cls)
         self.stride, self.act, self.slope, self.deform, self.transposed = 1, hip.ACT_NONE, 0.1, False, False
         self.nclass, self.os, self.KH, self.KW = 1, 1, 1, 1
@@ -237,7 +242,14 @@ class PackedConv:
                 wsb = torch.empty(need, dtype=torch.float32, device=x.t.device)
             d.ws = wsb.data_ptr()
             self._last_ws = wsb  # keep alive until the next call
-        hip.conv2d(d)
+        if CONV_TRACE is not None:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            hip.conv2d(d)
+            e1.record()
+            CONV_TRACE.append((self.flops(x.N, x.H, x.W), e0, e1))
+        else:
+            hip.conv2d(d)
         return out
 
     def flops(self, x_N, x_H, x_W):
