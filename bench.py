@@ -60,6 +60,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--height', type=int, default=H)
     ap.add_argument('--width', type=int, default=W)
+    ap.add_argument('--conv-table', default=None, help='write the per-layer-shape conv timing table of one frame here')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -91,7 +92,27 @@ def main():
         ref = frames[(t - 1) % len(frames)] if t else frames[0]
         return model(return_loss=False, rescale=True, img=[img], img_meta=[[metas[t]]], ref_img=[ref])
 
+    C = model.extra_neck.in_channels
+
+    def handoff():
+        """clip sharding (vps_amd/clip_shard.py): every rank computes the gathered pre-neck feature of its LAST frame first
+        and passes it to the next rank with ONE point-to-point send/recv (RCCL over the direct xGMI link); the receiver
+        uses it as ref_bsf of its first frame instead of recomputing ResNet+FPN on the previous image."""
+        if world == 1:
+            return None
+        ops, buf, feat = [], None, None
+        if rank < world - 1:
+            feat = model.gathered_feature(frames[(nfr - 1) % len(frames)])
+            ops.append(dist.P2POp(dist.isend, feat, rank + 1))
+        if rank > 0:
+            buf = torch.empty(1, Hh // 4, Ww // 4, C, dtype=torch.float32, device=dev)
+            ops.append(dist.P2POp(dist.irecv, buf, rank - 1))
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        return buf
+
     t = 0
+    handoff()                                       # untimed: RCCL p2p communicator setup
     for _ in range(args.warmup):
         step(t); t += 1
     torch.cuda.synchronize()
@@ -100,8 +121,14 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ndet = 0
-    for _ in range(args.steps):
-        out = step(t); t += 1
+    ref_feature = handoff()                         # timed: one hand-off per shard (rank > 0 receives)
+    for i in range(args.steps):
+        if i == 0 and ref_feature is not None:
+            img = frames[t % len(frames)]
+            out = model.simple_test(img, [metas[t]], ref_img=[frames[(t - 1) % len(frames)]], ref_feature=ref_feature)
+        else:
+            out = step(t)
+        t += 1
         ndet += int(out[2]['panoptic_cls_inds'].numel())
     torch.cuda.synchronize()
     if world > 1:
@@ -124,6 +151,14 @@ def main():
         fl = sum(c[0] for c in nhwc.CONV_TRACE)
         ms = sum(c[1].elapsed_time(c[2]) for c in nhwc.CONV_TRACE)
         nl = len(nhwc.CONV_TRACE)
+        if args.conv_table:
+            agg = {}
+            for c in nhwc.CONV_TRACE:
+                a = agg.setdefault(c[3], [0, 0.0, 0.0]); a[0] += 1; a[1] += c[1].elapsed_time(c[2]); a[2] += c[0]
+            with open(args.conv_table, 'w') as f:
+                f.write('%-58s %5s %9s %9s %8s\n' % ('layer shape', 'calls', 'ms', 'GFLOP', 'TFLOP/s'))
+                for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                    f.write('%-58s %5d %9.3f %9.2f %8.2f\n' % (k, a[0], a[1], a[2] / 1e9, a[2] / a[1] / 1e9))
         nhwc.CONV_TRACE = None
         model.profile = None
         ach = fl / (ms * 1e-3) / 1e12
@@ -141,7 +176,7 @@ def main():
                                    'synthetic %dx%d clip, batch 1, one clip shard per GPU' % (Hh, Ww),
                        'weights': 'synthetic (vps_amd.synth seed %d)' % args.seed,
                        'detections_per_frame': round(ndet / max(args.steps, 1), 1),
-                       'parallelism': 'clip-shard x%d' % world},
+                       'parallelism': 'clip-shard x%d, 1 p2p feature hand-off per shard boundary' % world},
             'roofline': roof, 'stage_ms': stages,
         }
         if not args.no_cpu_baseline:

@@ -1,0 +1,171 @@
+"""CPU / gloo, world_size 2: the clip-sharding protocol of vps_amd/clip_shard.py (frame partition, ONE point-to-point
+hand-off of the gathered pre-neck feature per shard boundary, sequential tracker replay on rank 0) gives exactly the
+outputs of the sequential single-process run. The compute backend injected here is oracle-backed (tests may use the
+oracle); on the GPU the same runner drives vps_amd.clip_shard.DetectorBackend.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from vps_amd.clip_shard import ClipShardRunner, partition  # noqa: E402
+
+H, W, NFR = 64, 128, 5
+
+
+def test_partition():
+    assert [b - a for a, b in partition(30, 8)] == [4, 4, 4, 4, 4, 4, 3, 3]
+    assert partition(30, 8)[0] == (0, 4) and partition(30, 8)[-1] == (27, 30)
+    assert partition(5, 2) == [(0, 3), (3, 5)]
+    assert sum(b - a for a, b in partition(7, 3)) == 7
+
+
+class OracleBackend:
+    """ClipShardRunner protocol on top of the CPU oracle (split into per-frame work and the sequential tracker)"""
+
+    def __init__(self, sd):
+        from oracle import fusetrack as OF
+        self.OF = OF
+        self.o = OF.FuseTrackOracle(sd)
+        self.sd = self.o.sd
+        self.prev = None          # tracker memory: (bboxes, feats, labels)
+
+    def ref_feature(self, img):
+        with torch.no_grad():
+            return self.OF.bfp_gather(self.o.extract_feat(img)).contiguous()
+
+    def ref_feature_buffer(self, img):
+        return torch.empty(1, 256, img.shape[2] // 4, img.shape[3] // 4)
+
+    def process(self, img, ref_img, ref_feature, iid, is_first):
+        OF, o, sd = self.OF, self.o, self.sd
+        import torch.nn.functional as F
+        with torch.no_grad():
+            flow = o.compute_flow(img, ref_img, 0.25)
+            x = o.extract_feat(img)
+            if ref_feature is None:
+                ref_levels = o.extract_feat(ref_img)
+                ref_bsf = OF.bfp_gather(ref_levels)
+            else:
+                ref_bsf = ref_feature
+            # bfp_tcea with an explicit ref_bsf (bfp_tcea.py:116-149)
+            bsf = OF.bfp_gather(x)
+            warp = OF.warping_layer(ref_bsf, flow)
+            fine = OF.liteflownet_corr(sd, 'extra_neck.liteflownet.', bsf, warp, flow)
+            warp = OF.warping_layer(warp, fine)
+            fused = OF.tcea_fusion(sd, 'extra_neck.tcea_fusion.', torch.stack([bsf, warp], 1), 0)
+            refined = F.relu(F.conv2d(fused, sd['extra_neck.refine.conv.weight'], sd['extra_neck.refine.conv.bias'], padding=1))
+            x = [F.adaptive_max_pool2d(refined, l.shape[2:]) + l for l in x]
+            fcn_output, fcn_score = OF.upsnet_fpn(sd, 'panopticFPN.', x[0:4])
+            im_shape = tuple(img.shape[2:])
+            proposals = OF.rpn_get_bboxes(OF.rpn_forward(sd, 'rpn_head.', x), im_shape)
+            rois = torch.cat([proposals.new_zeros(proposals.size(0), 1), proposals[:, :4]], -1)
+            cls_score, bbox_pred = OF.bbox_head(sd, 'bbox_head.', OF.roi_extract(x, rois, 7))
+            im_info = np.array([[float(im_shape[0]), float(im_shape[1]), 1.0]])
+            cls_prob, det_rois, cls_idx = OF.mask_roi(rois, bbox_pred, F.softmax(cls_score, 1), im_info)
+            feats = OF.roi_extract(x, det_rois, 7)
+            det = dict(det_rois=det_rois, cls_idx=cls_idx, cls_prob=cls_prob, det_labels=cls_idx - 1,
+                       det_obj_ids=np.full((det_rois.size(0),), -1))
+            pano = o.panoptic(x, fcn_output, det)
+        return dict(det_bboxes=det_rois[:, 1:], det_labels=cls_idx - 1, cls_prob=cls_prob, emb=feats,
+                    keep_inds=pano['keep_inds'], fcn_outputs=pano['fcn_outputs'], panoptic_outputs=pano['panoptic_outputs'],
+                    panoptic_cls_inds=pano['panoptic_cls_inds'], panoptic_cls_prob=pano['panoptic_cls_prob'],
+                    panoptic_det_labels=pano['panoptic_det_labels'])
+
+    def assign(self, rec, is_first):
+        OF = self.OF
+        bb, lab, feats, prob = rec['det_bboxes'], rec['det_labels'], rec['emb'], rec['cls_prob']
+        if is_first or self.prev is None:
+            self.prev = [bb.clone(), feats.clone(), lab.clone()]
+            return np.arange(bb.size(0))
+        with torch.no_grad():
+            comp = OF.track_scores(self.sd, 'track_head.', feats, self.prev[1], prob, bb, self.prev[0], lab, self.prev[2])
+        ids, updates = OF.greedy_assign(comp, self.prev[0].size(0))
+        for u in updates:
+            if u[0] == 'add':
+                i = u[1]
+                self.prev = [torch.cat((self.prev[0], bb[i][None])), torch.cat((self.prev[1], feats[i][None])),
+                             torch.cat((self.prev[2], lab[i][None]))]
+            else:
+                self.prev[1][u[1]] = feats[u[2]]; self.prev[0][u[1]] = bb[u[2]]
+        return ids
+
+    def finalize(self, rec, ids):
+        out = {k: rec[k] for k in ('fcn_outputs', 'panoptic_outputs', 'panoptic_cls_inds', 'panoptic_cls_prob', 'panoptic_det_labels')}
+        out['panoptic_det_obj_ids'] = np.asarray(ids)[np.asarray(rec['keep_inds'])]
+        out['t'] = rec['t']
+        return out
+
+
+def _make():
+    import warnings
+    warnings.simplefilter('ignore')
+    import vps_amd
+    from vps_amd import synth
+    cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', 'fusetrack.py'))
+    model = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    sd = synth.synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, 0)
+    frames = synth.synth_clip(H, W, NFR, 0)
+    return sd, frames
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    torch.set_num_threads(2)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sd, frames = _make()
+    runner = ClipShardRunner(OracleBackend(sd), rank, world, dist,
+                             track_keys=('det_bboxes', 'det_labels', 'cls_prob', 'emb'))
+    outs = runner.run(lambda t: frames[t], NFR)
+    if rank == 0:
+        q.put([{k: (v.numpy() if torch.is_tensor(v) else v) for k, v in o.items()} for o in outs])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_clip_shard_equals_sequential():
+    # sequential reference: the plain oracle detector, frame by frame, with its own tracker
+    from oracle.fusetrack import FuseTrackOracle
+    sd, frames = _make()
+    o = FuseTrackOracle(sd)
+    seq = []
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(2)        # same CPU reduction order as the workers
+    try:
+        with torch.no_grad():
+            for t in range(NFR):
+                seq.append(o.simple_test(frames[t], frames[t - 1 if t else 0], t == 0))
+    finally:
+        torch.set_num_threads(nthr)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = q.get(timeout=800)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [o_['t'] for o_ in outs] == list(range(NFR))
+    for t in range(NFR):
+        a, b = outs[t], seq[t]
+        assert np.array_equal(a['panoptic_det_obj_ids'], b['panoptic_det_obj_ids'].numpy()), (t, a['panoptic_det_obj_ids'], b['panoptic_det_obj_ids'])
+        assert np.array_equal(a['panoptic_cls_inds'], b['panoptic_cls_inds'].numpy())
+        # maps: identical up to CPU-thread-count dependent rounding of the convolutions (argmax flips on a few pixels)
+        assert (a['panoptic_outputs'] != b['panoptic_outputs'].numpy()).mean() < 2e-3
+        assert (a['fcn_outputs'] != b['fcn_outputs'].numpy()).mean() < 2e-3

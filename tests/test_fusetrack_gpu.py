@@ -137,3 +137,31 @@ def test_operator_api_matches_reference_signatures(setup):
     with torch.no_grad():
         rf = o.compute_flow(fr[1], fr[0], 0.25)
     assert _relmax(flow.cpu(), rf) < 2e-3
+
+
+def test_clip_shard_backend_and_handoff_feature(setup):
+    """(a) ClipShardRunner + DetectorBackend (deferred tracking + sequential replay) == plain sequential calls;
+    (b) frame 1 fed with the hand-off feature gathered_feature(frame 0) (what a neighbouring GPU would send) == the
+    cached-feature path."""
+    from vps_amd.clip_shard import ClipShardRunner, DetectorBackend
+    m, fr, dev = setup['model'], setup['frames'], setup['dev']
+    H, W, n = setup['H'], setup['W'], setup['n']
+    m._cache = None; m.reset_tracker()
+    seq = []
+    for t in range(n):
+        out = m(return_loss=False, rescale=True, img=[fr[t].to(dev)], img_meta=[[synth.img_meta(H, W, 10000 + t + 1)]],
+                ref_img=[fr[t - 1 if t else 0].to(dev)])
+        seq.append({k: v.cpu().numpy().copy() for k, v in out[2].items()})
+    m._cache = None; m.reset_tracker()
+    outs = ClipShardRunner(DetectorBackend(m, H, W), 0, 1, None, dev).run(lambda t: fr[t].to(dev), n)
+    for t in range(n):
+        assert np.array_equal(np.asarray(outs[t]['panoptic_det_obj_ids']), seq[t]['panoptic_det_obj_ids'])
+        assert np.array_equal(outs[t]['panoptic_outputs'].cpu().numpy(), seq[t]['panoptic_outputs'])
+    # (b)
+    m._cache = None; m.reset_tracker()
+    m(return_loss=False, rescale=True, img=[fr[0].to(dev)], img_meta=[[synth.img_meta(H, W, 10001)]], ref_img=[fr[0].to(dev)])
+    feat = m.gathered_feature(fr[0].to(dev)).clone()
+    m._cache = None
+    out = m.simple_test(fr[1].to(dev), [synth.img_meta(H, W, 10002)], ref_img=[fr[0].to(dev)], ref_feature=feat)
+    assert np.array_equal(out[2]['panoptic_outputs'].cpu().numpy(), seq[1]['panoptic_outputs'])
+    assert np.array_equal(out[2]['panoptic_det_obj_ids'].cpu().numpy(), seq[1]['panoptic_det_obj_ids'])

@@ -1,0 +1,139 @@
+"""Frame-sharded inference of ONE video clip over the GPUs of a node (one process per GPU, torch.distributed, RCCL/xGMI).
+
+The reference is single-GPU and strictly sequential (tools/test_vpq.py:28-69, `distributed = False` at :106); this is
+new design for BASELINE config 4:
+
+  * rank r owns the contiguous frame range partition(nframes, world)[r].
+  * every per-frame stage except instance-id assignment depends only on (frame_t, frame_{t-1}): FlowNet2 needs the two
+    raw images (input data, each rank loads frame s_r-1 itself), the BFP-TCEA neck needs the gathered pre-neck feature of
+    frame t-1 (bfp_tcea.py:117 `ref_bsf = gather(ref_inputs)`).
+  * the ONLY data-path exchange: rank r computes gather(FPN(frame e_r-1)) of its LAST frame first (it depends on that
+    image alone) and sends it point-to-point to rank r+1 (134 MB fp32 at 1024x2048: one direct xGMI link, ~0.9 ms,
+    overlapped with everything rank r+1 does before its neck). One send/recv per shard boundary, no ring, no all-reduce.
+  * instance ids depend on the whole history (panoptic_fusetrack.py:400-469): each rank ships its per-frame detection
+    records (boxes, labels, scores, 1024-d track embeddings: <0.5 MB/frame) to rank 0, which replays the greedy assignment
+    in frame order — exactly the sequential algorithm, so ids are identical to the single-GPU run.
+
+`backend` protocol (product: DetectorBackend below; CPU tests inject an oracle-backed one):
+    ref_feature(img) -> contiguous tensor          gathered pre-neck feature of a frame
+    process(img, ref_img, ref_feature, iid, is_first) -> dict record (no ids yet)
+    assign(record, is_first) -> np.ndarray ids     sequential tracker step (stateful)
+    finalize(record, ids) -> dict                  per-frame outputs with 'panoptic_det_obj_ids'
+"""
+import numpy as np
+import torch
+
+
+def partition(nframes, world):
+    """contiguous chunks, sizes differ by at most one, larger chunks first: 30/8 -> 4,4,4,4,4,4,3,3"""
+    base, rem = divmod(nframes, world)
+    out, s = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((s, s + n))
+        s += n
+    return out
+
+
+class ClipShardRunner:
+    def __init__(self, backend, rank=0, world=1, dist=None, device=None, track_keys=('det_bboxes', 'det_labels', 'cls_prob', 'emb')):
+        self.backend, self.rank, self.world, self.dist = backend, rank, world, dist
+        self.device = device
+        self.track_keys = track_keys
+
+    def run(self, load_frame, nframes, video_id=1):
+        """load_frame(t) -> normalised frame tensor [1,3,H,W] on this rank's device (data loading is not the sharded path).
+        Returns on rank 0 the list of per-frame outputs for the WHOLE clip (frame order), elsewhere this rank's outputs
+        without ids."""
+        dist, rank, world = self.dist, self.rank, self.world
+        s, e = partition(nframes, world)[rank]
+        be = self.backend
+        recv_buf = None
+        reqs = []
+        # 1) hand-off: last frame's gathered feature -> next rank (computed first: it only needs that image)
+        if world > 1 and e > s:
+            ops = []
+            if rank < world - 1:
+                feat = be.ref_feature(load_frame(e - 1))
+                ops.append(dist.P2POp(dist.isend, feat, rank + 1))
+            if rank > 0:
+                recv_buf = be.ref_feature_buffer(load_frame(s))
+                ops.append(dist.P2POp(dist.irecv, recv_buf, rank - 1))
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+        # 2) this rank's frames
+        records = []
+        prev = None
+        for t in range(s, e):
+            img = load_frame(t)
+            is_first = t == 0
+            ref_img = img if is_first else (prev if prev is not None else load_frame(t - 1))
+            ref_feature = None
+            if t == s and rank > 0:
+                for rq in reqs:
+                    rq.wait()
+                reqs = []
+                ref_feature = recv_buf
+            rec = be.process(img, ref_img, ref_feature, video_id * 10000 + t + 1, is_first)
+            rec['t'] = t
+            records.append(rec)
+            prev = img
+        for rq in reqs:
+            rq.wait()
+        # 3) sequential tracker replay on rank 0
+        if world == 1:
+            return [be.finalize(r, be.assign(r, r['t'] == 0)) for r in records]
+        slim = [{k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in r.items() if k in self.track_keys or k == 't'}
+                for r in records]
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(slim, gathered, dst=0)
+        ids_per_rank = None
+        if rank == 0:
+            allrec = sorted([r for chunk in gathered for r in chunk], key=lambda r: r['t'])
+            ids = {}
+            for r in allrec:
+                r = {k: (v.to(self.device) if torch.is_tensor(v) and self.device is not None else v) for k, v in r.items()}
+                ids[r['t']] = np.asarray(be.assign(r, r['t'] == 0))
+            parts = partition(nframes, world)
+            ids_per_rank = [{t: ids[t] for t in range(a, b)} for a, b in parts]
+        mine = [None]
+        dist.scatter_object_list(mine, ids_per_rank, src=0)
+        outs = [be.finalize(r, mine[0][r['t']]) for r in records]
+        # collect the finished per-frame outputs on rank 0 (small: uint8 maps + ids)
+        res = [None] * world if rank == 0 else None
+        dist.gather_object([{k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in o.items()} for o in outs], res, dst=0)
+        if rank == 0:
+            return [o for chunk in res for o in chunk]
+        return outs
+
+
+class DetectorBackend:
+    """adapts vps_amd.detector.PanopticFuseTrack to the ClipShardRunner protocol"""
+
+    def __init__(self, detector, H, W):
+        self.det, self.H, self.W = detector, H, W
+
+    def ref_feature(self, img):
+        return self.det.gathered_feature(img)
+
+    def ref_feature_buffer(self, img):
+        C = self.det.extra_neck.in_channels
+        return torch.empty(1, self.H // 4, self.W // 4, C, dtype=torch.float32, device=img.device)
+
+    def process(self, img, ref_img, ref_feature, iid, is_first):
+        from . import synth
+        meta = synth.img_meta(self.H, self.W, iid)
+        out = self.det.simple_test(img, [meta], ref_img=[ref_img], ref_feature=ref_feature, defer_tracking=True)
+        rec = dict(out[2])
+        rec.update(self.det._track_record)
+        return rec
+
+    def assign(self, rec, is_first):
+        return self.det.track_assign(rec, is_first)
+
+    def finalize(self, rec, ids):
+        keep = rec['keep_inds']
+        out = {k: rec[k] for k in ('fcn_outputs', 'panoptic_outputs', 'panoptic_cls_inds', 'panoptic_cls_prob',
+                                   'panoptic_det_labels')}
+        out['panoptic_det_obj_ids'] = np.asarray(ids)[np.asarray(keep)]
+        out['t'] = rec['t']
+        return out

@@ -151,9 +151,12 @@ class PanopticFuseTrack(HipModule):
         return self.simple_test(imgs[0], img_metas[0], **kwargs)
 
     @torch.no_grad()
-    def simple_test(self, img, img_meta, proposals=None, rescale=False, ref_img=None, inject=None):
+    def simple_test(self, img, img_meta, proposals=None, rescale=False, ref_img=None, inject=None, ref_feature=None,
+                    defer_tracking=False):
         """panoptic_fusetrack.py:502-606. `inject` (tests/bench only): dict overriding head inputs at the operator
-        boundaries of SURVEY §8d config 2 (fcn_score, proposals, cls_score, bbox_pred, mask_score)."""
+        boundaries of SURVEY §8d config 2 (fcn_score, proposals, cls_score, bbox_pred, mask_score).
+        ref_feature / defer_tracking (clip_shard.py): gathered pre-neck feature of the previous frame received from the
+        neighbouring GPU, and postponing the sequential id assignment to the clip-level replay."""
         assert proposals is None
         if not img.is_cuda:
             raise hip.VpsHipError('PanopticFuseTrack runs on the device only (no CPU path)')
@@ -188,7 +191,9 @@ class PanopticFuseTrack(HipModule):
         self._mark('backbone_fpn')
         # reference-frame gathered feature: cached from the previous call when the frames are consecutive
         cache = self._cache
-        if self.reuse_ref_features and cache is not None and cache['iid'] + 1 == iid and not is_first and cache['shape'] == (H, W):
+        if ref_feature is not None:
+            ref_bsf = nhwc.FMap(ref_feature.view(1, cat.H, cat.W, C))
+        elif self.reuse_ref_features and cache is not None and cache['iid'] + 1 == iid and not is_first and cache['shape'] == (H, W):
             ref_bsf = cache['cat'].window(0, C)
         elif self.reuse_ref_features and is_first:
             ref_bsf = cat.window(0, C)        # datasets/cityscapes_vps.py:137-148: the first frame's ref is itself
@@ -212,10 +217,12 @@ class PanopticFuseTrack(HipModule):
             proposals = self.rpn_head.run(x, ws, meta['img_shape'], self.test_cfg.rpn)
         self._mark('rpn')
         # (6) bbox head + MaskROI + tracking ---------------------------------------------------------------------
-        det = self.simple_test_bboxes(x, meta, proposals, im_info, is_first, ws, inject)
+        det = self.simple_test_bboxes(x, meta, proposals, im_info, is_first, ws, inject, defer_tracking)
         self._mark('bbox_track')
         det_bboxes, det_labels, det_obj_ids = det['det_bboxes'], det['det_labels'], det['det_obj_ids']
         cls_prob, mask_rois, cls_idx = det['cls_prob'], det['det_rois'], det['cls_idx']
+        if defer_tracking:
+            det_obj_ids = np.full((det_bboxes.size(0),), -1, dtype=np.int64)
         bbox_results = bbox2result_with_id(det_bboxes, det_labels, det_obj_ids, self.bbox_head.num_classes)
         mask_results = [[] for _ in range(self.mask_head.num_classes - 1)]       # simple_test_mask: `or True` stub
         # (8) mask head ------------------------------------------------------------------------------------------
@@ -249,30 +256,38 @@ class PanopticFuseTrack(HipModule):
             'panoptic_det_obj_ids': torch.from_numpy(np.asarray(det_obj_ids).astype(np.int64)).to(dev)[keep_t],
             'panoptic_outputs': pan,
         }
+        self._track_record = dict(det_bboxes=det_bboxes, det_labels=det_labels, cls_prob=cls_prob, emb=det['emb'],
+                                  keep_inds=keep_inds)
         self._aux = dict(flow=flow, levels=levels, cat=cat, neck_out=x, neck_aux=aux, fcn_score=fcn_score, det=det,
                          mask_score=mask_score, keep_inds=keep_inds, proposals=proposals)
         return bbox_results, mask_results, pano_results
 
     # ------------------------------------------------------------------------------------------------------
-    def simple_test_bboxes(self, x, meta, proposals, im_info, is_first, ws, inject=None):
-        """panoptic_fusetrack.py:358-471"""
+    def gathered_feature(self, img):
+        """gather(FPN(ResNet(img))) (bfp_tcea.py:96-109,117): the tensor the NEXT frame needs as ref_bsf; [1,H/4,W/4,C]"""
+        dev = img.device
+        self.ensure_packed(dev)
+        if self._ws is None or self._ws.device != dev:
+            self._ws = nhwc.Workspace(dev)
+        ws = self._ws
+        lv = self.neck.run(self.backbone.run(nhwc.from_nchw(img, ws, 'ho_nhwc'), ws, 'hbb.'), ws, 'hfpn.')
+        cat = self.extra_neck.gather(lv, ws, 'neck.handoff')
+        C = self.extra_neck.in_channels
+        return cat.t[..., :C].contiguous()
+
+    def track_assign(self, rec, is_first):
+        """sequential tracker step on a deferred record (clip_shard.py)"""
+        dev = rec['emb'].device
+        if self._ws is None or self._ws.device != dev:
+            self._ws = nhwc.Workspace(dev)
+        ids, _ = self._assign_ids(rec['det_bboxes'], rec['det_labels'], rec['cls_prob'], rec['emb'], is_first, self._ws)
+        return ids
+
+    def _assign_ids(self, det_bboxes, det_labels, cls_prob, emb, is_first, ws):
+        """panoptic_fusetrack.py:400-469 (tracking block of simple_test_bboxes)"""
         lib = hip.load()
-        dev = proposals.device
-        rois = torch.cat([proposals.new_zeros(proposals.size(0), 1), proposals[:, :4]], dim=-1).contiguous()   # bbox2roi
-        roi_feats = self.bbox_roi_extractor.run(x, rois)
-        cls_score, bbox_pred = self.bbox_head.run(roi_feats, ws)
-        if inject is not None and 'cls_score' in inject:
-            cls_score, bbox_pred = inject['cls_score'].to(dev).contiguous(), inject['bbox_pred'].to(dev).contiguous()
-        cls_prob_all = torch.empty_like(cls_score)
-        hip.check(lib.vps_row_softmax(hip.ptr(cls_score), hip.ptr(cls_prob_all), cls_score.shape[0], cls_score.shape[1], 0,
-                                      hip.stream_ptr()), 'vps_row_softmax')
-        cls_prob, det_rois, cls_idx = self.mask_roi_panoptic(rois, bbox_pred, cls_prob_all, im_info, ws)
-        det_labels = cls_idx - 1
-        det_rois = det_rois.contiguous()
-        det_roi_feats = self.bbox_roi_extractor.run(x, det_rois)
-        det_bboxes = det_rois[:, 1:]
+        dev = emb.device
         K = det_bboxes.size(0)
-        emb = self.track_head.embed(det_roi_feats, ws)
         comp_scores = None
         if is_first or self.prev_bboxes is None:
             det_obj_ids = np.arange(K)
@@ -323,6 +338,31 @@ class PanopticFuseTrack(HipModule):
                 self.prev_emb = torch.cat((self.prev_emb, emb[a]), dim=0)
                 self.prev_bboxes = torch.cat((self.prev_bboxes, det_bboxes[a]), dim=0)
                 self.prev_det_labels = torch.cat((self.prev_det_labels, det_labels[a]), dim=0)
+        return det_obj_ids, comp_scores
+
+    # ------------------------------------------------------------------------------------------------------
+    def simple_test_bboxes(self, x, meta, proposals, im_info, is_first, ws, inject=None, defer_tracking=False):
+        """panoptic_fusetrack.py:358-471"""
+        lib = hip.load()
+        dev = proposals.device
+        rois = torch.cat([proposals.new_zeros(proposals.size(0), 1), proposals[:, :4]], dim=-1).contiguous()   # bbox2roi
+        roi_feats = self.bbox_roi_extractor.run(x, rois)
+        cls_score, bbox_pred = self.bbox_head.run(roi_feats, ws)
+        if inject is not None and 'cls_score' in inject:
+            cls_score, bbox_pred = inject['cls_score'].to(dev).contiguous(), inject['bbox_pred'].to(dev).contiguous()
+        cls_prob_all = torch.empty_like(cls_score)
+        hip.check(lib.vps_row_softmax(hip.ptr(cls_score), hip.ptr(cls_prob_all), cls_score.shape[0], cls_score.shape[1], 0,
+                                      hip.stream_ptr()), 'vps_row_softmax')
+        cls_prob, det_rois, cls_idx = self.mask_roi_panoptic(rois, bbox_pred, cls_prob_all, im_info, ws)
+        det_labels = cls_idx - 1
+        det_rois = det_rois.contiguous()
+        det_roi_feats = self.bbox_roi_extractor.run(x, det_rois)
+        det_bboxes = det_rois[:, 1:]
+        K = det_bboxes.size(0)
+        emb = self.track_head.embed(det_roi_feats, ws)
+        det_obj_ids, comp_scores = None, None
+        if not defer_tracking:
+            det_obj_ids, comp_scores = self._assign_ids(det_bboxes, det_labels, cls_prob, emb, is_first, ws)
         return dict(det_bboxes=det_bboxes, det_labels=det_labels, det_obj_ids=det_obj_ids, cls_score=cls_score,
                     bbox_pred=bbox_pred, cls_prob=cls_prob, det_rois=det_rois, cls_idx=cls_idx, comp_scores=comp_scores,
                     det_roi_feats=det_roi_feats, emb=emb)

@@ -247,7 +247,10 @@ class PackedConv:
             e0.record()
             hip.conv2d(d)
             e1.record()
-            CONV_TRACE.append((self.flops(x.N, x.H, x.W), e0, e1))
+            CONV_TRACE.append((self.flops(x.N, x.H, x.W), e0, e1,
+                               '%d->%d k%dx%d s%d %s%s n%d %dx%d tile%d ksplit%d' % (self.cin, self.cout, self.KH, self.KW, self.stride,
+                                                                                   'T' if self.transposed else '', 'D' if self.deform else '',
+                                                                                   x.N, x.H, x.W, self.tile_n, ksplit)))
         else:
             hip.conv2d(d)
         return out

@@ -57,7 +57,9 @@ def synth_tensor(key, shape, seed=0):
         elif 'conv_offset' in key:
             std *= 0.5                                        # DCN offsets ~ N(0, <1 px)
         elif 'rpn_reg' in key:
-            std *= 0.15
+            std *= 0.03                                       # anchor deltas ~ N(0, 0.4)
+        elif 'rpn_cls' in key:
+            std *= 0.15                                       # objectness logits ~ N(0, 1.5): no saturated (tied) scores
         elif 'flow_estimator.convs.3' in key:
             std *= 0.3
         elif 'conv_logits' in key or 'conv_pred' in key:
