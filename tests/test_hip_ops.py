@@ -306,3 +306,24 @@ def test_delta2bbox_overlaps_softmax(dev):
         xd = x.to(dev)
         hip.check(lib.vps_row_softmax(hip.ptr(xd), hip.ptr(o), 300, 9, mode, hip.stream_ptr()), 'sm')
         _cmp(o, fn(x, dim=1), rtol=1e-5, atol=1e-6, what='softmax')
+
+
+# ------------------------------------------------------------------------------------------------ reference-named operator API
+def test_reference_named_operator_wrappers(dev):
+    """vps_amd/operators.py: the reference's operator classes (NCHW signatures) backed by the C-ABI"""
+    from vps_amd import operators as P
+    img = _rand(1, 3, 24, 32, seed=1); flow = _rand(1, 2, 24, 32, seed=2, scale=2.0)
+    _cmp(P.Resample2d()(img.to(dev), flow.to(dev)), O.resample2d(img, flow), 1e-6, 1e-6, 'Resample2d')
+    _cmp(P.ChannelNorm()(img.to(dev)), O.channelnorm(img), 1e-6, 1e-7, 'ChannelNorm')
+    a = _rand(1, 64, 10, 12, seed=3); b = _rand(1, 64, 10, 12, seed=4)
+    _cmp(P.Correlation(pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1)(a.to(dev), b.to(dev)),
+         O.correlation(a, b, 4, 1, 4, 1, 1), 1e-5, 1e-5, 'Correlation')
+    f = _rand(1, 16, 32, 48, seed=5); rois = _rand_rois(30, 128, 192, seed=6)
+    _cmp(P.RoIAlign(7, 1 / 4.0, 2)(f.to(dev), rois.to(dev)), O.roi_align(f, rois, 7, 0.25, 2), 5e-5, 5e-5, 'RoIAlign')
+    x = _rand(1, 32, 10, 14, seed=7); off = _rand(1, 18, 10, 14, seed=8)
+    dc = P.DeformConv(32, 64, 3, padding=1)
+    _cmp(dc(x.to(dev), off.to(dev)), O.deform_conv(x, off, dc.weight.detach(), 1, 1), 2e-5, 2e-5, 'DeformConv')
+    d = torch.cat([_rand_rois(200, 100, 150, seed=9)[:, 1:], torch.rand(200, 1)], 1)
+    kept, inds = P.nms(d.to(dev), 0.5)
+    assert torch.equal(inds.cpu(), O.nms_mmdet(d, 0.5)[1])
+    assert P.gpu_nms_wrapper(0.5, 0)(d.numpy()) == O.nms_upsnet(d.numpy(), 0.5)

@@ -244,7 +244,7 @@ class PanopticFuseTrack(HipModule):
                                     self.panopticFPN.num_stuff_classes, self.panopticFPN.num_classes, (H, W), ws, masks_valid)
         keep_t = torch.from_numpy(keep_inds).to(dev)
         h0, w0 = meta['img_shape'][0], meta['img_shape'][1]
-        pan = pan[:, 0:h0, 0:w0]; sem = sem[:, 0:h0, 0:w0]
+        pan = pan[:, 0:h0, 0:w0].clone(); sem = sem[:, 0:h0, 0:w0].clone()     # fresh tensors: the workspace is reused next frame
         if self.int64_outputs:
             pan, sem = pan.long(), sem.long()
         self._mark('panoptic_combine')
