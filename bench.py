@@ -60,6 +60,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--height', type=int, default=H)
     ap.add_argument('--width', type=int, default=W)
+    ap.add_argument('--prec', default='f32', choices=['f32', 'bf16x3', 'bf16x6'], help='arithmetic of the dense contractions')
     ap.add_argument('--conv-table', default=None, help='write the per-layer-shape conv timing table of one frame here')
     args = ap.parse_args()
 
@@ -75,7 +76,8 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
 
     import vps_amd
-    from vps_amd import nhwc, synth
+    from vps_amd import hip, nhwc, synth
+    nhwc.DEFAULT_PREC = {'f32': hip.PREC_F32, 'bf16x3': hip.PREC_BF16X3, 'bf16x6': hip.PREC_BF16X6}[args.prec]
     Hh, Ww = args.height, args.width
     cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', 'fusetrack.py'))
     model = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)

@@ -43,6 +43,11 @@ const char* vps_build_info(void);
  * (qy*os_y + py, qx*os_x + px).
  * -------------------------------------------------------------------------------------------- */
 enum { VPS_ACT_NONE = 0, VPS_ACT_RELU = 1, VPS_ACT_LEAKY = 2 };
+/* arithmetic of the contraction (accumulation is always fp32):
+ *   VPS_PREC_F32    exact fp32 MFMA (v_mfma_f32_32x32x2_f32), needs `w`
+ *   VPS_PREC_BF16X3 fp32 operands split into 2 bf16 terms, 3 bf16 MFMAs per product (~2^-16 relative), needs `w_split`
+ *   VPS_PREC_BF16X6 3 bf16 terms, 6 bf16 MFMAs per product (~2^-23 relative, fp32-grade), needs `w_split` */
+enum { VPS_PREC_F32 = 0, VPS_PREC_BF16X3 = 2, VPS_PREC_BF16X6 = 3 };
 
 typedef struct vps_conv_desc {
     /* input activation, NHWC */
@@ -77,6 +82,9 @@ typedef struct vps_conv_desc {
     int32_t tile_n;     /* 32, 64 or 128 */
     int32_t ksplit;     /* >=1; >1 needs ws of ksplit*M*cout_pad floats (M = nclass*N*Qh*Qw) */
     float* ws;
+    /* split-bf16 modes: weight planes [prec][nclass][cout_pad][kpad] bf16 (plane p = bf16 RNE of the residual after p terms) */
+    int32_t prec;       /* VPS_PREC_* */
+    const void* w_split;
 } vps_conv_desc;
 
 int vps_conv2d(const vps_conv_desc* d, void* stream);

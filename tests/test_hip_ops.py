@@ -54,8 +54,12 @@ CONV_CASES = [
 ]
 
 
+PRECS = [(hip.PREC_F32, 2e-5), (hip.PREC_BF16X3, 4e-4), (hip.PREC_BF16X6, 2e-5)]
+
+
+@pytest.mark.parametrize('prec,tol', PRECS, ids=['f32', 'bf16x3', 'bf16x6'])
 @pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'ci%d_co%d_k%d_s%d' % c[:4])
-def test_conv2d_matches_torch_cpu(dev, case):
+def test_conv2d_matches_torch_cpu(dev, case, prec, tol):
     cin, cout, k, stride, pad, H, W, act, bn, res = case
     x = _rand(1, cin, H, W, seed=1)
     w = _rand(cout, cin, k, k, seed=2, scale=(2.0 / (cin * k * k)) ** 0.5)
@@ -72,13 +76,13 @@ def test_conv2d_matches_torch_cpu(dev, case):
         ref = ref + r
     a = {'none': hip.ACT_NONE, 'relu': hip.ACT_RELU, 'leaky': hip.ACT_LEAKY}[act]
     ref = {'none': lambda t: t, 'relu': F.relu, 'leaky': lambda t: F.leaky_relu(t, 0.1)}[act](ref)
-    pc = nhwc.PackedConv(w, b, bnd, stride=stride, padding=pad, act=a, slope=0.1, device=dev)
+    pc = nhwc.PackedConv(w, b, bnd, stride=stride, padding=pad, act=a, slope=0.1, device=dev, prec=prec)
     ws = nhwc.Workspace(dev)
     xm = nhwc.from_nchw(x.to(dev))
     rm = nhwc.from_nchw(r.to(dev)) if res else None
     out = pc(xm, ws=ws, name='out', res=rm)
     torch.cuda.synchronize()
-    _cmp(out.to_nchw(), ref, what='conv %s' % (case,))
+    _cmp(out.to_nchw(), ref, rtol=tol, atol=tol * max(1.0, float(ref.abs().max()) / 4), what='conv %s prec %d' % (case, prec))
 
 
 def test_conv_writes_into_concat_window_and_reads_padded_window(dev):
@@ -103,16 +107,17 @@ def test_conv_writes_into_concat_window_and_reads_padded_window(dev):
     _cmp(out.to_nchw(), F.conv2d(full, w2, p2.shift.cpu(), padding=1), what='predict_flow on concat')
 
 
+@pytest.mark.parametrize('prec,tol', PRECS, ids=['f32', 'bf16x3', 'bf16x6'])
 @pytest.mark.parametrize('cin,cout,k,pad,H,W', [(1024, 512, 4, 1, 4, 8), (386, 64, 4, 1, 16, 24), (2, 2, 4, 1, 8, 12),
                                                 (256, 256, 2, 0, 14, 14), (162, 16, 4, 1, 20, 28)])
-def test_conv_transpose_matches_torch_cpu(dev, cin, cout, k, pad, H, W):
+def test_conv_transpose_matches_torch_cpu(dev, cin, cout, k, pad, H, W, prec, tol):
     x = _rand(2 if k == 2 else 1, cin, H, W, seed=1)
     w = _rand(cin, cout, k, k, seed=2, scale=(1.0 / (cin * k)) ** 0.5)
     b = _rand(cout, seed=3, scale=0.1)
     ref = F.leaky_relu(F.conv_transpose2d(x, w, b, stride=2, padding=pad), 0.1)
-    pc = nhwc.PackedConv(w, b, None, stride=2, padding=pad, act=hip.ACT_LEAKY, transposed=True, device=dev)
+    pc = nhwc.PackedConv(w, b, None, stride=2, padding=pad, act=hip.ACT_LEAKY, transposed=True, device=dev, prec=prec)
     out = pc(nhwc.from_nchw(x.to(dev)), ws=nhwc.Workspace(dev), name='o')
-    _cmp(out.to_nchw(), ref, what='deconv')
+    _cmp(out.to_nchw(), ref, rtol=tol, atol=tol * max(1.0, float(ref.abs().max()) / 4), what='deconv')
 
 
 def test_fpn_topdown_residual_upsample(dev):
@@ -136,15 +141,16 @@ def test_linear_as_conv_with_nhwc_flatten(dev):
     _cmp(out.t.view(R, 24), ref, what='linear')
 
 
+@pytest.mark.parametrize('prec,tol', PRECS, ids=['f32', 'bf16x3', 'bf16x6'])
 @pytest.mark.parametrize('cin,cout,H,W', [(256, 256, 12, 20), (256, 128, 9, 13), (128, 128, 16, 16)])
-def test_deform_conv_matches_oracle(dev, cin, cout, H, W):
+def test_deform_conv_matches_oracle(dev, cin, cout, H, W, prec, tol):
     x = _rand(1, cin, H, W, seed=1)
     off = _rand(1, 18, H, W, seed=2, scale=1.5)
     w = _rand(cout, cin, 3, 3, seed=3, scale=(2.0 / (cin * 9)) ** 0.5)
     ref = O.deform_conv(x, off, w, 1, 1)
-    pc = nhwc.PackedConv(w, None, None, 1, 1, device=dev, deform=True)
+    pc = nhwc.PackedConv(w, None, None, 1, 1, device=dev, deform=True, prec=prec)
     out = pc(nhwc.from_nchw(x.to(dev)), ws=nhwc.Workspace(dev), name='o', offset=nhwc.from_nchw(off.to(dev)))
-    _cmp(out.to_nchw(), ref, what='deform conv')
+    _cmp(out.to_nchw(), ref, rtol=tol, atol=tol * max(1.0, float(ref.abs().max()) / 4), what='deform conv')
 
 
 # ------------------------------------------------------------------------------------------------ flow ops

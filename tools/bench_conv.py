@@ -39,6 +39,7 @@ SHAPES = [  # name, cin, cout, k, stride, pad, H, W, transposed, deform
 
 
 def main():
+    prec = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     dev = torch.device('cuda:0')
     ws = nhwc.Workspace(dev)
     rows = []
@@ -46,7 +47,7 @@ def main():
         N = 100 if 'mask conv' in name else 1
         g = torch.Generator().manual_seed(0)
         w = torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k), generator=g) * 0.05
-        pc = nhwc.PackedConv(w, torch.zeros(cout), None, stride=s, padding=p, act=hip.ACT_LEAKY, transposed=tr, deform=df, device=dev)
+        pc = nhwc.PackedConv(w, torch.zeros(cout), None, stride=s, padding=p, act=hip.ACT_LEAKY, transposed=tr, deform=df, device=dev, prec=prec)
         x = nhwc.FMap(torch.randn(N, H, W, (cin + 3) // 4 * 4, device=dev), cin, 0)
         off = None
         if df:
@@ -64,7 +65,7 @@ def main():
         rows.append(dict(layer=name, ms=round(ms, 4), tflops=round(fl / ms / 1e9, 2), gflop=round(fl / 1e9, 2)))
         print('%-48s %8.3f ms  %7.2f TFLOP/s  (%.1f GFLOP)' % (name, ms, fl / ms / 1e9, fl / 1e9), flush=True)
     os.makedirs('gpurun_out', exist_ok=True)
-    json.dump(rows, open('gpurun_out/bench_conv.json', 'w'), indent=1)
+    json.dump(rows, open('gpurun_out/bench_conv_p%d.json' % prec, 'w'), indent=1)
 
 
 if __name__ == '__main__':

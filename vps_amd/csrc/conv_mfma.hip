@@ -47,6 +47,71 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+// ---- shared epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+template <int TM, int TN, int BN>
+__device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&acc)[TM][TN], const int M, const int tile_m,
+                                              const int tile_n, const int cls, const int split, const int py, const int px,
+                                              const int wm, const int wn, const int lane) {
+    const int col_l = lane & 31;
+    const int row_l = 4 * (lane >> 5);
+    if (d.ksplit > 1) {
+        float* __restrict__ ws = d.ws + ((size_t)(split * d.nclass + cls) * M) * d.cout_pad;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = tile_m * BM + wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+                if (m < M) {
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        const int co = tile_n * BN + wn * TN * 32 + b * 32 + col_l;
+                        ws[(size_t)m * d.cout_pad + co] = acc[a][b][r];
+                    }
+                }
+            }
+        return;
+    }
+
+    float sc[TN], sh[TN];
+    bool cok[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int co = tile_n * BN + wn * TN * 32 + b * 32 + col_l;
+        cok[b] = co < d.cout;
+        sc[b] = (cok[b] && d.scale) ? d.scale[co] : 1.f;
+        sh[b] = (cok[b] && d.shift) ? d.shift[co] : 0.f;
+    }
+    const bool simple_pix = (d.nclass == 1 && d.os_y == 1 && d.os_x == 1 && d.res_shift == 0);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = tile_m * BM + wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+            if (m >= M) continue;
+            size_t opix, rpix;
+            if (simple_pix) {
+                opix = rpix = (size_t)m;
+            } else {
+                const int qx = m % d.Qw;
+                const int tq = m / d.Qw;
+                const int qy = tq % d.Qh;
+                const int n = tq / d.Qh;
+                const int oy = qy * d.os_y + py, ox = qx * d.os_x + px;
+                opix = ((size_t)n * d.Ho + oy) * d.Wo + ox;
+                const int rs = d.res_shift;
+                rpix = ((size_t)n * (d.Ho >> rs) + (oy >> rs)) * (d.Wo >> rs) + (ox >> rs);
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                if (!cok[b]) continue;
+                const int co = tile_n * BN + wn * TN * 32 + b * 32 + col_l;
+                float v = acc[a][b][r] * sc[b] + sh[b];
+                if (d.res) v += d.res[rpix * d.res_ld + d.res_coff + co];
+                d.out[opix * d.out_ld + d.out_coff + co] = vps_act(v, d.act, d.slope);
+            }
+        }
+}
+
 template <int TM, int TN, int WAVES_M, int WAVES_N, bool DEFORM>
 __global__ __launch_bounds__(256, 2)
 void conv_mfma_f32_kernel(const vps_conv_desc d, const int M, const int tiles_m, const int tiles_n,
@@ -232,65 +297,241 @@ void conv_mfma_f32_kernel(const vps_conv_desc d, const int M, const int tiles_m,
         }
     }
 
-    // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int col_l = lane & 31;
-    const int row_l = 4 * (lane >> 5);
-    if (d.ksplit > 1) {
-        float* __restrict__ ws = d.ws + ((size_t)(split * d.nclass + cls) * M) * d.cout_pad;
+    conv_epilogue<TM, TN, BN>(d, acc, M, tile_m, tile_n, cls, split, py, px, wm, wn, lane);
+}
+
+// ================================================================================================
+// Split-bf16 variant: the same implicit GEMM on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA
+// rate) with fp32 operands decomposed into NS bf16 terms (x = x0 + x1 (+ x2), each term the bf16 RNE of the
+// remaining residual) and fp32 accumulation:
+//   NS = 2: products x0*w0 + x0*w1 + x1*w0          (3 MFMAs, relative error ~2^-16 per product, "bf16x3")
+//   NS = 3: x0w0 + x0w1 + x1w0 + x1w1 + x0w2 + x2w0 (6 MFMAs, relative error ~2^-23: fp32-grade,  "bf16x6")
+// Weights are split once on the host (planes [NS][class][cout_pad][kpad] bf16); activations stay fp32 in HBM and are
+// split by the thread that stages them into LDS (once per block, not once per consuming wave). LDS rows are
+// [row][32 k] bf16 with an 80-byte stride: the 16-byte fragment reads of a 16-lane group hit 16 distinct slots.
+// ================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int LDS_LDH = 40;   // bf16 elements per LDS row (32 + 8 pad) = 80 bytes
+
+template <int NS>
+__device__ __forceinline__ void split_bf16(const f32x4 v, bf16x4 (&out)[NS]) {
+    f32x4 r = v;
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+    for (int p = 0; p < NS; ++p) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = tile_m * BM + wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + row_l;
-                if (m < M) {
+        for (int e = 0; e < 4; ++e) {
+            const __bf16 h = (__bf16)r[e];
+            out[p][e] = h;
+            r[e] -= (float)h;
+        }
+    }
+}
+
+template <int TM, int TN, int WAVES_M, int WAVES_N, int NS, bool DEFORM>
+__global__ __launch_bounds__(256, 2)
+void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_m, const int tiles_n,
+                            const int ksteps_per_split) {
+    constexpr int BN = WAVES_N * TN * 32;
+    static_assert(WAVES_M * TM * 32 == BM, "block M tile must be 128");
+    static_assert(WAVES_M * WAVES_N == 4, "4 wavefronts per block");
+    constexpr int NBCH = (BN * 4 + 255) / 256;   // 16-byte weight chunks per thread per plane per k-step
+
+    __shared__ __attribute__((aligned(16))) __bf16 As[NS][BM * LDS_LDH];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[NS][BN * LDS_LDH];
+
+    const int t = threadIdx.x;
+    int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_n = swz % tiles_n; swz /= tiles_n;
+    const int tile_m = swz % tiles_m; swz /= tiles_m;
+    const int cls = swz % d.nclass;
+    const int split = swz / d.nclass;
+
+    const int py = cls / d.os_x, px = cls - py * d.os_x;
+    const int pad_y = d.pad_y[py], pad_x = d.pad_x[px];
+    const size_t plane = (size_t)d.nclass * d.cout_pad * d.kpad;   // elements per weight plane
+    const __bf16* __restrict__ wcls = reinterpret_cast<const __bf16*>(d.w_split) + (size_t)cls * d.cout_pad * d.kpad;
+
+    const int H = d.H, W = d.W, KH = d.KH, KW = d.KW, cin_pad = d.cin_pad;
+    const int k4 = t & 7;
+    const int r0 = t >> 3;
+
+    RowInfo ri[4];
 #pragma unroll
-                    for (int b = 0; b < TN; ++b) {
-                        const int co = tile_n * BN + wn * TN * 32 + b * 32 + col_l;
-                        ws[(size_t)m * d.cout_pad + co] = acc[a][b][r];
+    for (int i = 0; i < 4; ++i) {
+        const int m = tile_m * BM + r0 + 32 * i;
+        if (m < M) {
+            const int qx = m % d.Qw;
+            const int tq = m / d.Qw;
+            const int qy = tq % d.Qh;
+            const int n = tq / d.Qh;
+            ri[i].iy0 = qy * d.stride - pad_y;
+            ri[i].ix0 = qx * d.stride - pad_x;
+            ri[i].pixbase = n * H * W;
+            ri[i].moff = m;
+        } else {
+            ri[i].iy0 = -(1 << 24);
+            ri[i].ix0 = 0;
+            ri[i].pixbase = 0;
+            ri[i].moff = -1;
+        }
+    }
+
+    const int kstep0 = split * ksteps_per_split;
+    int nsteps = d.kpad / BK - kstep0;
+    if (nsteps > ksteps_per_split) nsteps = ksteps_per_split;
+    int ky, kx, ci;
+    {
+        const int kk = kstep0 * BK + k4 * 4;
+        const int tap = kk / cin_pad;
+        ci = kk - tap * cin_pad;
+        ky = tap / KW;
+        kx = tap - ky * KW;
+    }
+    // weight chunk of this thread: row bw_r (+64 per extra chunk), 8 bf16 starting at k = 8*bw_c
+    const int bw_c = t & 3, bw_r = t >> 2;
+    const __bf16* __restrict__ wrow = wcls + (size_t)(tile_n * BN + bw_r) * d.kpad + (size_t)kstep0 * BK + bw_c * 8;
+
+    f32x4 areg[4];
+    bf16x8 breg[NS][NBCH];
+    f32x4 dcv[DEFORM ? 4 : 1][4];
+    float dcw[DEFORM ? 4 : 1][4];
+
+    auto load_tiles = [&](int step) {
+        const bool kval = ky < KH;
+        if constexpr (!DEFORM) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int iy = ri[i].iy0 + ky, ix = ri[i].ix0 + kx;
+                const bool ok = kval && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) {
+                    const float* p = d.in + ((size_t)(ri[i].pixbase + iy * W + ix) * d.in_ld + d.in_coff + ci);
+                    v = *reinterpret_cast<const f32x4*>(p);
+                }
+                areg[i] = v;
+            }
+        } else {
+            const int tap = ky * KW + kx;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                dcv[i][0] = z; dcv[i][1] = z; dcv[i][2] = z; dcv[i][3] = z;
+                dcw[i][0] = 0.f; dcw[i][1] = 0.f; dcw[i][2] = 0.f; dcw[i][3] = 0.f;
+                if (kval && ri[i].moff >= 0) {
+                    const float* op = d.offset + (size_t)ri[i].moff * d.off_ld + 2 * tap;
+                    const float h_im = (float)(ri[i].iy0 + ky) + op[0];
+                    const float w_im = (float)(ri[i].ix0 + kx) + op[1];
+                    if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+                        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+                        const int h_high = h_low + 1, w_high = w_low + 1;
+                        const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+                        const float hh = 1.f - lh, hw = 1.f - lw;
+                        dcw[i][0] = hh * hw; dcw[i][1] = hh * lw; dcw[i][2] = lh * hw; dcw[i][3] = lh * lw;
+                        const float* base = d.in + (size_t)ri[i].pixbase * d.in_ld + d.in_coff + ci;
+                        if (h_low >= 0 && w_low >= 0)
+                            dcv[i][0] = *reinterpret_cast<const f32x4*>(base + (size_t)(h_low * W + w_low) * d.in_ld);
+                        if (h_low >= 0 && w_high <= W - 1)
+                            dcv[i][1] = *reinterpret_cast<const f32x4*>(base + (size_t)(h_low * W + w_high) * d.in_ld);
+                        if (h_high <= H - 1 && w_low >= 0)
+                            dcv[i][2] = *reinterpret_cast<const f32x4*>(base + (size_t)(h_high * W + w_low) * d.in_ld);
+                        if (h_high <= H - 1 && w_high <= W - 1)
+                            dcv[i][3] = *reinterpret_cast<const f32x4*>(base + (size_t)(h_high * W + w_high) * d.in_ld);
                     }
                 }
             }
-        return;
-    }
-
-    float sc[TN], sh[TN];
-    bool cok[TN];
+        }
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int co = tile_n * BN + wn * TN * 32 + b * 32 + col_l;
-        cok[b] = co < d.cout;
-        sc[b] = (cok[b] && d.scale) ? d.scale[co] : 1.f;
-        sh[b] = (cok[b] && d.shift) ? d.shift[co] : 0.f;
-    }
-    const bool simple_pix = (d.nclass == 1 && d.os_y == 1 && d.os_x == 1 && d.res_shift == 0);
+        for (int p = 0; p < NS; ++p)
+#pragma unroll
+            for (int j = 0; j < NBCH; ++j)
+                if (BN * 4 >= 256 || t < BN * 4)
+                    breg[p][j] = *reinterpret_cast<const bf16x8*>(wrow + (size_t)p * plane + (size_t)(64 * j) * d.kpad + (size_t)step * BK);
+        ci += BK;
+        while (ci >= cin_pad) {
+            ci -= cin_pad;
+            if (++kx == KW) { kx = 0; ++ky; }
+        }
+    };
+
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v;
+            if constexpr (DEFORM) {
+                v = dcw[i][0] * dcv[i][0] + dcw[i][1] * dcv[i][1] + dcw[i][2] * dcv[i][2] + dcw[i][3] * dcv[i][3];
+            } else {
+                v = areg[i];
+            }
+            bf16x4 sp[NS];
+            split_bf16<NS>(v, sp);
+#pragma unroll
+            for (int p = 0; p < NS; ++p)
+                *reinterpret_cast<bf16x4*>(&As[p][(r0 + 32 * i) * LDS_LDH + k4 * 4]) = sp[p];
+        }
+#pragma unroll
+        for (int p = 0; p < NS; ++p)
+#pragma unroll
+            for (int j = 0; j < NBCH; ++j)
+                if (BN * 4 >= 256 || t < BN * 4)
+                    *reinterpret_cast<bf16x8*>(&Bs[p][(bw_r + 64 * j) * LDS_LDH + bw_c * 8]) = breg[p][j];
+    };
+
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+    const int frag_off = (lane & 31) * LDS_LDH + (lane >> 5) * 8;
+
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = tile_m * BM + wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + row_l;
-            if (m >= M) continue;
-            size_t opix, rpix;
-            if (simple_pix) {
-                opix = rpix = (size_t)m;
-            } else {
-                const int qx = m % d.Qw;
-                const int tq = m / d.Qw;
-                const int qy = tq % d.Qh;
-                const int n = tq / d.Qh;
-                const int oy = qy * d.os_y + py, ox = qx * d.os_x + px;
-                opix = ((size_t)n * d.Ho + oy) * d.Wo + ox;
-                const int rs = d.res_shift;
-                rpix = ((size_t)n * (d.Ho >> rs) + (oy >> rs)) * (d.Wo >> rs) + (ox >> rs);
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    if (nsteps > 0) {
+        load_tiles(0);
+        store_tiles();
+    }
+    __syncthreads();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const bool more = step + 1 < nsteps;
+        if (more) load_tiles(step + 1);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {            // two K=16 MFMA slabs per 32-wide k-step
+            bf16x8 af[NS][TM], bf[NS][TN];
+#pragma unroll
+            for (int p = 0; p < NS; ++p) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+                    af[p][a] = *reinterpret_cast<const bf16x8*>(&As[p][(wm * TM * 32 + a * 32) * LDS_LDH + frag_off + m * 16]);
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    bf[p][b] = *reinterpret_cast<const bf16x8*>(&Bs[p][(wn * TN * 32 + b * 32) * LDS_LDH + frag_off + m * 16]);
             }
 #pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                if (!cok[b]) continue;
-                const int co = tile_n * BN + wn * TN * 32 + b * 32 + col_l;
-                float v = acc[a][b][r] * sc[b] + sh[b];
-                if (d.res) v += d.res[rpix * d.res_ld + d.res_coff + co];
-                d.out[opix * d.out_ld + d.out_coff + co] = vps_act(v, d.act, d.slope);
-            }
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    // smallest terms first
+                    if constexpr (NS == 3) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bf[0][b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[2][b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bf[1][b], acc[a][b], 0, 0, 0);
+                    }
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bf[0][b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[1][b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[0][b], acc[a][b], 0, 0, 0);
+                }
         }
+        __syncthreads();
+        if (more) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+    conv_epilogue<TM, TN, BN>(d, acc, M, tile_m, tile_n, cls, split, py, px, wm, wn, lane);
 }
 
 // sum the split-K partials and apply the epilogue
@@ -334,12 +575,19 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
     if (nsplit_eff != d.ksplit) return VPS_EARG(20);  // caller must pick ksplit | ceil-consistent
     const long nblk = (long)tiles_m * tiles_n * d.nclass * d.ksplit;
     if (nblk <= 0 || nblk > 0x7fffffffL) return VPS_EARG(21);
-    if (d.offset)
-        hipLaunchKernelGGL((conv_mfma_f32_kernel<TM, TN, WAVES_M, WAVES_N, true>), dim3((unsigned)nblk), dim3(256), 0, s,
-                           d, M, tiles_m, tiles_n, per_split);
-    else
-        hipLaunchKernelGGL((conv_mfma_f32_kernel<TM, TN, WAVES_M, WAVES_N, false>), dim3((unsigned)nblk), dim3(256), 0, s,
-                           d, M, tiles_m, tiles_n, per_split);
+#define VPS_CONV_LAUNCH(KERNEL)                                                                              \
+    hipLaunchKernelGGL((KERNEL), dim3((unsigned)nblk), dim3(256), 0, s, d, M, tiles_m, tiles_n, per_split)
+    if (d.prec == VPS_PREC_F32) {
+        if (d.offset) VPS_CONV_LAUNCH((conv_mfma_f32_kernel<TM, TN, WAVES_M, WAVES_N, true>));
+        else VPS_CONV_LAUNCH((conv_mfma_f32_kernel<TM, TN, WAVES_M, WAVES_N, false>));
+    } else if (d.prec == VPS_PREC_BF16X3) {
+        if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, 2, true>));
+        else VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, 2, false>));
+    } else {
+        if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, 3, true>));
+        else VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, 3, false>));
+    }
+#undef VPS_CONV_LAUNCH
     int st = vps_launch_status();
     if (st) return st;
     if (d.ksplit > 1) {
@@ -355,7 +603,9 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
 extern "C" int vps_conv2d(const vps_conv_desc* dp, void* stream) {
     if (!dp) return VPS_EARG(1);
     const vps_conv_desc& d = *dp;
-    if (!d.in || !d.w || !d.out) return VPS_EARG(2);
+    if (!d.in || !d.out) return VPS_EARG(2);
+    if (d.prec != VPS_PREC_F32 && d.prec != VPS_PREC_BF16X3 && d.prec != VPS_PREC_BF16X6) return VPS_EARG(12);
+    if (d.prec == VPS_PREC_F32 ? !d.w : !d.w_split) return VPS_EARG(13);
     if ((d.in_ld & 3) || (d.in_coff & 3) || (d.cin_pad & 3) || d.cin_pad <= 0) return VPS_EARG(3);
     if ((d.kpad % BK) || d.kpad < d.KH * d.KW * d.cin_pad) return VPS_EARG(4);
     if (d.tile_n != 32 && d.tile_n != 64 && d.tile_n != 128) return VPS_EARG(5);
@@ -363,7 +613,7 @@ extern "C" int vps_conv2d(const vps_conv_desc* dp, void* stream) {
     if (d.nclass != d.os_y * d.os_x || d.nclass < 1 || d.os_y > 2 || d.os_x > 2) return VPS_EARG(7);
     if (d.ksplit < 1 || (d.ksplit > 1 && !d.ws)) return VPS_EARG(8);
     if (d.offset && (d.nclass != 1 || d.off_ld < 2 * d.KH * d.KW)) return VPS_EARG(9);
-    if (((uintptr_t)d.in & 15) || ((uintptr_t)d.w & 15)) return VPS_EARG(10);
+    if (((uintptr_t)d.in & 15) || ((uintptr_t)d.w & 15) || ((uintptr_t)d.w_split & 15)) return VPS_EARG(10);
     const long Ml = (long)d.N * d.Qh * d.Qw;
     if (Ml <= 0 || Ml > 0x7fffffffL) return VPS_EARG(11);
     const int M = (int)Ml;

@@ -13,9 +13,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libvpship.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 2, 3
 
 # every symbol include/vps_hip.h declares (checked by tests/test_cabi.py without a GPU)
 SYMBOLS = [
@@ -41,6 +42,7 @@ class ConvDesc(Structure):
         ('act', c_int32), ('slope', c_float),
         ('offset', c_void_p), ('off_ld', c_int32),
         ('tile_n', c_int32), ('ksplit', c_int32), ('ws', c_void_p),
+        ('prec', c_int32), ('w_split', c_void_p),
     ]
 
 

@@ -18,6 +18,9 @@ def _ceil(a, b):
     return (a + b - 1) // b * b
 
 
+# arithmetic of every PackedConv created without an explicit `prec` (hip.PREC_F32 exact / PREC_BF16X3 / PREC_BF16X6)
+DEFAULT_PREC = hip.PREC_F32
+
 # bench.py sets this to a list to time every vps_conv2d launch with HIP events on the launch stream:
 # entries (algorithmic_flops, start_event, end_event). None = no instrumentation (the default).
 CONV_TRACE = None
@@ -103,8 +106,9 @@ class PackedConv:
     """
 
     def __init__(self, weight, bias=None, bn=None, stride=1, padding=0, act=hip.ACT_NONE, slope=0.1,
-                 transposed=False, deform=False, device='cuda'):
+                 transposed=False, deform=False, device='cuda', prec=None):
         w = weight.detach().float().cpu()
+        self.prec = DEFAULT_PREC if prec is None else prec
         self.stride = stride
         self.act, self.slope = act, float(slope)
         self.deform = deform
@@ -151,7 +155,7 @@ class PackedConv:
         packed = torch.zeros(self.nclass, self.cout_pad, self.kpad)
         for c, b in enumerate(blocks):
             packed[c, :O, :K] = b
-        self.w = packed.to(device)
+        self._set_weights(packed, device)
         # epilogue: y = acc*scale + shift
         scale = torch.ones(O)
         shift = torch.zeros(O) if bias is None else bias.detach().float().cpu().clone()
@@ -167,8 +171,20 @@ class PackedConv:
         self.scale = scale.to(device) if self.has_scale else None
         self.shift = shift.to(device) if (bias is not None or bn is not None) else None
 
+    def _set_weights(self, packed, device):
+        """packed fp32 [nclass][cout_pad][kpad] (host or device) -> the operand format of the selected arithmetic"""
+        if self.prec == hip.PREC_F32:
+            self.w, self.w_split = packed.to(device), None
+            return
+        planes, r = [], packed.to(device)
+        for _ in range(self.prec):                      # term p = bf16 RNE of the residual after p terms
+            h = r.to(torch.bfloat16)
+            planes.append(h)
+            r = r - h.float()
+        self.w, self.w_split = None, torch.stack(planes, 0).contiguous()
+
     @classmethod
-    def from_matrix(cls, mat):
+    def from_matrix(cls, mat, prec=None):
         """GEMM against a device matrix mat [M, D] (rows = output channels) without a host round trip: out = x @ mat^T."""
         M, D = mat.shape
         assert D % 32 == 0
@@ -182,7 +198,9 @@ class PackedConv:
         self.cout_pad = _ceil(M, self.tile_n)
         w = torch.zeros(1, self.cout_pad, D, dtype=torch.float32, device=mat.device)
         w[0, :M] = mat
-        self.w, self.scale, self.shift, self.has_scale = w, None, None, False
+        self.prec = DEFAULT_PREC if prec is None else prec
+        self._set_weights(w, mat.device)
+        self.scale, self.shift, self.has_scale = None, None, False
         return self
 
     def out_hw(self, H, W):
@@ -202,7 +220,12 @@ class PackedConv:
         d = hip.ConvDesc()
         d.inp = x.t.data_ptr(); d.N, d.H, d.W = x.N, x.H, x.W
         d.in_ld, d.in_coff, d.cin_pad = x.ld, x.coff, self.cin_pad
-        d.w = self.w.data_ptr(); d.cout, d.cout_pad, d.kpad = self.cout, self.cout_pad, self.kpad
+        d.prec = self.prec
+        if self.prec == hip.PREC_F32:
+            d.w = self.w.data_ptr()
+        else:
+            d.w_split = self.w_split.data_ptr()
+        d.cout, d.cout_pad, d.kpad = self.cout, self.cout_pad, self.kpad
         d.KH, d.KW, d.stride = self.KH, self.KW, self.stride
         d.pad_y[0], d.pad_y[1] = self.pad_y; d.pad_x[0], d.pad_x[1] = self.pad_x
         d.out = out.t.data_ptr(); d.Ho, d.Wo, d.out_ld, d.out_coff = Ho, Wo, out.ld, out.coff
@@ -248,9 +271,9 @@ class PackedConv:
             hip.conv2d(d)
             e1.record()
             CONV_TRACE.append((self.flops(x.N, x.H, x.W), e0, e1,
-                               '%d->%d k%dx%d s%d %s%s n%d %dx%d tile%d ksplit%d' % (self.cin, self.cout, self.KH, self.KW, self.stride,
+                               '%d->%d k%dx%d s%d %s%s n%d %dx%d tile%d ksplit%d p%d' % (self.cin, self.cout, self.KH, self.KW, self.stride,
                                                                                    'T' if self.transposed else '', 'D' if self.deform else '',
-                                                                                   x.N, x.H, x.W, self.tile_n, ksplit)))
+                                                                                   x.N, x.H, x.W, self.tile_n, ksplit, self.prec)))
         else:
             hip.conv2d(d)
         return out
@@ -263,7 +286,7 @@ class PackedConv:
         return 2.0 * x_N * Ho * Wo * self.cout * self.cin * self.KH * self.KW
 
 
-def pack_conv_module(m, bn=None, act=hip.ACT_NONE, slope=0.1, device='cuda', deform=False):
+def pack_conv_module(m, bn=None, act=hip.ACT_NONE, slope=0.1, device='cuda', deform=False, prec=None):
     """torch.nn.Conv2d / ConvTranspose2d (used purely as a parameter container) -> PackedConv."""
     import torch.nn as nn
     bnd = None
@@ -271,19 +294,19 @@ def pack_conv_module(m, bn=None, act=hip.ACT_NONE, slope=0.1, device='cuda', def
         bnd = dict(weight=bn.weight, bias=bn.bias, running_mean=bn.running_mean, running_var=bn.running_var, eps=bn.eps)
     if isinstance(m, nn.ConvTranspose2d):
         return PackedConv(m.weight, m.bias, bnd, stride=m.stride[0], padding=m.padding[0], act=act, slope=slope,
-                          transposed=True, device=device)
+                          transposed=True, device=device, prec=prec)
     return PackedConv(m.weight, m.bias, bnd, stride=m.stride[0], padding=m.padding[0], act=act, slope=slope,
-                      device=device, deform=deform)
+                      device=device, deform=deform, prec=prec)
 
 
-def pack_linear(weight, bias, act=hip.ACT_NONE, device='cuda', chw=None):
+def pack_linear(weight, bias, act=hip.ACT_NONE, device='cuda', chw=None, prec=None):
     """nn.Linear as a 1x1 conv over `rows` pixels. chw=(C,S): the reference flattens NCHW [C, S=h*w] while the NHWC
     RoI features flatten as [S, C] -> permute the weight columns once at pack time."""
     w = weight.detach().float().cpu()
     if chw is not None:
         C, S = chw
         w = w.view(w.shape[0], C, S).permute(0, 2, 1).reshape(w.shape[0], C * S)
-    return PackedConv(w.view(w.shape[0], w.shape[1], 1, 1), bias, None, 1, 0, act=act, device=device)
+    return PackedConv(w.view(w.shape[0], w.shape[1], 1, 1), bias, None, 1, 0, act=act, device=device, prec=prec)
 
 
 # ------------------------------------------------------------------------------------------------------------
