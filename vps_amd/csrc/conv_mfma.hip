@@ -199,30 +199,31 @@ void conv_mfma_f32_kernel(const vps_conv_desc d, const int M, const int tiles_m,
             const int tap = ky * KW + kx;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                dcv[i][0] = z; dcv[i][1] = z; dcv[i][2] = z; dcv[i][3] = z;
-                dcw[i][0] = 0.f; dcw[i][1] = 0.f; dcw[i][2] = 0.f; dcw[i][3] = 0.f;
-                if (kval && ri[i].moff >= 0) {
-                    const float* op = d.offset + (size_t)ri[i].moff * d.off_ld + 2 * tap;
-                    const float h_im = (float)(ri[i].iy0 + ky) + op[0];
-                    const float w_im = (float)(ri[i].ix0 + kx) + op[1];
-                    if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-                        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-                        const int h_high = h_low + 1, w_high = w_low + 1;
-                        const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
-                        const float hh = 1.f - lh, hw = 1.f - lw;
-                        dcw[i][0] = hh * hw; dcw[i][1] = hh * lw; dcw[i][2] = lh * hw; dcw[i][3] = lh * lw;
-                        const float* base = d.in + (size_t)ri[i].pixbase * d.in_ld + d.in_coff + ci;
-                        if (h_low >= 0 && w_low >= 0)
-                            dcv[i][0] = *reinterpret_cast<const f32x4*>(base + (size_t)(h_low * W + w_low) * d.in_ld);
-                        if (h_low >= 0 && w_high <= W - 1)
-                            dcv[i][1] = *reinterpret_cast<const f32x4*>(base + (size_t)(h_low * W + w_high) * d.in_ld);
-                        if (h_high <= H - 1 && w_low >= 0)
-                            dcv[i][2] = *reinterpret_cast<const f32x4*>(base + (size_t)(h_high * W + w_low) * d.in_ld);
-                        if (h_high <= H - 1 && w_high <= W - 1)
-                            dcv[i][3] = *reinterpret_cast<const f32x4*>(base + (size_t)(h_high * W + w_high) * d.in_ld);
-                    }
-                }
+                // branch-free: corner weights are zeroed where the reference zeroes the corner value (or skips the whole
+                // sample), corner addresses are clamped into the image, and all four float4 loads are always issued
+                const bool act = kval && ri[i].moff >= 0;
+                const float* op = d.offset + (size_t)(act ? ri[i].moff : 0) * d.off_ld + 2 * min(tap, KH * KW - 1);
+                const float h_im = (float)(ri[i].iy0 + ky) + op[0];
+                const float w_im = (float)(ri[i].ix0 + kx) + op[1];
+                const bool inside = act && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+                const float hf = floorf(h_im), wf = floorf(w_im);
+                const int h_low = inside ? (int)hf : 0, w_low = inside ? (int)wf : 0;
+                const int h_high = h_low + 1, w_high = w_low + 1;
+                const float lh = h_im - hf, lw = w_im - wf;
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                const bool hl = inside && h_low >= 0, hhv = inside && h_high <= H - 1;
+                const bool wl = w_low >= 0, whv = w_high <= W - 1;
+                dcw[i][0] = (hl && wl) ? hh * hw : 0.f;
+                dcw[i][1] = (hl && whv) ? hh * lw : 0.f;
+                dcw[i][2] = (hhv && wl) ? lh * hw : 0.f;
+                dcw[i][3] = (hhv && whv) ? lh * lw : 0.f;
+                const int hlc = min(max(h_low, 0), H - 1), hhc = min(max(h_high, 0), H - 1);
+                const int wlc = min(max(w_low, 0), W - 1), whc = min(max(w_high, 0), W - 1);
+                const float* base = d.in + (size_t)ri[i].pixbase * d.in_ld + d.in_coff + ci;
+                dcv[i][0] = *reinterpret_cast<const f32x4*>(base + (size_t)(hlc * W + wlc) * d.in_ld);
+                dcv[i][1] = *reinterpret_cast<const f32x4*>(base + (size_t)(hlc * W + whc) * d.in_ld);
+                dcv[i][2] = *reinterpret_cast<const f32x4*>(base + (size_t)(hhc * W + wlc) * d.in_ld);
+                dcv[i][3] = *reinterpret_cast<const f32x4*>(base + (size_t)(hhc * W + whc) * d.in_ld);
             }
         }
 #pragma unroll
@@ -415,30 +416,31 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
             const int tap = ky * KW + kx;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                dcv[i][0] = z; dcv[i][1] = z; dcv[i][2] = z; dcv[i][3] = z;
-                dcw[i][0] = 0.f; dcw[i][1] = 0.f; dcw[i][2] = 0.f; dcw[i][3] = 0.f;
-                if (kval && ri[i].moff >= 0) {
-                    const float* op = d.offset + (size_t)ri[i].moff * d.off_ld + 2 * tap;
-                    const float h_im = (float)(ri[i].iy0 + ky) + op[0];
-                    const float w_im = (float)(ri[i].ix0 + kx) + op[1];
-                    if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-                        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-                        const int h_high = h_low + 1, w_high = w_low + 1;
-                        const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
-                        const float hh = 1.f - lh, hw = 1.f - lw;
-                        dcw[i][0] = hh * hw; dcw[i][1] = hh * lw; dcw[i][2] = lh * hw; dcw[i][3] = lh * lw;
-                        const float* base = d.in + (size_t)ri[i].pixbase * d.in_ld + d.in_coff + ci;
-                        if (h_low >= 0 && w_low >= 0)
-                            dcv[i][0] = *reinterpret_cast<const f32x4*>(base + (size_t)(h_low * W + w_low) * d.in_ld);
-                        if (h_low >= 0 && w_high <= W - 1)
-                            dcv[i][1] = *reinterpret_cast<const f32x4*>(base + (size_t)(h_low * W + w_high) * d.in_ld);
-                        if (h_high <= H - 1 && w_low >= 0)
-                            dcv[i][2] = *reinterpret_cast<const f32x4*>(base + (size_t)(h_high * W + w_low) * d.in_ld);
-                        if (h_high <= H - 1 && w_high <= W - 1)
-                            dcv[i][3] = *reinterpret_cast<const f32x4*>(base + (size_t)(h_high * W + w_high) * d.in_ld);
-                    }
-                }
+                // branch-free: corner weights are zeroed where the reference zeroes the corner value (or skips the whole
+                // sample), corner addresses are clamped into the image, and all four float4 loads are always issued
+                const bool act = kval && ri[i].moff >= 0;
+                const float* op = d.offset + (size_t)(act ? ri[i].moff : 0) * d.off_ld + 2 * min(tap, KH * KW - 1);
+                const float h_im = (float)(ri[i].iy0 + ky) + op[0];
+                const float w_im = (float)(ri[i].ix0 + kx) + op[1];
+                const bool inside = act && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+                const float hf = floorf(h_im), wf = floorf(w_im);
+                const int h_low = inside ? (int)hf : 0, w_low = inside ? (int)wf : 0;
+                const int h_high = h_low + 1, w_high = w_low + 1;
+                const float lh = h_im - hf, lw = w_im - wf;
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                const bool hl = inside && h_low >= 0, hhv = inside && h_high <= H - 1;
+                const bool wl = w_low >= 0, whv = w_high <= W - 1;
+                dcw[i][0] = (hl && wl) ? hh * hw : 0.f;
+                dcw[i][1] = (hl && whv) ? hh * lw : 0.f;
+                dcw[i][2] = (hhv && wl) ? lh * hw : 0.f;
+                dcw[i][3] = (hhv && whv) ? lh * lw : 0.f;
+                const int hlc = min(max(h_low, 0), H - 1), hhc = min(max(h_high, 0), H - 1);
+                const int wlc = min(max(w_low, 0), W - 1), whc = min(max(w_high, 0), W - 1);
+                const float* base = d.in + (size_t)ri[i].pixbase * d.in_ld + d.in_coff + ci;
+                dcv[i][0] = *reinterpret_cast<const f32x4*>(base + (size_t)(hlc * W + wlc) * d.in_ld);
+                dcv[i][1] = *reinterpret_cast<const f32x4*>(base + (size_t)(hlc * W + whc) * d.in_ld);
+                dcv[i][2] = *reinterpret_cast<const f32x4*>(base + (size_t)(hhc * W + wlc) * d.in_ld);
+                dcv[i][3] = *reinterpret_cast<const f32x4*>(base + (size_t)(hhc * W + whc) * d.in_ld);
             }
         }
 #pragma unroll
