@@ -69,7 +69,8 @@ def test_stage_tensors_match_oracle(setup, runs, t):
     # proposals are score-sorted; rows whose scores differ by less than the fp32 noise may swap -> align rows by box
     ph, po = a['proposals'], r['det']['proposals']
     assert ph.shape == po.shape
-    dist = (ph[:, None, :4] - po[None, :, :4]).abs().amax(2)
+    # clamped boxes can coincide (several anchors decode to the same clipped box): match on box AND score
+    dist = torch.maximum((ph[:, None, :4] - po[None, :, :4]).abs().amax(2), 500.0 * (ph[:, None, 4] - po[None, :, 4]).abs())
     match = dist.argmin(1)
     # an NMS decision with IoU within fp32 noise of the 0.7 threshold may flip: allow <= 1 % unmatched proposals
     dmin = dist.gather(1, match[:, None])[:, 0]

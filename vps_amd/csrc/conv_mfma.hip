@@ -512,20 +512,17 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
                 for (int b = 0; b < TN; ++b)
                     bf[p][b] = *reinterpret_cast<const bf16x8*>(&Bs[p][(wn * TN * 32 + b * 32) * LDS_LDH + frag_off + m * 16]);
             }
+            // product terms outermost (smallest first), accumulators innermost: consecutive MFMAs never depend on each other
+            constexpr int NT = NS == 3 ? 6 : 3;
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+            constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
+            for (int q = 6 - NT; q < 6; ++q)
 #pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    // smallest terms first
-                    if constexpr (NS == 3) {
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][a], bf[0][b], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[2][b], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bf[1][b], acc[a][b], 0, 0, 0);
-                    }
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bf[0][b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[1][b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][a], bf[0][b], acc[a][b], 0, 0, 0);
-                }
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[q]][a], bf[PB[q]][b], acc[a][b], 0, 0, 0);
         }
         __syncthreads();
         if (more) {
