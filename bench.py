@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 warnings.simplefilter('ignore')
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA dense peak (not the 2:1-sparse headline)
 H, W = 1024, 2048
 
 
@@ -60,7 +61,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--height', type=int, default=H)
     ap.add_argument('--width', type=int, default=W)
-    ap.add_argument('--prec', default='f32', choices=['f32', 'bf16x3', 'bf16x6'], help='arithmetic of the dense contractions')
+    ap.add_argument('--prec', default='bf16x6', choices=['f32', 'bf16x3', 'bf16x6'], help='arithmetic of the dense contractions')
     ap.add_argument('--conv-table', default=None, help='write the per-layer-shape conv timing table of one frame here')
     args = ap.parse_args()
 
@@ -164,8 +165,14 @@ def main():
         nhwc.CONV_TRACE = None
         model.profile = None
         ach = fl / (ms * 1e-3) / 1e12
-        roof = dict(bound='mfma', kernel='conv_mfma_f32_kernel', achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS,
-                    unit='TFLOP/s', frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+        # algorithmic FLOPs (2*MAC, unpadded) / launch time. f32: exact fp32 MFMA, peak 157.3. bf16xN: every fp32 product is
+        # N bf16 MFMA products (fp32 accumulate): the matrix pipe executes N x the algorithmic FLOPs against the bf16 peak.
+        nprod = {'f32': 1, 'bf16x3': 3, 'bf16x6': 6}[args.prec]
+        peak = PEAK_FP32_MFMA_TFLOPS if args.prec == 'f32' else PEAK_BF16_MFMA_TFLOPS
+        roof = dict(bound='mfma', kernel='conv_mfma_f32_kernel' if args.prec == 'f32' else 'conv_mfma_bf16s_kernel',
+                    achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
+                    mfma_products_per_fp32_product=nprod, executed_tflops=round(ach * nprod, 1),
+                    executed_frac=round(ach * nprod / peak, 4),
                     launches_per_frame=nl, gflop_per_frame=round(fl / 1e9, 1), conv_ms_per_frame=round(ms, 3))
 
     if rank == 0:
@@ -173,7 +180,9 @@ def main():
         line = {
             'metric': 'frames/sec FuseTrack 1024x2048', 'value': round(fps, 3), 'unit': 'frames/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': {'f32': 'f32', 'bf16x6': 'f32-grade: bf16x6 split operands on MFMA, f32 accumulate',
+                      'bf16x3': 'bf16x3 split operands on MFMA, f32 accumulate'}[args.prec], 'data': 'synthetic',
             'config': {'workload': '2-frame pair FuseTrack (FlowNet2 + ResNet50-FPN + BFP-TCEA + UPSNet panoptic + track head), '
                                    'synthetic %dx%d clip, batch 1, one clip shard per GPU' % (Hh, Ww),
                        'weights': 'synthetic (vps_amd.synth seed %d)' % args.seed,

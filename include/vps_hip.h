@@ -227,6 +227,12 @@ int vps_mask_count(const float* logit, int S, int bx1, int by1, int bx2, int by2
 int vps_mask_commit(const float* logit, int S, int bx1, int by1, int bx2, int by2, int H, int W,
                     uint8_t* occ, const int32_t* counts, double thr, int32_t* flag, void* stream);
 
+/* the whole MaskRemoval box loop in ONE launch (one workgroup per class walks the score-sorted boxes; masks of different
+ * classes never interact). boxes [n][4] int32-truncated (x1,y1,x2,y2), cls0[n] 0-based class, mask_idx[n] row of logits,
+ * all in descending-score order and on the device; occ: ncls*H*W uint8 workspace (zeroed by the call); flags[n] = kept. */
+int vps_mask_removal(const float* logits, int S, const int32_t* boxes, const int32_t* cls0, const int32_t* mask_idx,
+                     int n, int ncls, int H, int W, uint8_t* occ, double thr, int32_t* flags, void* stream);
+
 /* one kept instance of the panoptic combine */
 typedef struct vps_pan_inst {
     int32_t sx0, sy0, sx1, sy1;     /* SegTerm crop [x0,x1) x [y0,y1): int(b), int(round(b)+1) (unary_logits.py:102-105) */

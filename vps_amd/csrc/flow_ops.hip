@@ -135,6 +135,95 @@ void correlation_kernel(const float* __restrict__ in1, int ld1, int coff1,
     }
 }
 
+// Specialised correlation for the two configurations on the path (FlowNetC: stride2 2, radius 10; LiteFlowNetCorr:
+// stride2 1, radius 4). The generic kernel above re-reads every in2 sample once per output pixel and is L2-bandwidth
+// bound (14.5 GB of L2 reads for FlowNetC at 128x256). Here one wavefront owns FOUR output pixels spaced stride2 apart on
+// a row: their displacement windows overlap in all but 3 columns, so each in2 sample (1 KiB coalesced load) is used by
+// up to four pixels from registers (3.5x fewer loads). Cross-lane sums use the same transposing butterfly; slot
+// (ti, p) -> lane, so each pixel's displacement run is stored as contiguous floats.
+template <int S2, int R, int NC4>
+__global__ __launch_bounds__(256)
+void correlation4_kernel(const float* __restrict__ in1, int ld1, int coff1,
+                         const float* __restrict__ in2, int ld2, int coff2,
+                         float* __restrict__ out, int out_ld, int out_coff,
+                         int N, int H, int W, int C, int act, float slope) {
+    constexpr int D = 2 * R + 1;
+    constexpr int NBATCH = (D + 15) / 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int gpr = W / 4;                       // pixel groups per row
+    const long ngroups = (long)N * H * gpr;
+    const int c4n = C >> 2;
+    const float invC = 1.0f / (float)C;
+    for (long grp = (long)blockIdx.x * 4 + wave; grp < ngroups; grp += (long)gridDim.x * 4) {
+        const int g = (int)(grp % gpr);
+        const int y = (int)((grp / gpr) % H);
+        const int n = (int)(grp / ((long)gpr * H));
+        const int xb = (S2 == 2) ? (8 * (g >> 1) + (g & 1)) : 4 * g;
+        const size_t rowbase = ((size_t)n * H + y) * W;
+        f32x4 a[4][NC4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < NC4; ++q) {
+                const int c4 = lane + 64 * q;
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                a[p][q] = c4 < c4n ? *reinterpret_cast<const f32x4*>(in1 + (rowbase + xb + p * S2) * ld1 + coff1 + 4 * c4) : z;
+            }
+        for (int tj = -R; tj <= R; ++tj) {
+            const int y2 = y + tj * S2;
+            const bool rowok = (unsigned)y2 < (unsigned)H;
+            const float* __restrict__ row2 = in2 + ((size_t)n * H + (rowok ? y2 : 0)) * W * ld2 + coff2;
+#pragma unroll
+            for (int bt = 0; bt < NBATCH; ++bt) {
+                constexpr int dummy = 0; (void)dummy;
+                const int base = bt * 16;                 // first displacement index of this batch
+                float v[64];
+#pragma unroll
+                for (int i = 0; i < 64; ++i) v[i] = 0.f;
+                // columns uu = ti_idx + p needed by slots (ti_idx in [base, base+16) , p in [0,4))
+#pragma unroll
+                for (int du = 0; du < 19; ++du) {
+                    const int uu = base + du;
+                    if (uu > D - 1 + 3) continue;
+                    const int x2 = xb + S2 * (uu - R);
+                    f32x4 b[NC4];
+                    const bool ok = rowok && (unsigned)x2 < (unsigned)W;
+#pragma unroll
+                    for (int q = 0; q < NC4; ++q) {
+                        const int c4 = lane + 64 * q;
+                        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        b[q] = (ok && c4 < c4n) ? *reinterpret_cast<const f32x4*>(row2 + (size_t)x2 * ld2 + 4 * c4) : z;
+                    }
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int ti = uu - p;            // displacement index of pixel p fed by this column
+                        if (ti < base || ti >= base + 16 || ti > D - 1) continue;
+                        float acc = 0.f;
+#pragma unroll
+                        for (int q = 0; q < NC4; ++q)
+                            acc += a[p][q][0] * b[q][0] + a[p][q][1] * b[q][1] + a[p][q][2] * b[q][2] + a[p][q][3] * b[q][3];
+                        v[(ti - base) * 4 + p] = acc;
+                    }
+                }
+#pragma unroll
+                for (int off = 32, nn = 64; off >= 1; off >>= 1, nn >>= 1) {
+                    const bool hi = (lane & off) != 0;
+#pragma unroll
+                    for (int i = 0; i < nn / 2; ++i) {
+                        const float keep = hi ? v[i + nn / 2] : v[i];
+                        const float send = hi ? v[i] : v[i + nn / 2];
+                        v[i] = keep + __shfl_xor(send, off, 64);
+                    }
+                }
+                const int ti = base + (lane >> 2), p = lane & 3;
+                if (ti < D)
+                    out[(rowbase + xb + p * S2) * out_ld + out_coff + (tj + R) * D + ti] = vps_act(v[0] * invC, act, slope);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // flow_modules.py:126-148 WarpingLayer: grid = linspace(-1,1) + flow/((size-1)/2), then F.grid_sample with
 // its defaults (bilinear, zeros, align_corners=False) — the align_corners mismatch is reproduced, not fixed.
@@ -383,6 +472,13 @@ extern "C" int vps_correlation(const float* in1, int ld1, int coff1, const float
     const long npix = (long)N * H * W;
     long g = (npix + 3) / 4; if (g > 65536) g = 65536;
     hipStream_t s = (hipStream_t)stream;
+#define CORR4_LAUNCH(S2, R, NC4)                                                                                       \
+    hipLaunchKernelGGL((correlation4_kernel<S2, R, NC4>), dim3((unsigned)g4), dim3(256), 0, s, in1, ld1, coff1, in2, ld2, \
+                       coff2, out, out_ld, out_coff, N, H, W, C, act, slope)
+    long g4 = ((long)N * H * (W / 4) + 3) / 4; if (g4 > 65536) g4 = 65536;
+    if (stride2 == 2 && r == 10 && (W % 8) == 0 && C <= 256) { CORR4_LAUNCH(2, 10, 1); return vps_launch_status(); }
+    if (stride2 == 1 && r == 4 && (W % 4) == 0 && C <= 256) { CORR4_LAUNCH(1, 4, 1); return vps_launch_status(); }
+#undef CORR4_LAUNCH
 #define CORR_LAUNCH(NC4)                                                                                        \
     hipLaunchKernelGGL((correlation_kernel<NC4>), dim3((unsigned)g), dim3(256), 0, s, in1, ld1, coff1, in2, ld2, \
                        coff2, out, out_ld, out_coff, N, H, W, C, r, stride2, act, slope)

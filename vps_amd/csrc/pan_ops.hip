@@ -86,6 +86,56 @@ void mask_commit_kernel(const float* __restrict__ logit, int S, int bx1, int by1
 }
 
 // ------------------------------------------------------------------------------------------------
+// The whole MaskRemoval box loop (mask_removal.py:56-88) in ONE launch: masks only interact within a class, so one
+// 1024-thread workgroup per class walks the score-sorted box list, skips other classes, and for each of its boxes
+// counts (block reduction), decides and commits. Replaces 3 launches per box (memset, count, commit).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024)
+void mask_removal_kernel(const float* __restrict__ logits, int S, const int* __restrict__ boxes, const int* __restrict__ cls0,
+                         const int* __restrict__ mask_idx, int n, int H, int W, uint8_t* __restrict__ occ_all, double thr,
+                         int* __restrict__ flags) {
+    __shared__ int red[2][16];
+    __shared__ int decision;
+    const int cls = blockIdx.x;
+    uint8_t* __restrict__ occ = occ_all + (size_t)cls * H * W;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i = 0; i < n; ++i) {
+        if (cls0[i] != cls) continue;                                   // uniform across the block
+        const BoxGeom g = box_geom(boxes[4 * i], boxes[4 * i + 1], boxes[4 * i + 2], boxes[4 * i + 3], H, W);
+        const float* __restrict__ lg = logits + (size_t)mask_idx[i] * S * S;
+        const int rw = g.x1 - g.x0, rh = g.y1 - g.y0;
+        const long total = (rw > 0 && rh > 0) ? (long)rw * rh : 0;
+        int ms = 0, ov = 0;
+        for (long idx = t; idx < total; idx += 1024) {
+            const int xx = g.x0 + (int)(idx % rw), yy = g.y0 + (int)(idx / rw);
+            if (resized_logit(lg, S, xx - g.bx1, yy - g.by1, g.w, g.h) > 0.f) {
+                ++ms;
+                if (occ[(size_t)yy * W + xx] >= 1) ++ov;
+            }
+        }
+        for (int off = 32; off >= 1; off >>= 1) { ms += __shfl_xor(ms, off, 64); ov += __shfl_xor(ov, off, 64); }
+        if (lane == 0) { red[0][wave] = ms; red[1][wave] = ov; }
+        __syncthreads();
+        if (t == 0) {
+            int a = 0, b = 0;
+            for (int w = 0; w < 16; ++w) { a += red[0][w]; b += red[1][w]; }
+            const int keep = (a != 0 && !((double)b / (double)a > thr)) ? 1 : 0;
+            decision = keep;
+            flags[i] = keep;
+        }
+        __syncthreads();
+        if (decision) {
+            for (long idx = t; idx < total; idx += 1024) {
+                const int xx = g.x0 + (int)(idx % rw), yy = g.y0 + (int)(idx / rw);
+                if (resized_logit(lg, S, xx - g.bx1, yy - g.by1, g.w, g.h) > 0.f) occ[(size_t)yy * W + xx] += 1;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused panoptic combine. For every full-resolution pixel:
 //   fcn_output[c] = bilinear x4 (align_corners=False) of fcn_score[c]           (upsnetFPN.py:81)
 //   sem = argmax_c fcn_output[c]                                                 (panoptic_fusetrack.py:593)
@@ -155,6 +205,19 @@ extern "C" int vps_mask_commit(const float* logit, int S, int bx1, int by1, int 
     const long area = (long)max(min(bx2 + 1, W) - max(bx1, 0), 0) * max(min(by2 + 1, H) - max(by1, 0), 0);
     hipLaunchKernelGGL(mask_commit_kernel, dim3(stream_grid(area > 0 ? area : 1, 256)), dim3(256), 0, (hipStream_t)stream,
                        logit, S, bx1, by1, bx2, by2, H, W, occ, counts, thr, flag);
+    return vps_launch_status();
+}
+
+extern "C" int vps_mask_removal(const float* logits, int S, const int32_t* boxes, const int32_t* cls0, const int32_t* mask_idx,
+                                int n, int ncls, int H, int W, uint8_t* occ, double thr, int32_t* flags, void* stream) {
+    if (!logits || !boxes || !cls0 || !mask_idx || !occ || !flags || S < 2 || n < 0 || ncls <= 0 || H <= 0 || W <= 0) return VPS_EARG(1);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(occ, 0, (size_t)ncls * H * W, s);
+    if (e != hipSuccess) return -(int)e;
+    if (n == 0) return 0;
+    e = hipMemsetAsync(flags, 0, sizeof(int32_t) * n, s);
+    if (e != hipSuccess) return -(int)e;
+    hipLaunchKernelGGL(mask_removal_kernel, dim3(ncls), dim3(1024), 0, s, logits, S, boxes, cls0, mask_idx, n, H, W, occ, thr, flags);
     return vps_launch_status();
 }
 

@@ -24,7 +24,7 @@ SYMBOLS = [
     'vps_flow_warp', 'vps_nchw_to_nhwc', 'vps_nhwc_to_nchw', 'vps_resize', 'vps_pool3x3s2', 'vps_bfp_gather',
     'vps_bfp_scatter', 'vps_axpb', 'vps_flow_prep', 'vps_flow_stage', 'vps_groupnorm_relu', 'vps_tcea_temporal',
     'vps_tcea_modulate', 'vps_roi_align', 'vps_nms_batched', 'vps_delta2bbox', 'vps_bbox_overlaps',
-    'vps_row_softmax', 'vps_mask_count', 'vps_mask_commit', 'vps_panoptic_combine',
+    'vps_row_softmax', 'vps_mask_count', 'vps_mask_commit', 'vps_mask_removal', 'vps_panoptic_combine',
 ]
 
 
@@ -119,6 +119,8 @@ def load():
                                    c_void_p]
     lib.vps_mask_commit.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                     c_double, c_void_p, c_void_p]
+    lib.vps_mask_removal.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                     c_double, c_void_p, c_void_p]
     lib.vps_panoptic_combine.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                          c_void_p, c_void_p, c_int, c_int, c_void_p]
     _lib = lib

@@ -108,7 +108,7 @@ class MaskROI(nn.Module):
 class MaskRemoval(nn.Module):
     """utils/mask_removal.py:23-92. The box loop order (numpy argsort of cls_prob, reversed) and the skip rule are the
     reference's; the cv2.resize + binarise + overlap count + occupancy update of each box run on the device with the
-    keep decision taken on the device, so the loop issues 2 launches per box and ONE host sync at the end."""
+    keep decision taken on the device: ONE launch for the whole loop (a workgroup per class) and ONE host sync."""
 
     def __init__(self, fraction_threshold=0.3):
         super().__init__()
@@ -133,22 +133,15 @@ class MaskRemoval(nn.Module):
         lib = hip.load()
         ncls = int(np.max(cls_np))
         occ = ws.get('mr.occ', (ncls, H, W), dtype=torch.uint8, zero=False)
-        occ.zero_()
-        counts = ws.get('mr.counts', (n, 2), dtype=torch.int32, zero=False)
-        flags = ws.get('mr.flags', (n,), dtype=torch.int32, zero=False)
+        flags = ws.get('mr.flags', (max(n, 1),), dtype=torch.int32, zero=False)
         mp = mask_prob.contiguous()
-        sp = hip.stream_ptr()
-        esz = mp.element_size() * S * S
-        for pos in range(n):
-            i = int(sorted_inds[pos])
-            b = ref_boxes[i]
-            lg = ctypes.c_void_p(mp.data_ptr() + i * esz)
-            oc = ctypes.c_void_p(occ.data_ptr() + int(cls0[i]) * H * W)
-            ct = ctypes.c_void_p(counts.data_ptr() + pos * 8)
-            fl = ctypes.c_void_p(flags.data_ptr() + pos * 4)
-            hip.check(lib.vps_mask_count(lg, S, int(b[0]), int(b[1]), int(b[2]), int(b[3]), H, W, oc, ct, sp), 'vps_mask_count')
-            hip.check(lib.vps_mask_commit(lg, S, int(b[0]), int(b[1]), int(b[2]), int(b[3]), H, W, oc, ct,
-                                          float(self.fraction_threshold), fl, sp), 'vps_mask_commit')
+        # score-sorted box list for the single-launch kernel (one workgroup per class, sequential inside)
+        host = np.concatenate([ref_boxes[sorted_inds].reshape(-1), cls0[sorted_inds].astype(np.int32),
+                               sorted_inds.astype(np.int32)]).astype(np.int32)
+        meta = torch.from_numpy(host).to(dev)
+        hip.check(lib.vps_mask_removal(hip.ptr(mp), S, hip.ptr(meta), ctypes.c_void_p(meta.data_ptr() + 16 * n),
+                                       ctypes.c_void_p(meta.data_ptr() + 20 * n), n, ncls, H, W, hip.ptr(occ),
+                                       float(self.fraction_threshold), hip.ptr(flags), hip.stream_ptr()), 'vps_mask_removal')
         fl = flags[:n].cpu().numpy()
         keep_inds = [int(sorted_inds[pos]) for pos in range(n) if fl[pos]]
         if len(keep_inds) == 0:
