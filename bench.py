@@ -70,11 +70,20 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, 'launch with --nproc-per-node == --gpus'
     assert torch.cuda.is_available(), 'bench.py measures the HIP path and needs the MI355X (no CPU fallback)'
+    ndev = torch.cuda.device_count()
+    if local >= ndev:
+        # only for smoke-testing the multi-rank code path on a 1-GPU box (VPS_BENCH_BACKEND=gloo): ranks share a device
+        assert os.environ.get('VPS_BENCH_BACKEND', 'nccl') != 'nccl', 'one GPU per rank is required with RCCL'
+        local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('VPS_BENCH_BACKEND', 'nccl')      # 'nccl' IS RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import vps_amd
     from vps_amd import hip, nhwc, synth

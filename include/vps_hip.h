@@ -85,6 +85,9 @@ typedef struct vps_conv_desc {
     /* split-bf16 modes: weight planes [prec][nclass][cout_pad][kpad] bf16 (plane p = bf16 RNE of the residual after p terms) */
     int32_t prec;       /* VPS_PREC_* */
     const void* w_split;
+    /* k ordering of the packed weights: 0 = tap-major k = (ky*KW+kx)*cin_pad + ci;
+     * 1 = chunk-major k = ((ci/32)*KH*KW + ky*KW+kx)*32 + ci%32, kpad = KH*KW*ceil(cin_pad/32)*32 (L2-friendly) */
+    int32_t korder;
 } vps_conv_desc;
 
 int vps_conv2d(const vps_conv_desc* d, void* stream);
@@ -232,6 +235,14 @@ int vps_mask_commit(const float* logit, int S, int bx1, int by1, int bx2, int by
  * all in descending-score order and on the device; occ: ncls*H*W uint8 workspace (zeroed by the call); flags[n] = kept. */
 int vps_mask_removal(const float* logits, int S, const int32_t* boxes, const int32_t* cls0, const int32_t* mask_idx,
                      int n, int ncls, int H, int W, uint8_t* occ, double thr, int32_t* flags, void* stream);
+
+/* one dependency LEVEL of the MaskRemoval loop (count launch + commit launch): `level` = nlevel indices (device) into the
+ * score-sorted box arrays whose boxes are mutually independent (no earlier same-class box of the same level intersects
+ * them); counts [n][2] and occ must have been zeroed by the caller before the first level; max_area = largest clipped
+ * box area of the level (grid sizing). Keep decision on the device, flags[i] written. */
+int vps_mask_level(const float* logits, int S, const int32_t* boxes, const int32_t* cls0, const int32_t* mask_idx,
+                   const int32_t* level, int nlevel, int max_area, int H, int W, uint8_t* occ, int32_t* counts,
+                   double thr, int32_t* flags, void* stream);
 
 /* one kept instance of the panoptic combine */
 typedef struct vps_pan_inst {

@@ -165,11 +165,20 @@ void conv_mfma_f32_kernel(const vps_conv_desc d, const int M, const int tiles_m,
     const int kstep0 = split * ksteps_per_split;
     int nsteps = d.kpad / BK - kstep0;
     if (nsteps > ksteps_per_split) nsteps = ksteps_per_split;
+    // k ordering. korder 0 (tap-major): k = tap*cin_pad + ci. korder 1 (chunk-major): k = (chunk*ntap + tap)*32 + c with
+    // ci = chunk*32 + c: all taps of one 32-channel slab are consecutive k-steps, so the 9 (25, 49) shifted reads of the same
+    // 128-byte activation lines happen within a few steps of each other and hit L1/L2 instead of the Infinity Cache / HBM.
+    const int korder = d.korder, ntap = KH * KW;
     int ky, kx, ci;
-    {
+    if (korder == 0) {
         const int kk = kstep0 * BK + k4 * 4;
         const int tap = kk / cin_pad;
         ci = kk - tap * cin_pad;
+        ky = tap / KW;
+        kx = tap - ky * KW;
+    } else {
+        const int chunk = kstep0 / ntap, tap = kstep0 - chunk * ntap;
+        ci = chunk * BK + k4 * 4;
         ky = tap / KW;
         kx = tap - ky * KW;
     }
@@ -182,7 +191,7 @@ void conv_mfma_f32_kernel(const vps_conv_desc d, const int M, const int tiles_m,
     float dcw[DEFORM ? 4 : 1][4];
 
     auto load_tiles = [&](int step) {
-        const bool kval = ky < KH;
+        const bool kval = ky < KH && ci < cin_pad;
         if constexpr (!DEFORM) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -230,10 +239,15 @@ void conv_mfma_f32_kernel(const vps_conv_desc d, const int M, const int tiles_m,
         for (int j = 0; j < NB; ++j)
             breg[j] = *reinterpret_cast<const f32x4*>(wrow + (size_t)(32 * j) * d.kpad + (size_t)step * BK);
         // advance this thread's (ky,kx,ci) by one k-slab
-        ci += BK;
-        while (ci >= cin_pad) {
-            ci -= cin_pad;
-            if (++kx == KW) { kx = 0; ++ky; }
+        if (korder == 0) {
+            ci += BK;
+            while (ci >= cin_pad) {
+                ci -= cin_pad;
+                if (++kx == KW) { kx = 0; ++ky; }
+            }
+        } else if (++kx == KW) {
+            kx = 0;
+            if (++ky == KH) { ky = 0; ci += BK; }
         }
     };
 
@@ -381,11 +395,20 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
     const int kstep0 = split * ksteps_per_split;
     int nsteps = d.kpad / BK - kstep0;
     if (nsteps > ksteps_per_split) nsteps = ksteps_per_split;
+    // k ordering. korder 0 (tap-major): k = tap*cin_pad + ci. korder 1 (chunk-major): k = (chunk*ntap + tap)*32 + c with
+    // ci = chunk*32 + c: all taps of one 32-channel slab are consecutive k-steps, so the 9 (25, 49) shifted reads of the same
+    // 128-byte activation lines happen within a few steps of each other and hit L1/L2 instead of the Infinity Cache / HBM.
+    const int korder = d.korder, ntap = KH * KW;
     int ky, kx, ci;
-    {
+    if (korder == 0) {
         const int kk = kstep0 * BK + k4 * 4;
         const int tap = kk / cin_pad;
         ci = kk - tap * cin_pad;
+        ky = tap / KW;
+        kx = tap - ky * KW;
+    } else {
+        const int chunk = kstep0 / ntap, tap = kstep0 - chunk * ntap;
+        ci = chunk * BK + k4 * 4;
         ky = tap / KW;
         kx = tap - ky * KW;
     }
@@ -399,7 +422,7 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
     float dcw[DEFORM ? 4 : 1][4];
 
     auto load_tiles = [&](int step) {
-        const bool kval = ky < KH;
+        const bool kval = ky < KH && ci < cin_pad;
         if constexpr (!DEFORM) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -449,10 +472,15 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
             for (int j = 0; j < NBCH; ++j)
                 if (BN * 4 >= 256 || t < BN * 4)
                     breg[p][j] = *reinterpret_cast<const bf16x8*>(wrow + (size_t)p * plane + (size_t)(64 * j) * d.kpad + (size_t)step * BK);
-        ci += BK;
-        while (ci >= cin_pad) {
-            ci -= cin_pad;
-            if (++kx == KW) { kx = 0; ++ky; }
+        if (korder == 0) {
+            ci += BK;
+            while (ci >= cin_pad) {
+                ci -= cin_pad;
+                if (++kx == KW) { kx = 0; ++ky; }
+            }
+        } else if (++kx == KW) {
+            kx = 0;
+            if (++ky == KH) { ky = 0; ci += BK; }
         }
     };
 
@@ -606,7 +634,8 @@ extern "C" int vps_conv2d(const vps_conv_desc* dp, void* stream) {
     if (d.prec != VPS_PREC_F32 && d.prec != VPS_PREC_BF16X3 && d.prec != VPS_PREC_BF16X6) return VPS_EARG(12);
     if (d.prec == VPS_PREC_F32 ? !d.w : !d.w_split) return VPS_EARG(13);
     if ((d.in_ld & 3) || (d.in_coff & 3) || (d.cin_pad & 3) || d.cin_pad <= 0) return VPS_EARG(3);
-    if ((d.kpad % BK) || d.kpad < d.KH * d.KW * d.cin_pad) return VPS_EARG(4);
+    if ((d.kpad % BK) || d.kpad < d.KH * d.KW * d.cin_pad || (d.korder != 0 && d.korder != 1)) return VPS_EARG(4);
+    if (d.korder == 1 && d.kpad != d.KH * d.KW * ((d.cin_pad + BK - 1) / BK) * BK) return VPS_EARG(14);
     if (d.tile_n != 32 && d.tile_n != 64 && d.tile_n != 128) return VPS_EARG(5);
     if (d.cout_pad % d.tile_n || d.cout > d.cout_pad || d.cout <= 0) return VPS_EARG(6);
     if (d.nclass != d.os_y * d.os_x || d.nclass < 1 || d.os_y > 2 || d.os_x > 2) return VPS_EARG(7);

@@ -1,11 +1,11 @@
 // Library identification for the ctypes loader.
 #include "common.h"
 
-#define VPS_ABI_VERSION 2
+#define VPS_ABI_VERSION 3
 
 extern "C" int vps_abi_version(void) { return VPS_ABI_VERSION; }
 
 extern "C" const char* vps_build_info(void) {
-    return "libvpship abi=2 arch=gfx950 wave=64 mfma=f32_32x32x2,bf16_32x32x16(split x3/x6) "
+    return "libvpship abi=3 arch=gfx950 wave=64 mfma=f32_32x32x2,bf16_32x32x16(split x3/x6) "
            "kernels=conv_mfma,flow_ops,nn_ops,det_ops,pan_ops";
 }

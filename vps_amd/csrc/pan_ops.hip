@@ -136,6 +136,56 @@ void mask_removal_kernel(const float* __restrict__ logits, int S, const int* __r
 }
 
 // ------------------------------------------------------------------------------------------------
+// Level-batched MaskRemoval: the host orders the boxes into dependency levels (a box depends on the EARLIER boxes of the
+// same class whose rectangles intersect it); all boxes of one level are independent, so one count launch and one commit
+// launch per level process them in parallel (grid.y = box within the level, grid.x = pixel blocks).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void mask_level_count_kernel(const float* __restrict__ logits, int S, const int* __restrict__ boxes, const int* __restrict__ cls0,
+                             const int* __restrict__ mask_idx, const int* __restrict__ level, int H, int W,
+                             const uint8_t* __restrict__ occ_all, int* __restrict__ counts) {
+    const int i = level[blockIdx.y];
+    const BoxGeom g = box_geom(boxes[4 * i], boxes[4 * i + 1], boxes[4 * i + 2], boxes[4 * i + 3], H, W);
+    const float* __restrict__ lg = logits + (size_t)mask_idx[i] * S * S;
+    const uint8_t* __restrict__ occ = occ_all + (size_t)cls0[i] * H * W;
+    const int rw = g.x1 - g.x0, rh = g.y1 - g.y0;
+    int ms = 0, ov = 0;
+    if (rw > 0 && rh > 0) {
+        const long total = (long)rw * rh;
+        for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+            const int xx = g.x0 + (int)(idx % rw), yy = g.y0 + (int)(idx / rw);
+            if (resized_logit(lg, S, xx - g.bx1, yy - g.by1, g.w, g.h) > 0.f) {
+                ++ms;
+                if (occ[(size_t)yy * W + xx] >= 1) ++ov;
+            }
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) { ms += __shfl_xor(ms, off, 64); ov += __shfl_xor(ov, off, 64); }
+    if ((threadIdx.x & 63) == 0 && (ms | ov)) { atomicAdd(&counts[2 * i], ms); atomicAdd(&counts[2 * i + 1], ov); }
+}
+
+__global__ __launch_bounds__(256)
+void mask_level_commit_kernel(const float* __restrict__ logits, int S, const int* __restrict__ boxes, const int* __restrict__ cls0,
+                              const int* __restrict__ mask_idx, const int* __restrict__ level, int H, int W,
+                              uint8_t* __restrict__ occ_all, const int* __restrict__ counts, double thr, int* __restrict__ flags) {
+    const int i = level[blockIdx.y];
+    const int ms = counts[2 * i], ov = counts[2 * i + 1];
+    const bool keep = ms != 0 && !((double)ov / (double)ms > thr);
+    if (blockIdx.x == 0 && threadIdx.x == 0) flags[i] = keep ? 1 : 0;
+    if (!keep) return;
+    const BoxGeom g = box_geom(boxes[4 * i], boxes[4 * i + 1], boxes[4 * i + 2], boxes[4 * i + 3], H, W);
+    const float* __restrict__ lg = logits + (size_t)mask_idx[i] * S * S;
+    uint8_t* __restrict__ occ = occ_all + (size_t)cls0[i] * H * W;
+    const int rw = g.x1 - g.x0, rh = g.y1 - g.y0;
+    if (rw <= 0 || rh <= 0) return;
+    const long total = (long)rw * rh;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int xx = g.x0 + (int)(idx % rw), yy = g.y0 + (int)(idx / rw);
+        if (resized_logit(lg, S, xx - g.bx1, yy - g.by1, g.w, g.h) > 0.f) occ[(size_t)yy * W + xx] += 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused panoptic combine. For every full-resolution pixel:
 //   fcn_output[c] = bilinear x4 (align_corners=False) of fcn_score[c]           (upsnetFPN.py:81)
 //   sem = argmax_c fcn_output[c]                                                 (panoptic_fusetrack.py:593)
@@ -218,6 +268,18 @@ extern "C" int vps_mask_removal(const float* logits, int S, const int32_t* boxes
     e = hipMemsetAsync(flags, 0, sizeof(int32_t) * n, s);
     if (e != hipSuccess) return -(int)e;
     hipLaunchKernelGGL(mask_removal_kernel, dim3(ncls), dim3(1024), 0, s, logits, S, boxes, cls0, mask_idx, n, H, W, occ, thr, flags);
+    return vps_launch_status();
+}
+
+extern "C" int vps_mask_level(const float* logits, int S, const int32_t* boxes, const int32_t* cls0, const int32_t* mask_idx,
+                              const int32_t* level, int nlevel, int max_area, int H, int W, uint8_t* occ, int32_t* counts,
+                              double thr, int32_t* flags, void* stream) {
+    if (!logits || !boxes || !cls0 || !mask_idx || !level || !occ || !counts || !flags || S < 2 || nlevel <= 0) return VPS_EARG(1);
+    hipStream_t s = (hipStream_t)stream;
+    int gx = (max_area + 255) / 256; if (gx > 256) gx = 256; if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(mask_level_count_kernel, dim3(gx, nlevel), dim3(256), 0, s, logits, S, boxes, cls0, mask_idx, level, H, W, occ, counts);
+    hipLaunchKernelGGL(mask_level_commit_kernel, dim3(gx, nlevel), dim3(256), 0, s, logits, S, boxes, cls0, mask_idx, level, H, W, occ,
+                       counts, thr, flags);
     return vps_launch_status();
 }
 

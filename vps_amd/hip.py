@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libvpship.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 2, 3
@@ -24,7 +24,7 @@ SYMBOLS = [
     'vps_flow_warp', 'vps_nchw_to_nhwc', 'vps_nhwc_to_nchw', 'vps_resize', 'vps_pool3x3s2', 'vps_bfp_gather',
     'vps_bfp_scatter', 'vps_axpb', 'vps_flow_prep', 'vps_flow_stage', 'vps_groupnorm_relu', 'vps_tcea_temporal',
     'vps_tcea_modulate', 'vps_roi_align', 'vps_nms_batched', 'vps_delta2bbox', 'vps_bbox_overlaps',
-    'vps_row_softmax', 'vps_mask_count', 'vps_mask_commit', 'vps_mask_removal', 'vps_panoptic_combine',
+    'vps_row_softmax', 'vps_mask_count', 'vps_mask_commit', 'vps_mask_removal', 'vps_mask_level', 'vps_panoptic_combine',
 ]
 
 
@@ -42,7 +42,7 @@ class ConvDesc(Structure):
         ('act', c_int32), ('slope', c_float),
         ('offset', c_void_p), ('off_ld', c_int32),
         ('tile_n', c_int32), ('ksplit', c_int32), ('ws', c_void_p),
-        ('prec', c_int32), ('w_split', c_void_p),
+        ('prec', c_int32), ('w_split', c_void_p), ('korder', c_int32),
     ]
 
 
@@ -121,6 +121,8 @@ def load():
                                     c_double, c_void_p, c_void_p]
     lib.vps_mask_removal.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                      c_double, c_void_p, c_void_p]
+    lib.vps_mask_level.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                   c_void_p, c_double, c_void_p, c_void_p]
     lib.vps_panoptic_combine.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                          c_void_p, c_void_p, c_int, c_int, c_void_p]
     _lib = lib

@@ -120,9 +120,8 @@ class PackedConv:
             self.pad_y = (padding, padding)
             self.pad_x = (padding, padding)
             cin_pad = _ceil(I, 4)
-            wp = torch.zeros(O, kh, kw, cin_pad)
-            wp[..., :I] = w.permute(0, 2, 3, 1)
-            blocks = [wp.reshape(O, kh * kw * cin_pad)]
+            self.korder = 1 if (cin_pad >= 64 or cin_pad % 32 == 0) and kh * kw > 1 else 0
+            blocks = [self._pack_taps(w.permute(0, 2, 3, 1).reshape(O, kh * kw, I), cin_pad)]
         else:
             I, O, kh, kw = w.shape
             assert stride == 2 and kh == kw and kh % 2 == 0, 'only stride-2 even-kernel transposed convs are on the path'
@@ -139,18 +138,19 @@ class PackedConv:
                 taps.append([r + 2 * ((kc - 1) - u) for u in range(kc)])  # kernel index used by tap u
             self.pad_y = tuple(pads)
             self.pad_x = tuple(pads)
+            self.korder = 1 if (cin_pad >= 64 or cin_pad % 32 == 0) and kc * kc > 1 else 0
             blocks = []
             for py in range(2):
                 for px in range(2):
-                    wp = torch.zeros(O, kc, kc, cin_pad)
+                    wp = torch.zeros(O, kc * kc, I)
                     for uy in range(kc):
                         for ux in range(kc):
-                            wp[:, uy, ux, :I] = w[:, :, taps[py][uy], taps[px][ux]].t()
-                    blocks.append(wp.reshape(O, kc * kc * cin_pad))
+                            wp[:, uy * kc + ux, :] = w[:, :, taps[py][uy], taps[px][ux]].t()
+                    blocks.append(self._pack_taps(wp, cin_pad))
         self.cin, self.cin_pad, self.cout = I, cin_pad, O
         self.tile_n = _tile_n(O)
         self.cout_pad = _ceil(O, self.tile_n)
-        K = self.KH * self.KW * cin_pad
+        K = blocks[0].shape[1]
         self.kpad = _ceil(K, 32)
         packed = torch.zeros(self.nclass, self.cout_pad, self.kpad)
         for c, b in enumerate(blocks):
@@ -170,6 +170,18 @@ class PackedConv:
             self.has_scale = False
         self.scale = scale.to(device) if self.has_scale else None
         self.shift = shift.to(device) if (bias is not None or bn is not None) else None
+
+    def _pack_taps(self, wt, cin_pad):
+        """wt [O, ntap, I] -> [O, K] in the kernel's k order (see vps_conv_desc.korder)"""
+        O, ntap, I = wt.shape
+        if self.korder == 0:                                   # tap-major: k = tap*cin_pad + ci
+            wp = torch.zeros(O, ntap, cin_pad)
+            wp[..., :I] = wt
+            return wp.reshape(O, ntap * cin_pad)
+        nch = (cin_pad + 31) // 32                             # chunk-major: k = (chunk*ntap + tap)*32 + c
+        wp = torch.zeros(O, ntap, nch * 32)
+        wp[..., :I] = wt
+        return wp.view(O, ntap, nch, 32).permute(0, 2, 1, 3).reshape(O, nch * ntap * 32)
 
     def _set_weights(self, packed, device):
         """packed fp32 [nclass][cout_pad][kpad] (host or device) -> the operand format of the selected arithmetic"""
@@ -193,6 +205,7 @@ class PackedConv:
         self.nclass, self.os, self.KH, self.KW = 1, 1, 1, 1
         self.pad_y = self.pad_x = (0, 0)
         self.cin = self.cin_pad = self.kpad = D
+        self.korder = 0
         self.cout = M
         self.tile_n = _tile_n(M)
         self.cout_pad = _ceil(M, self.tile_n)
@@ -221,6 +234,7 @@ class PackedConv:
         d.inp = x.t.data_ptr(); d.N, d.H, d.W = x.N, x.H, x.W
         d.in_ld, d.in_coff, d.cin_pad = x.ld, x.coff, self.cin_pad
         d.prec = self.prec
+        d.korder = self.korder
         if self.prec == hip.PREC_F32:
             d.w = self.w.data_ptr()
         else:

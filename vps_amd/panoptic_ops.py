@@ -108,7 +108,7 @@ class MaskROI(nn.Module):
 class MaskRemoval(nn.Module):
     """utils/mask_removal.py:23-92. The box loop order (numpy argsort of cls_prob, reversed) and the skip rule are the
     reference's; the cv2.resize + binarise + overlap count + occupancy update of each box run on the device with the
-    keep decision taken on the device: ONE launch for the whole loop (a workgroup per class) and ONE host sync."""
+    keep decision taken on the device; boxes are batched into dependency levels (2 launches per level) and there is ONE host sync."""
 
     def __init__(self, fraction_threshold=0.3):
         super().__init__()
@@ -135,13 +135,32 @@ class MaskRemoval(nn.Module):
         occ = ws.get('mr.occ', (ncls, H, W), dtype=torch.uint8, zero=False)
         flags = ws.get('mr.flags', (max(n, 1),), dtype=torch.int32, zero=False)
         mp = mask_prob.contiguous()
-        # score-sorted box list for the single-launch kernel (one workgroup per class, sequential inside)
-        host = np.concatenate([ref_boxes[sorted_inds].reshape(-1), cls0[sorted_inds].astype(np.int32),
-                               sorted_inds.astype(np.int32)]).astype(np.int32)
+        # dependency levels over the score-sorted list: a box depends on the earlier same-class boxes whose rectangles
+        # intersect it (mask_removal.py:75-80 only looks at the class plane inside the box); boxes of one level are independent
+        sb = ref_boxes[sorted_inds].astype(np.int64)
+        sc = cls0[sorted_inds]
+        x0 = np.maximum(sb[:, 0], 0); x1 = np.minimum(sb[:, 2] + 1, W); y0 = np.maximum(sb[:, 1], 0); y1 = np.minimum(sb[:, 3] + 1, H)
+        area = np.maximum(x1 - x0, 0) * np.maximum(y1 - y0, 0)
+        lvl = np.zeros(n, dtype=np.int64)
+        for i in range(1, n):
+            dep = (sc[:i] == sc[i]) & (x0[:i] < x1[i]) & (x0[i] < x1[:i]) & (y0[:i] < y1[i]) & (y0[i] < y1[:i])
+            if dep.any():
+                lvl[i] = lvl[:i][dep].max() + 1
+        order = np.argsort(lvl, kind='stable')
+        nlv = int(lvl.max()) + 1
+        starts = np.searchsorted(lvl[order], np.arange(nlv + 1))
+        host = np.concatenate([sb.reshape(-1), sc, sorted_inds, order]).astype(np.int32)
         meta = torch.from_numpy(host).to(dev)
-        hip.check(lib.vps_mask_removal(hip.ptr(mp), S, hip.ptr(meta), ctypes.c_void_p(meta.data_ptr() + 16 * n),
-                                       ctypes.c_void_p(meta.data_ptr() + 20 * n), n, ncls, H, W, hip.ptr(occ),
-                                       float(self.fraction_threshold), hip.ptr(flags), hip.stream_ptr()), 'vps_mask_removal')
+        counts = ws.get('mr.counts', (max(n, 1), 2), dtype=torch.int32, zero=False)
+        occ.zero_(); counts.zero_()
+        base = meta.data_ptr()
+        sp = hip.stream_ptr()
+        for l in range(nlv):
+            a, b = int(starts[l]), int(starts[l + 1])
+            hip.check(lib.vps_mask_level(hip.ptr(mp), S, ctypes.c_void_p(base), ctypes.c_void_p(base + 16 * n),
+                                         ctypes.c_void_p(base + 20 * n), ctypes.c_void_p(base + 24 * n + 4 * a), b - a,
+                                         int(area[order[a:b]].max()), H, W, hip.ptr(occ), hip.ptr(counts),
+                                         float(self.fraction_threshold), hip.ptr(flags), sp), 'vps_mask_level')
         fl = flags[:n].cpu().numpy()
         keep_inds = [int(sorted_inds[pos]) for pos in range(n) if fl[pos]]
         if len(keep_inds) == 0:

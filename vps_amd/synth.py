@@ -40,7 +40,10 @@ def synth_tensor(key, shape, seed=0):
             return w
         return torch.randn(shape, generator=g) * 0.1
     if leaf == 'bias':
-        return torch.randn(shape, generator=g) * 0.05
+        b = torch.randn(shape, generator=g) * 0.05
+        if key.endswith('bbox_head.fc_reg.bias'):
+            b[2::4] -= 4.0; b[3::4] -= 4.0        # dw, dh ~ -0.8 after the /5 weights: detections shrink like refined boxes
+        return b
     # weights
     if len(shape) == 4:
         if 'deconv' in key or 'upsampled_flow' in key or key.endswith('mask_head.upsample.weight'):
@@ -69,6 +72,8 @@ def synth_tensor(key, shape, seed=0):
         std = math.sqrt(2.0 / shape[1])
         if 'fc_cls' in key:
             std *= 0.25                                       # logit std ~3 on the O(10) synthetic FPN features
+            w = torch.randn(shape, generator=g) * std
+            return w - w.mean(dim=0, keepdim=True)           # no class is favoured by the (mostly positive) features
         elif 'fc_reg' in key:
             std *= 0.05
         elif 'track_head.fcs.1' in key:
