@@ -323,11 +323,15 @@ void conv_mfma_f32_kernel(const vps_conv_desc d, const int M, const int tiles_m,
 //   NS = 3: x0w0 + x0w1 + x1w0 + x1w1 + x0w2 + x2w0 (6 MFMAs, relative error ~2^-23: fp32-grade,  "bf16x6")
 // Weights are split once on the host (planes [NS][class][cout_pad][kpad] bf16); activations stay fp32 in HBM and are
 // split by the thread that stages them into LDS (once per block, not once per consuming wave). LDS rows are
-// [row][32 k] bf16 with an 80-byte stride: the 16-byte fragment reads of a 16-lane group hit 16 distinct slots.
+// [row][32 k] bf16 (64 bytes) with XOR-swizzled 16-byte chunks (conflict-free staging writes and fragment reads).
 // ================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int LDS_LDH = 40;   // bf16 elements per LDS row (32 + 8 pad) = 80 bytes
+constexpr int LDS_LDH = 32;   // bf16 elements per LDS row = 64 bytes, no padding: the four 16-byte chunks of a row are
+                              // XOR-swizzled with (row>>2)&3, which makes the 8-byte/16-byte staging writes of two consecutive
+                              // rows cover all 32 banks once and the 16-lane groups of the fragment ds_read_b128 hit 16
+                              // distinct 16-byte slots (the padded 80-byte layout measured 33 % conflict cycles)
+__device__ __forceinline__ int lds_swz(int row) { return (row >> 2) & 3; }
 
 template <int NS>
 __device__ __forceinline__ void split_bf16(const f32x4 v, bf16x4 (&out)[NS]) {
@@ -497,19 +501,22 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
             split_bf16<NS>(v, sp);
 #pragma unroll
             for (int p = 0; p < NS; ++p)
-                *reinterpret_cast<bf16x4*>(&As[p][(r0 + 32 * i) * LDS_LDH + k4 * 4]) = sp[p];
+                *reinterpret_cast<bf16x4*>(&As[p][(r0 + 32 * i) * LDS_LDH + (((k4 >> 1) ^ lds_swz(r0 + 32 * i)) << 3) + ((k4 & 1) << 2)]) = sp[p];
         }
 #pragma unroll
         for (int p = 0; p < NS; ++p)
 #pragma unroll
             for (int j = 0; j < NBCH; ++j)
                 if (BN * 4 >= 256 || t < BN * 4)
-                    *reinterpret_cast<bf16x8*>(&Bs[p][(bw_r + 64 * j) * LDS_LDH + bw_c * 8]) = breg[p][j];
+                    *reinterpret_cast<bf16x8*>(&Bs[p][(bw_r + 64 * j) * LDS_LDH + ((bw_c ^ lds_swz(bw_r + 64 * j)) << 3)]) = breg[p][j];
     };
 
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
-    const int frag_off = (lane & 31) * LDS_LDH + (lane >> 5) * 8;
+    // fragment of slab m: logical 16-byte chunk 2m + (lane>>5) of row (lane&31), swizzled like the writes
+    const int frag_row = (lane & 31) * LDS_LDH;
+    const int frag_sw = lds_swz(lane & 31);
+    const int frag_chunk[2] = {(((lane >> 5)) ^ frag_sw) << 3, ((2 + (lane >> 5)) ^ frag_sw) << 3};
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -530,15 +537,16 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
         if (more) load_tiles(step + 1);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {            // two K=16 MFMA slabs per 32-wide k-step
+            const int frag_off = frag_row + frag_chunk[m];
             bf16x8 af[NS][TM], bf[NS][TN];
 #pragma unroll
             for (int p = 0; p < NS; ++p) {
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
-                    af[p][a] = *reinterpret_cast<const bf16x8*>(&As[p][(wm * TM * 32 + a * 32) * LDS_LDH + frag_off + m * 16]);
+                    af[p][a] = *reinterpret_cast<const bf16x8*>(&As[p][(wm * TM * 32 + a * 32) * LDS_LDH + frag_off]);
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    bf[p][b] = *reinterpret_cast<const bf16x8*>(&Bs[p][(wn * TN * 32 + b * 32) * LDS_LDH + frag_off + m * 16]);
+                    bf[p][b] = *reinterpret_cast<const bf16x8*>(&Bs[p][(wn * TN * 32 + b * 32) * LDS_LDH + frag_off]);
             }
             // product terms outermost (smallest first), accumulators innermost: consecutive MFMAs never depend on each other
             constexpr int NT = NS == 3 ? 6 : 3;
