@@ -185,6 +185,7 @@ void conv_mfma_f32_kernel(const vps_conv_desc d, const int M, const int tiles_m,
     const float* __restrict__ wrow = wcls + (size_t)(tile_n * BN + r0) * d.kpad + (size_t)kstep0 * BK + k4 * 4;
 
     f32x4 areg[4];
+    unsigned aok = 0;   // bit i: staged row i of the tile in flight is inside the image
     f32x4 breg[NB];
     // deformable: 4 corners + 4 weights per staged row, blended when written to LDS
     f32x4 dcv[DEFORM ? 4 : 1][4];
@@ -195,14 +196,13 @@ void conv_mfma_f32_kernel(const vps_conv_desc d, const int M, const int tiles_m,
         if constexpr (!DEFORM) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                // branch-free: out-of-image taps read pixel 0 of the image (always mapped) and are zeroed when the tile is
+                // written to LDS, so the load is issued unconditionally and its wait sits at the consumer, one tile later
                 const int iy = ri[i].iy0 + ky, ix = ri[i].ix0 + kx;
                 const bool ok = kval && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ok) {
-                    const float* p = d.in + ((size_t)(ri[i].pixbase + iy * W + ix) * d.in_ld + d.in_coff + ci);
-                    v = *reinterpret_cast<const f32x4*>(p);
-                }
-                areg[i] = v;
+                const int pix = ri[i].pixbase + (ok ? iy * W + ix : 0);
+                areg[i] = *reinterpret_cast<const f32x4*>(d.in + ((size_t)pix * d.in_ld + d.in_coff + (ok ? ci : 0)));
+                aok = (aok & ~(1u << i)) | ((ok ? 1u : 0u) << i);
             }
         } else {
             const int tap = ky * KW + kx;
@@ -258,7 +258,8 @@ void conv_mfma_f32_kernel(const vps_conv_desc d, const int M, const int tiles_m,
             if constexpr (DEFORM) {
                 v = dcw[i][0] * dcv[i][0] + dcw[i][1] * dcv[i][1] + dcw[i][2] * dcv[i][2] + dcw[i][3] * dcv[i][3];
             } else {
-                v = areg[i];
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                v = ((aok >> i) & 1u) ? areg[i] : z;
             }
             *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDS_LD + k4 * 4]) = v;
         }
@@ -421,6 +422,7 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
     const __bf16* __restrict__ wrow = wcls + (size_t)(tile_n * BN + bw_r) * d.kpad + (size_t)kstep0 * BK + bw_c * 8;
 
     f32x4 areg[4];
+    unsigned aok = 0;   // bit i: staged row i of the tile in flight is inside the image
     bf16x8 breg[NS][NBCH];
     f32x4 dcv[DEFORM ? 4 : 1][4];
     float dcw[DEFORM ? 4 : 1][4];
@@ -430,14 +432,13 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
         if constexpr (!DEFORM) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                // branch-free: out-of-image taps read pixel 0 of the image (always mapped) and are zeroed when the tile is
+                // written to LDS, so the load is issued unconditionally and its wait sits at the consumer, one tile later
                 const int iy = ri[i].iy0 + ky, ix = ri[i].ix0 + kx;
                 const bool ok = kval && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ok) {
-                    const float* p = d.in + ((size_t)(ri[i].pixbase + iy * W + ix) * d.in_ld + d.in_coff + ci);
-                    v = *reinterpret_cast<const f32x4*>(p);
-                }
-                areg[i] = v;
+                const int pix = ri[i].pixbase + (ok ? iy * W + ix : 0);
+                areg[i] = *reinterpret_cast<const f32x4*>(d.in + ((size_t)pix * d.in_ld + d.in_coff + (ok ? ci : 0)));
+                aok = (aok & ~(1u << i)) | ((ok ? 1u : 0u) << i);
             }
         } else {
             const int tap = ky * KW + kx;
@@ -495,7 +496,8 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
             if constexpr (DEFORM) {
                 v = dcw[i][0] * dcv[i][0] + dcw[i][1] * dcv[i][1] + dcw[i][2] * dcv[i][2] + dcw[i][3] * dcv[i][3];
             } else {
-                v = areg[i];
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                v = ((aok >> i) & 1u) ? areg[i] : z;
             }
             bf16x4 sp[NS];
             split_bf16<NS>(v, sp);
