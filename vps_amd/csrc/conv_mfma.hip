@@ -571,6 +571,76 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
     conv_epilogue<TM, TN, BN>(d, acc, M, tile_m, tile_n, cls, split, py, px, wm, wn, lane);
 }
 
+// ================================================================================================
+// Narrow-output convolution (cout <= 4: the FlowNet predict_flow / upsampled_flow layers, 2 channels). A 32-column MFMA
+// tile would waste 94 % of the matrix pipe and still stage the whole activation tile through LDS; these layers are
+// pure activation streaming, so they run on the vector ALU in exact fp32: G lanes (G = pow2 >= cin_pad/4, <= 64) share
+// one output pixel and stride its channels with float4 loads, all taps accumulate in registers, one G-lane shuffle
+// reduction per pixel. Same descriptor, k ordering, parity classes and epilogue as the MFMA kernels.
+// ================================================================================================
+template <int CO>
+__global__ __launch_bounds__(256)
+void conv_small_kernel(const vps_conv_desc d, const int M, const int G, const int logG) {
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (G - 1);                       // channel slot inside the pixel group
+    const int ppw = 64 >> logG;                           // pixels per wavefront
+    const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    const long total = (long)d.nclass * M;
+    const int H = d.H, W = d.W, KH = d.KH, KW = d.KW, cin_pad = d.cin_pad, ntap = KH * KW;
+    const int c4n = cin_pad >> 2;
+    for (long base = wave_id * ppw; base < total; base += nwaves * ppw) {
+        const long idx = base + (lane >> logG);
+        const bool pv = idx < total;
+        const int cls = pv ? (int)(idx / M) : 0;
+        const int m = pv ? (int)(idx - (long)cls * M) : 0;
+        const int py = cls / d.os_x, px = cls - py * d.os_x;
+        const int qx = m % d.Qw;
+        const int tq = m / d.Qw;
+        const int qy = tq % d.Qh;
+        const int n = tq / d.Qh;
+        const int iy0 = qy * d.stride - d.pad_y[py], ix0 = qx * d.stride - d.pad_x[px];
+        const float* __restrict__ wcls = d.w + (size_t)cls * d.cout_pad * d.kpad;
+        float acc[CO];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+        for (int tap = 0; tap < ntap; ++tap) {
+            const int ky = tap / KW, kx = tap - ky * KW;
+            const int iy = iy0 + ky, ix = ix0 + kx;
+            const bool ok = pv && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const float* __restrict__ ap = d.in + ((size_t)(n * H * W + (ok ? iy * W + ix : 0)) * d.in_ld + d.in_coff);
+            for (int c4 = sub; c4 < c4n; c4 += G) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 a = ok ? *reinterpret_cast<const f32x4*>(ap + 4 * c4) : z;
+                const int ci = 4 * c4;
+                const int k = d.korder == 0 ? tap * cin_pad + ci : ((ci >> 5) * ntap + tap) * 32 + (ci & 31);
+#pragma unroll
+                for (int c = 0; c < CO; ++c) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wcls + (size_t)c * d.kpad + k);
+                    acc[c] += a[0] * wv[0] + a[1] * wv[1] + a[2] * wv[2] + a[3] * wv[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CO; ++c)
+            for (int off = G >> 1; off >= 1; off >>= 1) acc[c] += __shfl_xor(acc[c], off, 64);
+        if (pv && sub == 0) {
+            const int oy = qy * d.os_y + py, ox = qx * d.os_x + px;
+            const size_t opix = ((size_t)n * d.Ho + oy) * d.Wo + ox;
+            const int rs = d.res_shift;
+            const size_t rpix = ((size_t)n * (d.Ho >> rs) + (oy >> rs)) * (d.Wo >> rs) + (ox >> rs);
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+                if (c < d.cout) {
+                    float v = acc[c] * (d.scale ? d.scale[c] : 1.f) + (d.shift ? d.shift[c] : 0.f);
+                    if (d.res) v += d.res[rpix * d.res_ld + d.res_coff + c];
+                    d.out[opix * d.out_ld + d.out_coff + c] = vps_act(v, d.act, d.slope);
+                }
+            }
+        }
+    }
+}
+
 // sum the split-K partials and apply the epilogue
 __global__ __launch_bounds__(256)
 void conv_splitk_reduce_kernel(const vps_conv_desc d, const int M) {
@@ -656,6 +726,16 @@ extern "C" int vps_conv2d(const vps_conv_desc* dp, void* stream) {
     if (Ml <= 0 || Ml > 0x7fffffffL) return VPS_EARG(11);
     const int M = (int)Ml;
     hipStream_t s = (hipStream_t)stream;
+    if (d.cout <= 4 && d.prec == VPS_PREC_F32 && !d.offset && d.ksplit == 1 && d.tile_n == 32) {
+        int G = 1, logG = 0;
+        while (G < 64 && G < (d.cin_pad >> 2)) { G <<= 1; ++logG; }
+        const long total = (long)d.nclass * M;
+        long waves = (total + (64 >> logG) - 1) / (64 >> logG);
+        long blocks = (waves + 3) / 4; if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
+        if (d.cout <= 2) hipLaunchKernelGGL((conv_small_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, d, M, G, logG);
+        else hipLaunchKernelGGL((conv_small_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, s, d, M, G, logG);
+        return vps_launch_status();
+    }
     switch (d.tile_n) {
         case 128: return launch_conv<2, 2, 2, 2>(d, M, s);
         case 64: return launch_conv<1, 2, 4, 1>(d, M, s);

@@ -109,6 +109,10 @@ class PackedConv:
                  transposed=False, deform=False, device='cuda', prec=None):
         w = weight.detach().float().cpu()
         self.prec = DEFAULT_PREC if prec is None else prec
+        nout = w.shape[1] if transposed else w.shape[0]
+        self.small = nout <= 4 and not deform          # narrow outputs run on the exact-fp32 vector kernel in every mode
+        if self.small:
+            self.prec = hip.PREC_F32
         self.stride = stride
         self.act, self.slope = act, float(slope)
         self.deform = deform
@@ -206,6 +210,7 @@ class PackedConv:
         self.pad_y = self.pad_x = (0, 0)
         self.cin = self.cin_pad = self.kpad = D
         self.korder = 0
+        self.small = False
         self.cout = M
         self.tile_n = _tile_n(M)
         self.cout_pad = _ceil(M, self.tile_n)
@@ -263,7 +268,7 @@ class PackedConv:
         tiles = ((M + 127) // 128) * (self.cout_pad // self.tile_n) * d.nclass
         ksteps = self.kpad // 32
         ksplit = 1
-        if tiles < 256 and ksteps >= 8:
+        if tiles < 256 and ksteps >= 8 and not getattr(self, 'small', False):
             ksplit = max(1, min((512 + tiles - 1) // tiles, ksteps // 4, 32))
             per = (ksteps + ksplit - 1) // ksplit
             ksplit = (ksteps + per - 1) // per
