@@ -82,7 +82,10 @@ typedef struct vps_conv_desc {
     int32_t tile_n;     /* 32, 64 or 128 */
     int32_t ksplit;     /* >=1; >1 needs ws of ksplit*M*cout_pad floats (M = nclass*N*Qh*Qw) */
     float* ws;
-    /* split-bf16 modes: weight planes [prec][nclass][cout_pad][kpad] bf16 (plane p = bf16 RNE of the residual after p terms) */
+    /* split-bf16 modes: bf16 weight planes (plane p = bf16 RNE of the residual after p terms), no `w`.
+     *   with `offset` (deformable):  [prec][nclass][cout_pad][kpad]
+     *   otherwise, MFMA-fragment order (weights go straight to registers, one coalesced 1 KB load per fragment):
+     *                               [prec][nclass][cout_pad/32][kpad/16][lane 0..63][8], lane = 32*((k/8)%2) + cout%32 */
     int32_t prec;       /* VPS_PREC_* */
     const void* w_split;
     /* k ordering of the packed weights: 0 = tap-major k = (ky*KW+kx)*cin_pad + ci;

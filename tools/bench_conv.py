@@ -43,7 +43,10 @@ def main():
     dev = torch.device('cuda:0')
     ws = nhwc.Workspace(dev)
     rows = []
+    flt = os.environ.get('BENCH_CONV_FILTER')
     for name, cin, cout, k, s, p, H, W, tr, df in SHAPES:
+        if flt and flt not in name:
+            continue
         N = 100 if 'mask conv' in name else 1
         g = torch.Generator().manual_seed(0)
         w = torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k), generator=g) * 0.05

@@ -572,6 +572,242 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
 }
 
 // ================================================================================================
+// Split-bf16, software-pipelined ("bf16p"): the kernel every non-deformable layer runs in the bf16x3 / bf16x6 modes.
+//
+// Why it looks the way it does (measurements: tools/pipebench.hip, profiles/r01_pipebench.txt, and phase knock-outs /
+// in-kernel phase timers of the kernel above on the 256->256 3x3 @256x512 layer):
+//   * on one SIMD, a wave issuing MFMAs and a second wave doing anything else (VALU, ds_read, global loads) take the SUM
+//     of their times, not the max: the two-phase "compute | barrier | stage | barrier" loop above therefore runs at
+//     matrix time + everything else, whatever the occupancy (measured 1.08 ms against 0.42 ms of pure matrix time);
+//   * ds_read_b128 delivers ~64 B/clk/CU: the 24 fragment reads per wave and k-step of the kernel above keep the LDS
+//     pipe as busy as the matrix pipe; coalesced 1 KB global loads deliver ~47 B/clk/CU.
+// So: (1) the weight operand skips LDS. It is split and packed once on the host in MFMA-fragment order,
+//       w_split[plane][class][cout_pad/32][kpad/16][lane 0..63][8 bf16],  lane = 32*(k/8 % 2) + cout % 32,
+//     and each wave fetches its B fragments with one coalesced 1 KB global_load_dwordx4 per fragment (L2-resident), one
+//     k-step ahead, double-buffered in registers: half the LDS reads, no weight staging writes.
+// (2) LDS holds the split activations only, double-buffered, ONE barrier per k-step.
+// (3) everything that is not an MFMA - converting and staging the activations of step s+1, the fragment reads of the
+//     second slab, issuing the activation loads of step s+2 and the weight loads of step s+1 - is cut into small work
+//     items that are interleaved between the MFMAs of step s in program order (sched_barrier-pinned), so that each
+//     wave keeps the matrix pipe, the LDS pipe and the memory pipe busy at the same time instead of in turns.
+// The loop body is branch-free: loads past the last k-step are clamped / masked rather than skipped.
+// ================================================================================================
+template <int TM, int TN, int WAVES_M, int WAVES_N, int NS>
+__global__ __launch_bounds__(256, 2)
+void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_m, const int tiles_n,
+                            const int ksteps_per_split) {
+    constexpr int BN = WAVES_N * TN * 32;
+    static_assert(WAVES_M * TM * 32 == BM, "block M tile must be 128");
+    static_assert(WAVES_M * WAVES_N == 4, "4 wavefronts per block");
+    constexpr int ABUF = NS * BM * LDS_LDH;      // bf16 elements of one activation buffer (all planes)
+
+    __shared__ __attribute__((aligned(16))) __bf16 As[2 * ABUF];
+
+    const int t = threadIdx.x;
+    int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_n = swz % tiles_n; swz /= tiles_n;
+    const int tile_m = swz % tiles_m; swz /= tiles_m;
+    const int cls = swz % d.nclass;
+    const int split = swz / d.nclass;
+
+    const int py = cls / d.os_x, px = cls - py * d.os_x;
+    const int pad_y = d.pad_y[py], pad_x = d.pad_x[px];
+    const int H = d.H, W = d.W, KH = d.KH, KW = d.KW, cin_pad = d.cin_pad;
+    const int k4 = t & 7;      // 4-channel group of the 32-wide k-step staged by this thread (8 lanes = one 128-byte line)
+    const int r0 = t >> 3;     // rows r0 + 32 i of the tile
+
+    RowInfo ri[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = tile_m * BM + r0 + 32 * i;
+        if (m < M) {
+            const int qx = m % d.Qw;
+            const int tq = m / d.Qw;
+            const int qy = tq % d.Qh;
+            const int n = tq / d.Qh;
+            ri[i].iy0 = qy * d.stride - pad_y;
+            ri[i].ix0 = qx * d.stride - pad_x;
+            ri[i].pixbase = n * H * W;
+        } else {
+            ri[i].iy0 = -(1 << 24);
+            ri[i].ix0 = 0;
+            ri[i].pixbase = 0;
+        }
+        ri[i].moff = m;
+    }
+
+    const int kstep0 = split * ksteps_per_split;
+    int nsteps = d.kpad / BK - kstep0;
+    if (nsteps > ksteps_per_split) nsteps = ksteps_per_split;
+    // k ordering as in the kernels above. korder 1: one k-step = one (32-channel chunk, tap), the same for all threads.
+    const int korder = d.korder, ntap = KH * KW;
+    int ky = 0, kx = 0, chunk = 0, astep = kstep0;   // state of the next activation tile to load
+    if (korder == 1) {
+        chunk = kstep0 / ntap;
+        const int tap = kstep0 - chunk * ntap;
+        ky = tap / KW;
+        kx = tap - ky * KW;
+    }
+
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+    // B fragments of this wave: 32-column blocks nb0 .. nb0+TN-1, k-slab ks, plane p
+    const int nbt = d.cout_pad >> 5, kst = d.kpad >> 4;
+    const size_t wplane = (size_t)d.nclass * nbt * kst * 512;
+    const __bf16* __restrict__ wfrag = reinterpret_cast<const __bf16*>(d.w_split) +
+        ((size_t)(cls * nbt + tile_n * (BN / 32) + wn * TN) * kst + 2 * (size_t)kstep0) * 512 + lane * 8;
+
+    f32x4 areg[4];
+    unsigned aok = 0;   // bit i: staged row i is inside the image and inside the channel range
+    bf16x8 bnext[2][NS][TN];
+
+    // activation tile of the next k-step -> registers (sequential: every call advances the k state by one step)
+    auto load_A = [&]() {
+        int kyc, kxc, cic;
+        bool kv;
+        if (korder == 1) {
+            kyc = ky; kxc = kx;
+            cic = chunk * BK + k4 * 4;
+            kv = cic < cin_pad;
+            if (++kx == KW) {
+                kx = 0;
+                if (++ky == KH) { ky = 0; ++chunk; }
+            }
+        } else if (ntap == 1) {
+            kyc = 0; kxc = 0;
+            cic = astep * BK + k4 * 4;
+            kv = cic < cin_pad;
+        } else {
+            // tap-major with a small channel count (the first layers)
+            const int kk = astep * BK + k4 * 4;
+            const int tap = kk / cin_pad;
+            cic = kk - tap * cin_pad;
+            kyc = tap / KW;
+            kxc = tap - kyc * KW;
+            kv = tap < ntap;
+        }
+        ++astep;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // branch-free: out-of-image / out-of-range taps read pixel 0 (always mapped) and are zeroed when staged
+            const int iy = ri[i].iy0 + kyc, ix = ri[i].ix0 + kxc;
+            const bool ok = kv && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const int pix = ri[i].pixbase + (ok ? iy * W + ix : 0);
+            areg[i] = *reinterpret_cast<const f32x4*>(d.in + ((size_t)pix * d.in_ld + d.in_coff + (ok ? cic : 0)));
+            aok = (aok & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+        }
+    };
+
+    // weight fragments (plane p, slab m) of k-step `step` -> bnext
+    auto load_B = [&](int step, int m, int p) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+            bnext[m][p][b] = *reinterpret_cast<const bf16x8*>(wfrag + (size_t)p * wplane + ((size_t)b * kst + 2 * step + m) * 512);
+    };
+
+    // split staged row i and write it into activation buffer `buf`
+    auto store_A = [&](int i, int buf) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        bf16x4 sp[NS];
+        split_bf16<NS>(((aok >> i) & 1u) ? areg[i] : z, sp);
+        const int row = r0 + 32 * i;
+#pragma unroll
+        for (int p = 0; p < NS; ++p)
+            *reinterpret_cast<bf16x4*>(&As[buf * ABUF + p * (BM * LDS_LDH) + row * LDS_LDH + (((k4 >> 1) ^ lds_swz(row)) << 3) + ((k4 & 1) << 2)]) = sp[p];
+    };
+
+    // fragment of slab m: logical 16-byte chunk 2m + (lane>>5) of row (lane&31), swizzled like the writes
+    const int frag_row = (wm * TM * 32 + (lane & 31)) * LDS_LDH;
+    const int frag_sw = lds_swz(lane & 31);
+    const int frag_chunk[2] = {(((lane >> 5)) ^ frag_sw) << 3, ((2 + (lane >> 5)) ^ frag_sw) << 3};
+    bf16x8 af[2][NS][TM];
+    auto read_A = [&](int m, int buf) {
+#pragma unroll
+        for (int p = 0; p < NS; ++p)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+                af[m][p][a] = *reinterpret_cast<const bf16x8*>(&As[buf * ABUF + p * (BM * LDS_LDH) + a * 32 * LDS_LDH + frag_row + frag_chunk[m]]);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // prologue: tile 0 staged in buffer 0, tile 1 in flight in registers, weights of step 0 in flight
+    if (nsteps > 0) {
+        load_A();
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int p = 0; p < NS; ++p) load_B(0, m, p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store_A(i, 0);
+        load_A();
+    }
+    __syncthreads();
+
+    // work items interleaved between the MFMAs of a k-step (program order; positions are compile-time after unrolling)
+    constexpr int NT = NS == 3 ? 6 : 3;
+    constexpr int NMF = 2 * NT * TM * TN;            // MFMAs per wave and k-step
+    constexpr int NW = 4 + 1 + 1 + 2 * NS;           // 4 row stagings, slab-1 fragment reads, next A loads, 2*NS weight loads
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+        const int bstep = min(step + 1, nsteps - 1);   // weights of the next step (clamped: the last prefetch is unused)
+        bf16x8 bcur[2][NS][TN];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int p = 0; p < NS; ++p)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bcur[m][p][b] = bnext[m][p][b];
+        read_A(0, cur);
+        __builtin_amdgcn_sched_barrier(0);
+
+        auto work = [&](const int w) {
+            if (w < 2) store_A(w, cur ^ 1);                       // stage tile step+1 (its loads are one step old)
+            else if (w == 2) read_A(1, cur);                      // fragments of the second slab
+            else if (w < 5) store_A(w - 1, cur ^ 1);
+            else if (w == 5) load_A();                            // tile step+2 -> registers
+            else load_B(bstep, (w - 6) / NS, (w - 6) % NS);       // weights of step+1 -> registers
+        };
+
+        int mf = 0;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 6 - NT; q < 6; ++q)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][PA[q]][a], bcur[m][PB[q]][b], acc[a][b], 0, 0, 0);
+                        ++mf;
+                        // item w runs after MFMA number max(1, (w+1)*NMF/(NW+1)): evenly spread, and the slab-1 fragment
+                        // reads (item 2) always land in the first quarter of the stream, well before their consumers
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) {
+                            const int pos = ((w + 1) * NMF) / (NW + 1);
+                            if (mf == (pos < 1 ? 1 : pos)) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                work(w);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+        __syncthreads();
+    }
+    conv_epilogue<TM, TN, BN>(d, acc, M, tile_m, tile_n, cls, split, py, px, wm, wn, lane);
+}
+
+// ================================================================================================
 // Narrow-output convolution (cout <= 4: the FlowNet predict_flow / upsampled_flow layers, 2 channels). A 32-column MFMA
 // tile would waste 94 % of the matrix pipe and still stage the whole activation tile through LDS; these layers are
 // pure activation streaming, so they run on the vector ALU in exact fp32: G lanes (G = pow2 >= cin_pad/4, <= 64) share
@@ -689,10 +925,10 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
         else VPS_CONV_LAUNCH((conv_mfma_f32_kernel<TM, TN, WAVES_M, WAVES_N, false>));
     } else if (d.prec == VPS_PREC_BF16X3) {
         if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, 2, true>));
-        else VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, 2, false>));
+        else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, 2>));
     } else {
         if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, 3, true>));
-        else VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, 3, false>));
+        else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, 3>));
     }
 #undef VPS_CONV_LAUNCH
     int st = vps_launch_status();

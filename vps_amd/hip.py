@@ -12,8 +12,9 @@ from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_in
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libvpship.so')
-ABI_VERSION = 3
+# VPS_HIP_LIB: developer override to load an experimental build of the same ABI (kernel A/B timing)
+LIB_PATH = os.environ.get('VPS_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libvpship.so')
+ABI_VERSION = 4
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 2, 3

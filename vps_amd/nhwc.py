@@ -197,7 +197,13 @@ class PackedConv:
             h = r.to(torch.bfloat16)
             planes.append(h)
             r = r - h.float()
-        self.w, self.w_split = None, torch.stack(planes, 0).contiguous()
+        ws = torch.stack(planes, 0)                     # [planes][class][cout_pad][kpad]
+        if not self.deform:
+            # MFMA-fragment order for the direct-to-register weight path (conv_mfma_bf16d_kernel):
+            # [plane][class][cout_pad/32][kpad/16][lane = 32*(k/8 % 2) + cout % 32][8 consecutive k]
+            P, C, O, K = ws.shape
+            ws = ws.view(P, C, O // 32, 32, K // 16, 2, 8).permute(0, 1, 2, 4, 5, 3, 6)
+        self.w, self.w_split = None, ws.contiguous()
 
     @classmethod
     def from_matrix(cls, mat, prec=None):
