@@ -163,6 +163,7 @@ def main():
         fl = sum(c[0] for c in nhwc.CONV_TRACE)
         ms = sum(c[1].elapsed_time(c[2]) for c in nhwc.CONV_TRACE)
         nl = len(nhwc.CONV_TRACE)
+        abytes = sum(c[4] for c in nhwc.CONV_TRACE)
         if args.conv_table:
             agg = {}
             for c in nhwc.CONV_TRACE:
@@ -186,8 +187,15 @@ def main():
                     achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
                     mfma_products_per_fp32_product=nprod, matrix_pipe_executed_tflops=round(ach * nprod, 1),
                     matrix_pipe_peak=pipe_peak, matrix_pipe_frac=round(ach * nprod / pipe_peak, 4),
-                    launches_per_frame=nl, gflop_per_frame=round(fl / 1e9, 1), conv_ms_per_frame=round(ms, 3))
+                    algorithmic_bytes_per_frame=round(abytes), launches_per_frame=nl, gflop_per_frame=round(fl / 1e9, 1), conv_ms_per_frame=round(ms, 3))
 
+    if rank == 0 and roof is not None:
+        # HBM traffic of the conv kernels per frame: measured by separate rocprofv3 --pmc passes (tools/pmc_traffic.py), not
+        # collectable from inside this process; the committed measurement is attached when it is for this arithmetic mode
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic_%s.json' % args.prec)
+        if os.path.exists(pmc):
+            roof['traffic'] = round(json.load(open(pmc))['conv_hbm_bytes_per_frame'])
+            roof['traffic_source'] = 'profiles/' + os.path.basename(pmc) + ' (bytes per frame over all conv launches, like algorithmic_bytes_per_frame)'
     if rank == 0:
         fps = world * args.steps / dt
         line = {

@@ -12,7 +12,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-enum Role { NONE = 0, MFMA = 1, VALU = 2, LOAD_LIN = 3, LOAD_ROWS = 4, LDSR = 5, LOAD_HALF = 6, MIX_VALU = 7, MIX_LDS = 8 };
+enum Role { NONE = 0, MFMA = 1, VALU = 2, LOAD_LIN = 3, LOAD_ROWS = 4, LDSR = 5, LOAD_HALF = 6, MIX_VALU = 7, MIX_LDS = 8, MFMA16 = 9 };
 
 __device__ __forceinline__ float role_mfma(int iters, int lane) {
     f32x16 acc[4];
@@ -27,6 +27,24 @@ __device__ __forceinline__ float role_mfma(int iters, int lane) {
     }
     float s = 0.f;
     for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+    return s;
+}
+
+// same FLOPs per iteration as role_mfma with the 16x16x32 shape (4 passes, 4 accumulator VGPRs per instruction: half
+// the accumulator write-back per FLOP of 32x32x16)
+__device__ __forceinline__ float role_mfma16(int iters, int lane) {
+    f32x4 acc[8];
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    bf16x8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(float)(lane + e); b[e] = (__bf16)(float)(lane - e); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 12; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 4; ++r) s += acc[i][r];
     return s;
 }
 
@@ -45,7 +63,10 @@ __device__ __forceinline__ float role_mix(const __bf16* lds, int iters, int lane
 #pragma unroll
         for (int u = 0; u < 12; ++u) {
             bf16x8 v;
-            if (KIND == 1) v = *reinterpret_cast<const volatile bf16x8*>(&lds[((u & 3) * 32 + row) * 32 + ((((lane >> 5) + 2 * (u >> 2 & 1)) ^ sw) << 3)]);
+            if (KIND == 1) {
+                const unsigned ad = (unsigned)(size_t)lds + (((u & 3) * 32 + row) * 32 + ((((lane >> 5) + 2 * (u >> 2 & 1)) ^ sw) << 3)) * 2;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(ad));
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
@@ -54,7 +75,7 @@ __device__ __forceinline__ float role_mix(const __bf16* lds, int iters, int lane
                     for (int j = 0; j < 5; ++j) x[j] = __builtin_fmaf(x[j], 1.0001f, 0.5f);
                 }
             }
-            if (KIND == 1) s += (float)v[0];
+            if (KIND == 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); s += (float)v[0]; }
         }
     }
     for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
@@ -99,17 +120,23 @@ __device__ __forceinline__ float role_load(const float* __restrict__ buf, size_t
     return s[0] + s[1] + s[2] + s[3];
 }
 
+// 12 ds_read_b128 per iteration with the conv kernels' fragment addressing (64-byte rows, XOR-swizzled 16-byte chunks).
+// Inline asm: the compiler removed the plain (even volatile) vector reads of the first version of this role.
 __device__ __forceinline__ float role_lds(const __bf16* lds, int iters, int lane, int wave) {
-    float s = 0.f;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
     const int row = lane & 31, sw = (row >> 2) & 3;
+    const unsigned base = (unsigned)(size_t)lds;
+    unsigned addr[12];
+    for (int u = 0; u < 12; ++u) addr[u] = base + (((u & 3) * 32 + row) * 32 + ((((lane >> 5) + 2 * (u >> 2 & 1)) ^ sw) << 3)) * 2;
     for (int it = 0; it < iters; ++it) {
+        f32x4 v[12];
 #pragma unroll
-        for (int u = 0; u < 12; ++u) {
-            const bf16x8 v = *reinterpret_cast<const volatile bf16x8*>(&lds[((u & 3) * 32 + row) * 32 + ((((lane >> 5) + 2 * (u >> 2 & 1)) ^ sw) << 3)]);
-            s += (float)v[0];
-        }
+        for (int u = 0; u < 12; ++u) asm volatile("ds_read_b128 %0, %1" : "=v"(v[u]) : "v"(addr[u]));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < 12; ++u) s += v[u];
     }
-    return s;
+    return s[0] + s[1] + s[2] + s[3];
 }
 
 __global__ __launch_bounds__(512) void pipe_kernel(int roleA, int roleB, int itA, int itB, const float* buf, size_t nfloat, float* sink, int prioB) {
@@ -127,6 +154,7 @@ __global__ __launch_bounds__(512) void pipe_kernel(int roleA, int roleB, int itA
     else if (role == LOAD_ROWS) r = role_load(buf, nfloat, iters, lane, wave, blockIdx.x, 1);
     else if (role == LOAD_HALF) r = role_load(buf, nfloat, iters, lane, wave, blockIdx.x, 2);
     else if (role == LDSR) r = role_lds(lds, iters, lane, wave);
+    else if (role == MFMA16) r = role_mfma16(iters, lane);
     else if (role == MIX_VALU) r = role_mix<0>(lds, iters, lane);
     else if (role == MIX_LDS) r = role_mix<1>(lds, iters, lane);
     if (r == 12345.678f) sink[0] = r;
@@ -152,7 +180,7 @@ int main() {
     float *buf, *sink;
     hipMalloc(&buf, nfloat * 4); hipMalloc(&sink, 64);
     hipMemset(buf, 0, nfloat * 4);
-    const char* names[] = {"none", "mfma", "valu", "load-1KB", "load-8x128B", "lds-read", "load-16x64B", "mfma+valu", "mfma+lds"};
+    const char* names[] = {"none", "mfma", "valu", "load-1KB", "load-8x128B", "lds-read", "load-16x64B", "mfma+valu", "mfma+lds", "mfma16x16x32"};
     const int IT_M = 2000, IT_V = 1000, IT_L = 1500, IT_S = 6000;
     auto its = [&](int role) { return (role == MFMA || role >= MIX_VALU) ? IT_M : role == VALU ? IT_V : role == LDSR ? IT_S : IT_L; };
     auto report = [&](int a, int b) {
@@ -189,6 +217,12 @@ int main() {
     report(VALU, LOAD_LIN);
     report(VALU, LDSR);
     report(LDSR, LOAD_LIN);
+    printf("-- 16x16x32 shape (same FLOPs per iteration)\n");
+    report(MFMA16, NONE);
+    report(MFMA16, VALU);
+    report(MFMA16, LOAD_LIN);
+    report(MFMA16, LDSR);
+    report(MFMA16, MFMA16);
     printf("-- same wave interleaved (A only): compare with mfma alone\n");
     report(MIX_VALU, NONE);
     report(MIX_LDS, NONE);

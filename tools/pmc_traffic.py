@@ -1,0 +1,43 @@
+"""Aggregate the HBM-side traffic of the conv kernels from two rocprofv3 --pmc passes over bench.py (GPU box).
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline
+    python $R/tools/pmc_traffic.py $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write 3 > $R/gpurun_out/pmc_traffic.json
+
+(separate passes, no other trace domain: MI355X_MICROARCH.md "HBM" / "rocprofv3 PMC slots"). FETCH_SIZE / WRITE_SIZE are
+in KiB; on gfx950 FETCH_SIZE counts 128-byte requests of wide (16 B/lane) coalesced reads as 64 bytes, so it is doubled
+(all loads of the conv kernels are global_load_dwordx4); WRITE_SIZE is taken as reported (uncalibrated, see the guide).
+The third argument is the number of frames the profiled command ran (warmup + steps + 1 instrumented frame)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def total(directory, counter, match):
+    tot, n = 0.0, 0
+    for fn in glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True):
+        for row in csv.DictReader(open(fn)):
+            if row['Counter_Name'] == counter and match in row['Kernel_Name']:
+                tot += float(row['Counter_Value']); n += 1
+    return tot, n
+
+
+def main():
+    fetch_dir, write_dir, frames = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    out = {'frames': frames, 'kernels': {}}
+    for name in ('conv_mfma_bf16p_kernel', 'conv_mfma_bf16s_kernel', 'conv_mfma_f32_kernel', 'conv_small_kernel', 'conv_splitk_reduce_kernel'):
+        f, nf = total(fetch_dir, 'FETCH_SIZE', name)
+        w, nw = total(write_dir, 'WRITE_SIZE', name)
+        if nf or nw:
+            out['kernels'][name] = {'launches_per_frame': nf / frames, 'fetch_bytes_per_frame': 2.0 * f * 1024 / frames,
+                                    'write_bytes_per_frame': w * 1024 / frames}
+    out['conv_hbm_bytes_per_frame'] = sum(k['fetch_bytes_per_frame'] + k['write_bytes_per_frame'] for k in out['kernels'].values())
+    out['note'] = 'FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE as reported; Infinity-Cache hits are counted'
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()

@@ -22,7 +22,7 @@ def _ceil(a, b):
 DEFAULT_PREC = hip.PREC_F32
 
 # bench.py sets this to a list to time every vps_conv2d launch with HIP events on the launch stream:
-# entries (algorithmic_flops, start_event, end_event). None = no instrumentation (the default).
+# entries (algorithmic_flops, start_event, end_event, shape tag, algorithmic_bytes). None = no instrumentation (the default).
 CONV_TRACE = None
 
 
@@ -298,10 +298,17 @@ class PackedConv:
             CONV_TRACE.append((self.flops(x.N, x.H, x.W), e0, e1,
                                '%d->%d k%dx%d s%d %s%s n%d %dx%d tile%d ksplit%d p%d' % (self.cin, self.cout, self.KH, self.KW, self.stride,
                                                                                    'T' if self.transposed else '', 'D' if self.deform else '',
-                                                                                   x.N, x.H, x.W, self.tile_n, ksplit, self.prec)))
+                                                                                   x.N, x.H, x.W, self.tile_n, ksplit, self.prec),
+                               self.bytes(x.N, x.H, x.W, res is not None)))
         else:
             hip.conv2d(d)
         return out
+
+    def bytes(self, x_N, x_H, x_W, has_res=False):
+        """algorithmic HBM bytes of one call: every input / weight / residual element read once, every output written once."""
+        Ho, Wo = self.out_hw(x_H, x_W)
+        wbytes = self.nclass * self.cout * self.KH * self.KW * self.cin * (4 if self.prec == hip.PREC_F32 else 2 * self.prec)
+        return 4.0 * x_N * (x_H * x_W * self.cin + Ho * Wo * self.cout * (2 if has_res else 1)) + wbytes
 
     def flops(self, x_N, x_H, x_W):
         """algorithmic FLOPs (2*MACs, unpadded) of one call on an input of that size."""
