@@ -51,6 +51,11 @@ CONV_CASES = [
     (1024, 1024, 3, 1, 1, 4, 8, 'leaky', False, False), # conv6_1: deep, tiny M -> split-K
     (512, 512, 3, 2, 1, 16, 16, 'leaky', False, False), # split-K, stride 2
     (256, 36, 1, 1, 0, 7, 9, 'none', False, False),     # tile_n 64, tiny M
+    # whole 8x16 output patches, stride 1, 3x3, chunk-major k: the halo-staged kernel in the split-bf16 modes
+    (64, 64, 3, 1, 1, 16, 32, 'relu', True, True),      # tile_n 64, residual
+    (82, 16, 3, 1, 1, 24, 48, 'leaky', False, False),   # fusion conv (cin pad 84 -> 3 chunks, tile_n 32)
+    (256, 256, 3, 1, 1, 8, 16, 'relu', True, False),    # tile_n 128, a single patch
+    (194, 130, 3, 1, 1, 16, 16, 'none', False, False),  # ragged channel chunk, cout not a multiple of 32
 ]
 
 
@@ -109,7 +114,9 @@ def test_conv_writes_into_concat_window_and_reads_padded_window(dev):
 
 @pytest.mark.parametrize('prec,tol', PRECS, ids=['f32', 'bf16x3', 'bf16x6'])
 @pytest.mark.parametrize('cin,cout,k,pad,H,W', [(1024, 512, 4, 1, 4, 8), (386, 64, 4, 1, 16, 24), (2, 2, 4, 1, 8, 12),
-                                                (256, 256, 2, 0, 14, 14), (162, 16, 4, 1, 20, 28)])
+                                                (256, 256, 2, 0, 14, 14), (162, 16, 4, 1, 20, 28),
+                                                # whole 8x16 patches per parity class: halo-staged kernel
+                                                (386, 64, 4, 1, 16, 32), (162, 16, 4, 1, 8, 48), (128, 160, 4, 1, 24, 16)])
 def test_conv_transpose_matches_torch_cpu(dev, cin, cout, k, pad, H, W, prec, tol):
     x = _rand(2 if k == 2 else 1, cin, H, W, seed=1)
     w = _rand(cin, cout, k, k, seed=2, scale=(1.0 / (cin * k)) ** 0.5)
@@ -118,6 +125,25 @@ def test_conv_transpose_matches_torch_cpu(dev, cin, cout, k, pad, H, W, prec, to
     pc = nhwc.PackedConv(w, b, None, stride=2, padding=pad, act=hip.ACT_LEAKY, transposed=True, device=dev, prec=prec)
     out = pc(nhwc.from_nchw(x.to(dev)), ws=nhwc.Workspace(dev), name='o')
     _cmp(out.to_nchw(), ref, rtol=tol, atol=tol * max(1.0, float(ref.abs().max()) / 4), what='deconv')
+
+
+@pytest.mark.parametrize('prec,tol', PRECS[1:], ids=['bf16x3', 'bf16x6'])
+def test_halo_conv_batch_and_concat_window(dev, prec, tol):
+    """halo-staged kernel with N=2 images, reading a channel window of a wider buffer and writing into a concat window"""
+    N, H, W = 2, 16, 32
+    x = _rand(N, 96, H, W, seed=1); w = _rand(48, 96, 3, 3, seed=2, scale=0.05); b = _rand(48, seed=3, scale=0.1)
+    ws = nhwc.Workspace(dev)
+    src = ws.fmap('src', N, H, W, 128)                       # input lives in channels [32, 128) of a 128-wide buffer
+    xd = x.to(dev)                                           # kept alive until the synchronize below
+    hip.check(hip.load().vps_nchw_to_nhwc(hip.ptr(xd), src.ptr(), src.ld, 32, N, 96, H, W, 96, hip.stream_ptr()), 't')
+    dst = ws.fmap('dst', N, H, W, 80)
+    pc = nhwc.PackedConv(w, b, None, 1, 1, act=hip.ACT_LEAKY, slope=0.1, device=dev, prec=prec)
+    pc(src.window(32, 96), out=dst.window(16, 48))
+    torch.cuda.synchronize()
+    ref = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.1)
+    _cmp(dst.to_nchw()[:, 16:64], ref, rtol=tol, atol=tol * max(1.0, float(ref.abs().max()) / 4), what='halo conv window')
+    full = dst.to_nchw()
+    assert float(full[:, :16].abs().max()) == 0.0 and float(full[:, 64:].abs().max()) == 0.0
 
 
 def test_fpn_topdown_residual_upsample(dev):

@@ -48,7 +48,8 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
 }
 
 // ---- shared epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-template <int TM, int TN, int BN>
+// TILE2D: the block's 128 rows are an 8x16 patch of output positions (halo kernel), tile_m = (n*Qh/8 + ty)*Qw/16 + tx
+template <int TM, int TN, int BN, bool TILE2D = false>
 __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&acc)[TM][TN], const int M, const int tile_m,
                                               const int tile_n, const int cls, const int split, const int py, const int px,
                                               const int wm, const int wn, const int lane) {
@@ -81,21 +82,33 @@ __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&a
         sc[b] = (cok[b] && d.scale) ? d.scale[co] : 1.f;
         sh[b] = (cok[b] && d.shift) ? d.shift[co] : 0.f;
     }
-    const bool simple_pix = (d.nclass == 1 && d.os_y == 1 && d.os_x == 1 && d.res_shift == 0);
+    const bool simple_pix = !TILE2D && (d.nclass == 1 && d.os_y == 1 && d.os_x == 1 && d.res_shift == 0);
+    int t2_n = 0, t2_y0 = 0, t2_x0 = 0;
+    if constexpr (TILE2D) {
+        const int tiles_x = d.Qw >> 4, tiles_y = d.Qh >> 3;
+        const int tx = tile_m % tiles_x, tq = tile_m / tiles_x;
+        t2_x0 = tx * 16; t2_y0 = (tq % tiles_y) * 8; t2_n = tq / tiles_y;
+    }
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = tile_m * BM + wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+            const int jl = wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + row_l;   // row of the block tile
+            const int m = tile_m * BM + jl;
             if (m >= M) continue;
             size_t opix, rpix;
             if (simple_pix) {
                 opix = rpix = (size_t)m;
             } else {
-                const int qx = m % d.Qw;
-                const int tq = m / d.Qw;
-                const int qy = tq % d.Qh;
-                const int n = tq / d.Qh;
+                int qx, qy, n;
+                if constexpr (TILE2D) {
+                    qx = t2_x0 + (jl & 15); qy = t2_y0 + (jl >> 4); n = t2_n;
+                } else {
+                    qx = m % d.Qw;
+                    const int tq = m / d.Qw;
+                    qy = tq % d.Qh;
+                    n = tq / d.Qh;
+                }
                 const int oy = qy * d.os_y + py, ox = qx * d.os_x + px;
                 opix = ((size_t)n * d.Ho + oy) * d.Wo + ox;
                 const int rs = d.res_shift;
@@ -808,6 +821,197 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
 }
 
 // ================================================================================================
+// Split-bf16, halo-staged ("bf16h"): stride-1 KHxKW layers (3x3 convolutions, the 2x2 parity classes of the transposed
+// convolutions) whose output is a whole number of 8x16 patches. Same pipeline as bf16p, different activation path:
+// the block's 128 rows are an 8x16 PATCH of output positions, and per 32-channel chunk its (8+KH-1)x(16+KW-1) input
+// halo is loaded, split and staged in LDS ONCE; the KH*KW taps of the chunk then read their A fragments from that halo
+// tile at a per-tap row offset. Versus bf16p (which re-loads and re-splits the 128x32 activation tile for every tap):
+// 6.4x (3x3) / 3.3x (2x2) fewer activation loads, conversions and LDS writes, one barrier per chunk instead of per
+// k-step. On this chip a saturated MFMA stream does not overlap with the other instructions of its SIMD (profiles/
+// r01_pipebench.txt), so every removed instruction is time. The tap loop is fully unrolled (KH, KW are template
+// parameters), so which work item goes between which MFMAs is decided at compile time.
+// ================================================================================================
+template <int TM, int TN, int WAVES_M, int WAVES_N, int NS, int KH, int KW>
+__global__ __launch_bounds__(256, 2)
+void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int tiles_n) {
+    constexpr int BN = WAVES_N * TN * 32;
+    static_assert(WAVES_M * TM * 32 == BM, "block M tile must be 128");
+    static_assert(WAVES_M * WAVES_N == 4, "4 wavefronts per block");
+    constexpr int NTAP = KH * KW;
+    constexpr int HW = 16 + KW - 1, HH = 8 + KH - 1;   // halo tile
+    constexpr int HROWS = HH * HW;                      // <= 180
+    constexpr int NLD = (HROWS + 31) / 32;              // staged rows per thread (32 rows per pass of the 256 threads)
+    constexpr int PLANE = NLD * 32 * LDS_LDH;           // bf16 elements of one plane of one buffer
+    constexpr int ABUF = NS * PLANE;
+
+    __shared__ __attribute__((aligned(16))) __bf16 As[2 * ABUF];
+
+    const int t = threadIdx.x;
+    int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_n = swz % tiles_n; swz /= tiles_n;
+    const int tile_m = swz % tiles_m;
+    const int cls = swz / tiles_m;
+
+    const int py = cls / d.os_x, px = cls - py * d.os_x;
+    const int H = d.H, W = d.W, cin_pad = d.cin_pad;
+    const int tiles_x = d.Qw >> 4, tiles_y = d.Qh >> 3;
+    const int tx = tile_m % tiles_x, tq = tile_m / tiles_x;
+    const int ty = tq % tiles_y, n = tq / tiles_y;
+    const int iy_org = ty * 8 - d.pad_y[py], ix_org = tx * 16 - d.pad_x[px];   // input position of halo row 0, column 0
+
+    const int k4 = t & 7;      // 4-channel group staged by this thread (8 lanes = one 128-byte line)
+    const int r0 = t >> 3;     // halo rows r0 + 32 i
+    const int nchunks = d.kpad / (BK * NTAP);
+    const int nsteps = nchunks * NTAP;
+
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+    const int nbt = d.cout_pad >> 5, kst = d.kpad >> 4;
+    const size_t wplane = (size_t)d.nclass * nbt * kst * 512;
+    const __bf16* __restrict__ wfrag = reinterpret_cast<const __bf16*>(d.w_split) +
+        ((size_t)(cls * nbt + tile_n * (BN / 32) + wn * TN) * kst) * 512 + lane * 8;
+
+    f32x4 areg[NLD];
+    unsigned aok = 0;
+    int achunk = 0;            // next chunk to load
+    bf16x8 bnext[2][NS][TN];
+
+    auto load_A = [&]() {
+        const int cic = achunk * BK + k4 * 4;
+        const bool kv = cic < cin_pad;
+        ++achunk;
+        aok = 0;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            // the halo position is recomputed per chunk (a handful of VALU per 9 taps) instead of held in registers.
+            // branch-free: rows outside the image / channel range read element 0 and are zeroed when staged
+            const int hp = r0 + 32 * i;
+            const int hy = hp / HW, hx = hp - hy * HW;
+            const int iy = iy_org + hy, ix = ix_org + hx;
+            const bool ok = kv && hp < HROWS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const int pix = ok ? (n * H + iy) * W + ix : 0;
+            areg[i] = *reinterpret_cast<const f32x4*>(d.in + ((size_t)pix * d.in_ld + d.in_coff + (ok ? cic : 0)));
+            aok |= (ok ? 1u : 0u) << i;
+        }
+    };
+    auto load_B = [&](int step, int m, int p) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+            bnext[m][p][b] = *reinterpret_cast<const bf16x8*>(wfrag + (size_t)p * wplane + ((size_t)b * kst + 2 * step + m) * 512);
+    };
+    auto store_A = [&](int i, int buf) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        bf16x4 sp[NS];
+        split_bf16<NS>(((aok >> i) & 1u) ? areg[i] : z, sp);
+        const int row = r0 + 32 * i;
+#pragma unroll
+        for (int p = 0; p < NS; ++p)
+            *reinterpret_cast<bf16x4*>(&As[buf * ABUF + p * PLANE + row * LDS_LDH + (((k4 >> 1) ^ lds_swz(row)) << 3) + ((k4 & 1) << 2)]) = sp[p];
+    };
+
+    // halo row of tile row j = wm*TM*32 + a*32 + (lane&31) for tap (0,0); tap (ky,kx) adds ky*HW + kx
+    int hbase[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const int j = wm * TM * 32 + a * 32 + (lane & 31);
+        hbase[a] = (j >> 4) * HW + (j & 15);
+    }
+    bf16x8 af[2][NS][TM];
+    auto read_A = [&](int m, int buf, int toff) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int hrow = hbase[a] + toff;
+            const int off = buf * ABUF + hrow * LDS_LDH + (((2 * m + (lane >> 5)) ^ lds_swz(hrow)) << 3);
+#pragma unroll
+            for (int p = 0; p < NS; ++p) af[m][p][a] = *reinterpret_cast<const bf16x8*>(&As[off + p * PLANE]);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // prologue: chunk 0 staged in buffer 0, chunk 1 in flight in registers, weights of step 0 in flight
+    load_A();
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int p = 0; p < NS; ++p) load_B(0, m, p);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) store_A(i, 0);
+    load_A();
+    __syncthreads();
+
+    constexpr int NT = NS == 3 ? 6 : 3;
+    constexpr int NMF = 2 * NT * TM * TN;                       // MFMAs per wave and tap
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int SPT = (NLD + NTAP - 2) / (NTAP - 1);          // halo rows staged per tap (the last tap issues the loads)
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int cur = chunk & 1;
+#pragma unroll
+        for (int tp = 0; tp < NTAP; ++tp) {
+            const int step = chunk * NTAP + tp;
+            const int bstep = min(step + 1, nsteps - 1);        // weights of the next step (clamped: the last prefetch is unused)
+            const int toff = (tp / KW) * HW + (tp % KW);
+            bf16x8 bcur[2][NS][TN];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int p = 0; p < NS; ++p)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) bcur[m][p][b] = bnext[m][p][b];
+            read_A(0, cur, toff);
+            __builtin_amdgcn_sched_barrier(0);
+
+            // work items of this tap: SPT halo-row stagings (or, on the last tap, the loads of chunk+2), the fragment reads
+            // of the second slab, 2*NS weight loads of the next step
+            const int NW = SPT + 1 + 2 * NS;
+            auto work = [&](const int w) {
+                if (w == 1) read_A(1, cur, toff);
+                else if (w == 0 || (w >= 2 && w < SPT + 1)) {
+                    const int si = (w == 0 ? 0 : w - 1);             // 0 .. SPT-1
+                    if (tp < NTAP - 1) {
+                        const int row = tp * SPT + si;
+                        if (row < NLD) store_A(row, cur ^ 1);
+                    } else if (si == 0) load_A();
+                } else load_B(bstep, (w - SPT - 1) / NS, (w - SPT - 1) % NS);
+            };
+
+            int mf = 0;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 6 - NT; q < 6; ++q)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) {
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][PA[q]][a], bcur[m][PB[q]][b], acc[a][b], 0, 0, 0);
+                            ++mf;
+#pragma unroll
+                            for (int w = 0; w < NW; ++w) {
+                                const int pos = ((w + 1) * NMF) / (NW + 1);
+                                if (mf == (pos < 1 ? 1 : pos)) {
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    work(w);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            }
+                        }
+        }
+        __syncthreads();
+    }
+    conv_epilogue<TM, TN, BN, true>(d, acc, tiles_m * BM, tile_m, tile_n, cls, 0, py, px, wm, wn, lane);
+}
+
+// ================================================================================================
 // Narrow-output convolution (cout <= 4: the FlowNet predict_flow / upsampled_flow layers, 2 channels). A 32-column MFMA
 // tile would waste 94 % of the matrix pipe and still stage the whole activation tile through LDS; these layers are
 // pure activation streaming, so they run on the vector ALU in exact fp32: G lanes (G = pow2 >= cin_pad/4, <= 64) share
@@ -918,6 +1122,17 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
     if (nsplit_eff != d.ksplit) return VPS_EARG(20);  // caller must pick ksplit | ceil-consistent
     const long nblk = (long)tiles_m * tiles_n * d.nclass * d.ksplit;
     if (nblk <= 0 || nblk > 0x7fffffffL) return VPS_EARG(21);
+    // stride-1 3x3 / 2x2-class layers on whole 8x16 output patches: halo-staged kernel
+    if (d.prec != VPS_PREC_F32 && !d.offset && d.stride == 1 && d.korder == 1 && d.ksplit == 1 && d.Qh % 8 == 0 && d.Qw % 16 == 0 &&
+        d.KH == d.KW && (d.KH == 3 || d.KH == 2)) {
+#define VPS_HALO_LAUNCH(NS, K)                                                                                                   \
+    hipLaunchKernelGGL((conv_mfma_bf16h_kernel<TM, TN, WAVES_M, WAVES_N, NS, K, K>), dim3((unsigned)nblk), dim3(256), 0, s, d, tiles_m, \
+                       tiles_n)
+        if (d.prec == VPS_PREC_BF16X3) { if (d.KH == 3) VPS_HALO_LAUNCH(2, 3); else VPS_HALO_LAUNCH(2, 2); }
+        else { if (d.KH == 3) VPS_HALO_LAUNCH(3, 3); else VPS_HALO_LAUNCH(3, 2); }
+#undef VPS_HALO_LAUNCH
+        return vps_launch_status();
+    }
 #define VPS_CONV_LAUNCH(KERNEL)                                                                              \
     hipLaunchKernelGGL((KERNEL), dim3((unsigned)nblk), dim3(256), 0, s, d, M, tiles_m, tiles_n, per_split)
     if (d.prec == VPS_PREC_F32) {
