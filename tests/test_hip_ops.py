@@ -51,6 +51,11 @@ CONV_CASES = [
     (1024, 1024, 3, 1, 1, 4, 8, 'leaky', False, False), # conv6_1: deep, tiny M -> split-K
     (512, 512, 3, 2, 1, 16, 16, 'leaky', False, False), # split-K, stride 2
     (256, 36, 1, 1, 0, 7, 9, 'none', False, False),     # tile_n 64, tiny M
+    # narrow outputs (exact-fp32 vector kernels in every mode): sliding-window 3x3 kernel with 1..5 channel slots per lane
+    (16, 2, 3, 1, 1, 40, 56, 'none', False, False),     # 4 lanes per pixel
+    (386, 2, 3, 1, 1, 16, 24, 'none', False, False),    # predict_flow3: two channel slots per lane
+    (1026, 2, 3, 1, 1, 8, 13, 'none', False, False),    # predict_flow5: five slots, 76 KB of weights in LDS, ragged run
+    (64, 3, 3, 1, 1, 16, 24, 'leaky', False, False),    # cout 3
     # whole 8x16 output patches, stride 1, 3x3, chunk-major k: the halo-staged kernel in the split-bf16 modes
     (64, 64, 3, 1, 1, 16, 32, 'relu', True, True),      # tile_n 64, residual
     (82, 16, 3, 1, 1, 24, 48, 'leaky', False, False),   # fusion conv (cin pad 84 -> 3 chunks, tile_n 32)

@@ -1081,6 +1081,123 @@ void conv_small_kernel(const vps_conv_desc d, const int M, const int G, const in
     }
 }
 
+// Narrow-output 3x3 stride-1 convolution (the predict_flow layers): same arithmetic as conv_small_kernel, organised for the
+// memory pipe. The CO x kpad weights sit in LDS (loaded once per workgroup); every G-lane group walks a horizontal run of
+// RUN output pixels whose RUN+2 input columns (float4 channel slices of 3 rows) are all requested up front, so each
+// activation is loaded 3.75 times instead of 9 and a run costs one memory latency instead of 9 per pixel (the layer is
+// pure activation streaming: latency and load count are the cost); loads are branch-free (clamped address, value zeroed
+// afterwards).
+template <int CO, int RUN>
+__global__ __launch_bounds__(512)
+void conv_small3x3_kernel(const vps_conv_desc d, const int G, const int logG, const int runs_per_row, const long total_runs) {
+    extern __shared__ __attribute__((aligned(16))) float wlds[];   // [CO][kpad]
+    const int t = threadIdx.x;
+    const int kpad = d.kpad;
+    for (int i = t * 4; i < CO * kpad; i += 512 * 4) {
+        const int co = i / kpad, k = i - co * kpad;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(&wlds[i]) = co < d.cout_pad ? *reinterpret_cast<const f32x4*>(d.w + (size_t)co * kpad + k) : z;
+    }
+    __syncthreads();
+
+    const int lane = t & 63;
+    const int sub = lane & (G - 1);
+    const int ppw = 64 >> logG;
+    const long group = ((long)blockIdx.x * 8 + (t >> 6)) * ppw + (lane >> logG);
+    const long ngroups = (long)gridDim.x * 8 * ppw;
+    const int H = d.H, W = d.W, cin_pad = d.cin_pad, c4n = cin_pad >> 2;
+    const int nslot = (c4n + G - 1) >> logG;
+
+    for (long run = group; run - (lane >> logG) < total_runs; run += ngroups) {   // whole wavefronts iterate together (shuffles below)
+        const bool rv = run < total_runs;
+        const long rr = rv ? run : 0;
+        const int x0 = (int)(rr % runs_per_row) * RUN;
+        const long ty = rr / runs_per_row;
+        const int y = (int)(ty % H), n = (int)(ty / H);
+        float acc[RUN][CO];
+#pragma unroll
+        for (int xi = 0; xi < RUN; ++xi)
+#pragma unroll
+            for (int c = 0; c < CO; ++c) acc[xi][c] = 0.f;
+
+        for (int slot = 0; slot < nslot; ++slot) {
+            const int c4 = sub + (slot << logG);
+            const bool cv = rv && c4 < c4n;
+            const int ci = cv ? 4 * c4 : 0;
+            // weight offsets of this channel slice: tap stride in k
+            const int kbase = d.korder == 0 ? ci : ((ci >> 5) * 9) * 32 + (ci & 31);
+            const int kstep = d.korder == 0 ? cin_pad : 32;
+            const float* __restrict__ rowp[3];
+            bool rowok[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = y + ky - 1;
+                rowok[ky] = cv && (unsigned)iy < (unsigned)H;
+                rowp[ky] = d.in + ((size_t)(n * H + (rowok[ky] ? iy : 0)) * W) * d.in_ld + d.in_coff + ci;
+            }
+            // all RUN+2 columns of the run are requested before the first value is touched (a select right behind each load
+            // would put an s_waitcnt vmcnt(0) behind each load: 30 serial memory latencies per run); masks are applied in
+            // place once the data is there
+            f32x4 col[RUN + 2][3];
+#pragma unroll
+            for (int j = 0; j < RUN + 2; ++j) {
+                const int x = x0 - 1 + j;
+                const size_t xo = (size_t)((unsigned)x < (unsigned)W ? x : 0) * d.in_ld;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) col[j][ky] = *reinterpret_cast<const f32x4*>(rowp[ky] + xo);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < RUN + 2; ++j) {
+                const bool xok = (unsigned)(x0 - 1 + j) < (unsigned)W;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    col[j][ky] = (xok && rowok[ky]) ? col[j][ky] : z;
+                }
+            }
+#pragma unroll
+            for (int xi = 0; xi < RUN; ++xi) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const f32x4 a = col[xi + kx][ky];
+                        const int k = kbase + (ky * 3 + kx) * kstep;
+#pragma unroll
+                        for (int c = 0; c < CO; ++c) {
+                            const f32x4 wv = *reinterpret_cast<const f32x4*>(&wlds[c * kpad + k]);
+                            acc[xi][c] += a[0] * wv[0] + a[1] * wv[1] + a[2] * wv[2] + a[3] * wv[3];
+                        }
+                    }
+            }
+        }
+#pragma unroll
+        for (int xi = 0; xi < RUN; ++xi)
+#pragma unroll
+            for (int c = 0; c < CO; ++c)
+                for (int off = G >> 1; off >= 1; off >>= 1) acc[xi][c] += __shfl_xor(acc[xi][c], off, 64);
+        if (rv && sub == 0) {
+#pragma unroll
+            for (int xi = 0; xi < RUN; ++xi) {
+                const int x = x0 + xi;
+                if (x >= W) break;
+                const size_t opix = ((size_t)n * d.Ho + y) * d.Wo + x;
+                const int rs = d.res_shift;
+                const size_t rpix = ((size_t)n * (d.Ho >> rs) + (y >> rs)) * (d.Wo >> rs) + (x >> rs);
+#pragma unroll
+                for (int c = 0; c < CO; ++c) {
+                    if (c < d.cout) {
+                        float v = acc[xi][c] * (d.scale ? d.scale[c] : 1.f) + (d.shift ? d.shift[c] : 0.f);
+                        if (d.res) v += d.res[rpix * d.res_ld + d.res_coff + c];
+                        d.out[opix * d.out_ld + d.out_coff + c] = vps_act(v, d.act, d.slope);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // sum the split-K partials and apply the epilogue
 __global__ __launch_bounds__(256)
 void conv_splitk_reduce_kernel(const vps_conv_desc d, const int M) {
@@ -1180,6 +1297,26 @@ extern "C" int vps_conv2d(const vps_conv_desc* dp, void* stream) {
     if (d.cout <= 4 && d.prec == VPS_PREC_F32 && !d.offset && d.ksplit == 1 && d.tile_n == 32) {
         int G = 1, logG = 0;
         while (G < 64 && G < (d.cin_pad >> 2)) { G <<= 1; ++logG; }
+        const size_t wbytes = (size_t)(d.cout <= 2 ? 2 : 4) * d.kpad * sizeof(float);
+        if (d.KH == 3 && d.KW == 3 && d.stride == 1 && d.nclass == 1 && d.pad_y[0] == 1 && d.pad_x[0] == 1 && d.Ho == d.H && d.Wo == d.W &&
+            wbytes <= 150 * 1024 && (d.cout <= 2 || d.cout_pad >= 4)) {
+            constexpr int RUN = 4;
+            const int run = d.cout <= 2 ? RUN : RUN / 2;
+            const int runs_per_row = (d.W + run - 1) / run;
+            const long total_runs = (long)d.N * d.H * runs_per_row;
+            const int ppw = 64 >> logG;
+            long blocks = (total_runs + 8 * ppw - 1) / (8 * ppw);
+            if (blocks > 1024) blocks = 1024;
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small3x3_kernel<2, RUN>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small3x3_kernel<4, RUN / 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                attr_set = true;
+            }
+            if (d.cout <= 2) hipLaunchKernelGGL((conv_small3x3_kernel<2, RUN>), dim3((unsigned)blocks), dim3(512), wbytes, s, d, G, logG, runs_per_row, total_runs);
+            else hipLaunchKernelGGL((conv_small3x3_kernel<4, RUN / 2>), dim3((unsigned)blocks), dim3(512), wbytes, s, d, G, logG, runs_per_row, total_runs);
+            return vps_launch_status();
+        }
         const long total = (long)d.nclass * M;
         long waves = (total + (64 >> logG) - 1) / (64 >> logG);
         long blocks = (waves + 3) / 4; if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
