@@ -263,8 +263,35 @@ def test_groupnorm_relu(dev, C):
     ref = F.relu(F.group_norm(x, 32, g, b, 1e-5))
     ws = nhwc.Workspace(dev)
     stats = ws.get('st', (64,), dtype=torch.float64)
-    out = nhwc.groupnorm_relu(nhwc.from_nchw(x.to(dev)), ws.fmap('o', 1, 20, 28, C), 32, g.to(dev), b.to(dev), 1e-5, stats)
+    gd, bd = g.to(dev), b.to(dev)
+    out = nhwc.groupnorm_relu(nhwc.from_nchw(x.to(dev)), ws.fmap('o', 1, 20, 28, C), 32, gd, bd, 1e-5, stats)
     _cmp(out.to_nchw(), ref, rtol=1e-5, atol=1e-5, what='groupnorm')
+    # into a channel window of a wider buffer (float4 path: offset multiple of 4; scalar path: odd leading dimension)
+    for ld, coff in ((C + 32, 16), (C + 7, 3)):
+        wide = ws.fmap('w%d' % ld, 1, 20, 28, ld)
+        nhwc.groupnorm_relu(nhwc.from_nchw(x.to(dev)), wide.window(coff, C), 32, gd, bd, 1e-5, stats)
+        full = wide.to_nchw()
+        _cmp(full[:, coff:coff + C], ref, rtol=1e-5, atol=1e-5, what='groupnorm window ld %d' % ld)
+        assert float(full[:, :coff].abs().max()) == 0.0 and float(full[:, coff + C:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('C,Hi,Wi,mode', [(64, 33, 47, 0), (3, 32, 48, 1), (8, 16, 24, 1), (6, 17, 9, 0)])
+def test_pool3x3s2_vector_and_scalar_paths(dev, C, Hi, Wi, mode):
+    x = _rand(2, C, Hi, Wi, seed=3)
+    ref = F.max_pool2d(x, 3, 2, 1) if mode == 0 else F.avg_pool2d(x, 3, 2, 1, count_include_pad=True)
+    ws = nhwc.Workspace(dev)
+    Ho, Wo = (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1
+    out = nhwc.pool3x3s2(nhwc.from_nchw(x.to(dev)), ws.fmap('p', 2, Ho, Wo, C), mode='max' if mode == 0 else 'avg')
+    _cmp(out.to_nchw(), ref, rtol=1e-6, atol=1e-6, what='pool')
+
+
+@pytest.mark.parametrize('C,mode', [(128, 'bilinear'), (2, 'bilinear'), (19, 'bilinear'), (32, 'nearest'), (3, 'nearest')])
+def test_resize_vector_and_scalar_paths(dev, C, mode):
+    x = _rand(1, C, 12, 20, seed=4)
+    ref = F.interpolate(x, size=(48, 80), mode=mode, align_corners=False) if mode == 'bilinear' else F.interpolate(x, size=(48, 80), mode=mode)
+    ws = nhwc.Workspace(dev)
+    out = nhwc.resize(nhwc.from_nchw(x.to(dev)), ws.fmap('r', 1, 48, 80, C), mode)
+    _cmp(out.to_nchw(), ref, rtol=1e-6, atol=1e-6, what='resize')
 
 
 # ------------------------------------------------------------------------------------------------ detection ops

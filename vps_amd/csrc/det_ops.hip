@@ -215,21 +215,34 @@ void bbox_overlaps_kernel(const float* __restrict__ a, int lda, int m, const flo
     out[idx] = overlap / (area1 + area2 - overlap);
 }
 
+// One wavefront per row: the row is read with one coalesced load per 64 columns, the exponentials are evaluated one per
+// lane, and the max / sum are then folded column by column in the original sequential order (values broadcast with
+// readlane), so the result is bitwise the one-thread-per-row loop it replaces without its chain of dependent loads.
 __global__ __launch_bounds__(256)
 void row_softmax_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int mode) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     const float* p = in + (size_t)r * cols;
     float mx = -INFINITY;
-    for (int c = 0; c < cols; ++c) mx = fmaxf(mx, p[c]);
+    for (int base = 0; base < cols; base += 64) {
+        const float v = base + lane < cols ? p[base + lane] : -INFINITY;
+        const int n = min(64, cols - base);
+        for (int c = 0; c < n; ++c) mx = fmaxf(mx, __shfl(v, c, 64));
+    }
     float s = 0.f;
-    for (int c = 0; c < cols; ++c) s += expf(p[c] - mx);
+    for (int base = 0; base < cols; base += 64) {
+        const float e = base + lane < cols ? expf(p[base + lane] - mx) : 0.f;
+        const int n = min(64, cols - base);
+        for (int c = 0; c < n; ++c) s += __shfl(e, c, 64);
+    }
     float* o = out + (size_t)r * cols;
-    if (mode == 0) {
-        for (int c = 0; c < cols; ++c) o[c] = expf(p[c] - mx) / s;
-    } else {
-        const float ls = logf(s);
-        for (int c = 0; c < cols; ++c) o[c] = p[c] - mx - ls;
+    const float ls = logf(s);
+    for (int base = 0; base < cols; base += 64) {
+        if (base + lane < cols) {
+            const float v = p[base + lane];
+            o[base + lane] = mode == 0 ? expf(v - mx) / s : v - mx - ls;
+        }
     }
 }
 
@@ -287,6 +300,6 @@ extern "C" int vps_bbox_overlaps(const float* a, int lda, int m, const float* b,
 extern "C" int vps_row_softmax(const float* in, float* out, int rows, int cols, int mode, void* stream) {
     if (!in || !out || rows < 0 || cols <= 0) return VPS_EARG(1);
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(row_softmax_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, in, out, rows, cols, mode);
+    hipLaunchKernelGGL(row_softmax_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, in, out, rows, cols, mode);
     return vps_launch_status();
 }

@@ -9,23 +9,30 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // F.interpolate bilinear (align_corners=False) / nearest, as ATen's upsample_*2d CPU kernels compute them.
 // ------------------------------------------------------------------------------------------------
+// V = 4: float4 over channels (C, leading dimensions and channel offsets multiples of 4), V = 1: any layout.
+template <int V> struct vecn { typedef float type; };
+template <> struct vecn<4> { typedef f32x4 type; };
+
+template <int V>
 __global__ __launch_bounds__(256)
 void resize_kernel(const float* __restrict__ in, int in_ld, int in_coff, int Hi, int Wi,
                    float* __restrict__ out, int out_ld, int out_coff, int Ho, int Wo,
                    int N, int C, int mode, float alpha, float sh, float sw) {
-    const long total = (long)N * Ho * Wo * C;
+    typedef typename vecn<V>::type vt;
+    const int cv = C / V;
+    const long total = (long)N * Ho * Wo * cv;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
-        const long pix = idx / C;
-        const int x = (int)(pix % Wo);
-        const int y = (int)((pix / Wo) % Ho);
-        const int n = (int)(pix / ((long)Wo * Ho));
+        const int c = (int)(idx % cv) * V;
+        const int pix = (int)(idx / cv);
+        const int x = pix % Wo;
+        const int yy = pix / Wo;
+        const int y = yy % Ho, n = yy / Ho;
         const float* ib = in + (size_t)n * Hi * Wi * in_ld + in_coff + c;
-        float v;
+        vt v;
         if (mode == 1) {
             const int ys = min((int)floorf((float)y * sh), Hi - 1);
             const int xs = min((int)floorf((float)x * sw), Wi - 1);
-            v = ib[((size_t)ys * Wi + xs) * in_ld];
+            v = *reinterpret_cast<const vt*>(ib + ((size_t)ys * Wi + xs) * in_ld);
         } else {
             float sy = sh * ((float)y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
             float sx = sw * ((float)x + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
@@ -33,41 +40,52 @@ void resize_kernel(const float* __restrict__ in, int in_ld, int in_coff, int Hi,
             const int yp = y0 < Hi - 1 ? 1 : 0, xp = x0 < Wi - 1 ? 1 : 0;
             const float ly = sy - (float)y0, lx = sx - (float)x0;
             const float hy = 1.f - ly, hx = 1.f - lx;
-            const float p00 = ib[((size_t)y0 * Wi + x0) * in_ld];
-            const float p01 = ib[((size_t)y0 * Wi + x0 + xp) * in_ld];
-            const float p10 = ib[((size_t)(y0 + yp) * Wi + x0) * in_ld];
-            const float p11 = ib[((size_t)(y0 + yp) * Wi + x0 + xp) * in_ld];
+            const vt p00 = *reinterpret_cast<const vt*>(ib + ((size_t)y0 * Wi + x0) * in_ld);
+            const vt p01 = *reinterpret_cast<const vt*>(ib + ((size_t)y0 * Wi + x0 + xp) * in_ld);
+            const vt p10 = *reinterpret_cast<const vt*>(ib + ((size_t)(y0 + yp) * Wi + x0) * in_ld);
+            const vt p11 = *reinterpret_cast<const vt*>(ib + ((size_t)(y0 + yp) * Wi + x0 + xp) * in_ld);
             v = hy * (hx * p00 + lx * p01) + ly * (hx * p10 + lx * p11);
         }
-        out[(size_t)pix * out_ld + out_coff + c] = v * alpha;
+        *reinterpret_cast<vt*>(out + (size_t)pix * out_ld + out_coff + c) = v * alpha;
     }
 }
 
-// 3x3 stride 2 pad 1 max / avg (count_include_pad) pooling
+// 3x3 stride 2 pad 1 max / avg (count_include_pad) pooling. All nine loads are issued unconditionally at clamped
+// coordinates (a duplicate never changes a max; the average masks them afterwards): no load waits behind a branch.
+template <int V>
 __global__ __launch_bounds__(256)
 void pool3x3s2_kernel(const float* __restrict__ in, int in_ld, int in_coff, int Hi, int Wi,
                       float* __restrict__ out, int out_ld, int out_coff, int Ho, int Wo, int N, int C, int mode) {
-    const long total = (long)N * Ho * Wo * C;
+    typedef typename vecn<V>::type vt;
+    const int cv = C / V;
+    const long total = (long)N * Ho * Wo * cv;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
-        const long pix = idx / C;
-        const int x = (int)(pix % Wo);
-        const int y = (int)((pix / Wo) % Ho);
-        const int n = (int)(pix / ((long)Wo * Ho));
+        const int c = (int)(idx % cv) * V;
+        const int pix = (int)(idx / cv);
+        const int x = pix % Wo;
+        const int yy0 = pix / Wo;
+        const int y = yy0 % Ho, n = yy0 / Ho;
         const float* ib = in + (size_t)n * Hi * Wi * in_ld + in_coff + c;
-        float m = -INFINITY, s = 0.f;
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int yy = 2 * y + dy;
-            if ((unsigned)yy >= (unsigned)Hi) continue;
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int xx = 2 * x + dx;
-                if ((unsigned)xx >= (unsigned)Wi) continue;
-                const float v = ib[((size_t)yy * Wi + xx) * in_ld];
-                m = fmaxf(m, v);
-                s += v;
-            }
+        vt t[9];
+        bool ok[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int yy = 2 * y + k / 3 - 1, xx = 2 * x + k % 3 - 1;
+            ok[k] = (unsigned)yy < (unsigned)Hi && (unsigned)xx < (unsigned)Wi;
+            const int yc = min(max(yy, 0), Hi - 1), xc = min(max(xx, 0), Wi - 1);
+            t[k] = *reinterpret_cast<const vt*>(ib + ((size_t)yc * Wi + xc) * in_ld);
         }
-        out[(size_t)pix * out_ld + out_coff + c] = mode == 0 ? m : s / 9.0f;
+        vt m = t[4], s = vt{}, zero = vt{};   // the centre tap is always inside
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {     // same visiting order as the reference loops (dy outer, dx inner)
+            if constexpr (V == 1) { m = fmaxf(m, t[k]); }
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], t[k][e]);
+            }
+            s += ok[k] ? t[k] : zero;
+        }
+        *reinterpret_cast<vt*>(out + (size_t)pix * out_ld + out_coff + c) = mode == 0 ? m : s / 9.0f;
     }
 }
 
@@ -193,7 +211,70 @@ void groupnorm_apply_kernel(const float* __restrict__ in, int in_ld, float* __re
         const float bi = -sc * (float)mean + beta[c];
         float v = in[(size_t)pix * in_ld + c] * sc + bi;
         if (relu) v = v > 0.f ? v : 0.f;
-        out[(size_t)pix * out_ld + c] = v;
+        out[(size_t)pix * out_ld + out_coff + c] = v;
+    }
+}
+
+// float4 variants (C, leading dimensions, offsets and channels-per-group multiples of 4: the layers of this path).
+// One thread owns 4 consecutive channels = a whole number of groups never splits inside a float4 when cpg % 4 == 0 or
+// cpg divides 4; the per-channel sums go through the same LDS table as the scalar kernel.
+__global__ __launch_bounds__(256)
+void groupnorm_stats4_kernel(const float* __restrict__ in, int in_ld, long npix, int C, int G, double* __restrict__ stats) {
+    __shared__ double ssum[1024], ssq[1024];     // [pixel slot][channel], 256 threads x 4 channels
+    const int t = threadIdx.x;
+    const int c4n = C >> 2;
+    const int c4 = t % c4n;
+    const int ppb = 256 / c4n;   // pixels handled per block iteration
+    const int sub = t / c4n;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    for (long p = (long)blockIdx.x * ppb + sub; p < npix; p += (long)gridDim.x * ppb) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in + (size_t)p * in_ld + 4 * c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[e] += (double)v[e]; q[e] += (double)v[e] * (double)v[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ssum[sub * C + 4 * c4 + e] = s[e]; ssq[sub * C + 4 * c4 + e] = q[e]; }
+    __syncthreads();
+    const int cpg = C / G;
+    if (t < G) {
+        double gs = 0.0, gq = 0.0;
+        for (int k = 0; k < ppb; ++k)
+            for (int j = 0; j < cpg; ++j) {
+                gs += ssum[k * C + t * cpg + j];
+                gq += ssq[k * C + t * cpg + j];
+            }
+        atomicAdd(&stats[2 * t], gs);
+        atomicAdd(&stats[2 * t + 1], gq);
+    }
+}
+
+__global__ __launch_bounds__(256)
+void groupnorm_apply4_kernel(const float* __restrict__ in, int in_ld, float* __restrict__ out, int out_ld, int out_coff, long npix,
+                             int C, int G, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                             int relu, const double* __restrict__ stats) {
+    const int c4n = C >> 2;
+    const long total = npix * c4n;
+    const int cpg = C / G;
+    const double cnt = (double)npix * cpg;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        const long pix = idx / c4n;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(in + (size_t)pix * in_ld + c);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int g = (c + e) / cpg;
+            const double mean = stats[2 * g] / cnt;
+            double var = stats[2 * g + 1] / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float sc = rstd * gamma[c + e];
+            const float bi = -sc * (float)mean + beta[c + e];
+            float v = x[e] * sc + bi;
+            if (relu) v = v > 0.f ? v : 0.f;
+            y[e] = v;
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)pix * out_ld + out_coff + c) = y;
     }
 }
 
@@ -246,8 +327,13 @@ extern "C" int vps_resize(const float* in, int in_ld, int in_coff, int Hi, int W
                           int Ho, int Wo, int N, int C, int mode, float alpha, void* stream) {
     if (!in || !out || N <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return VPS_EARG(1);
     const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
-    hipLaunchKernelGGL(resize_kernel, dim3(stream_grid((long)N * Ho * Wo * C, 256)), dim3(256), 0, (hipStream_t)stream,
-                       in, in_ld, in_coff, Hi, Wi, out, out_ld, out_coff, Ho, Wo, N, C, mode, alpha, sh, sw);
+    if ((long)N * Ho * Wo > 0x7fffffffL) return VPS_EARG(2);
+    if (!((C | in_ld | in_coff | out_ld | out_coff) & 3))
+        hipLaunchKernelGGL(resize_kernel<4>, dim3(stream_grid((long)N * Ho * Wo * (C >> 2), 256)), dim3(256), 0, (hipStream_t)stream,
+                           in, in_ld, in_coff, Hi, Wi, out, out_ld, out_coff, Ho, Wo, N, C, mode, alpha, sh, sw);
+    else
+        hipLaunchKernelGGL(resize_kernel<1>, dim3(stream_grid((long)N * Ho * Wo * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                           in, in_ld, in_coff, Hi, Wi, out, out_ld, out_coff, Ho, Wo, N, C, mode, alpha, sh, sw);
     return vps_launch_status();
 }
 
@@ -255,8 +341,13 @@ extern "C" int vps_pool3x3s2(const float* in, int in_ld, int in_coff, int Hi, in
                              int N, int C, int mode, void* stream) {
     if (!in || !out || N <= 0 || C <= 0 || Hi <= 0 || Wi <= 0) return VPS_EARG(1);
     const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(pool3x3s2_kernel, dim3(stream_grid((long)N * Ho * Wo * C, 256)), dim3(256), 0, (hipStream_t)stream,
-                       in, in_ld, in_coff, Hi, Wi, out, out_ld, out_coff, Ho, Wo, N, C, mode);
+    if ((long)N * Ho * Wo > 0x7fffffffL) return VPS_EARG(2);
+    if (!((C | in_ld | in_coff | out_ld | out_coff) & 3))
+        hipLaunchKernelGGL(pool3x3s2_kernel<4>, dim3(stream_grid((long)N * Ho * Wo * (C >> 2), 256)), dim3(256), 0, (hipStream_t)stream,
+                           in, in_ld, in_coff, Hi, Wi, out, out_ld, out_coff, Ho, Wo, N, C, mode);
+    else
+        hipLaunchKernelGGL(pool3x3s2_kernel<1>, dim3(stream_grid((long)N * Ho * Wo * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                           in, in_ld, in_coff, Hi, Wi, out, out_ld, out_coff, Ho, Wo, N, C, mode);
     return vps_launch_status();
 }
 
@@ -300,6 +391,14 @@ extern "C" int vps_groupnorm_relu(const float* in, int in_ld, float* out, int ou
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * G, s);
     if (e != hipSuccess) return -(int)e;
+    if (!((C | in_ld | out_ld | out_coff) & 3) && 1024 % C == 0) {
+        const int ppb4 = 1024 / C;
+        long g4 = (npix + ppb4 - 1) / ppb4; if (g4 > 1024) g4 = 1024;
+        hipLaunchKernelGGL(groupnorm_stats4_kernel, dim3((unsigned)g4), dim3(256), 0, s, in, in_ld, (long)npix, C, G, stats);
+        hipLaunchKernelGGL(groupnorm_apply4_kernel, dim3(stream_grid((long)npix * (C >> 2), 256)), dim3(256), 0, s, in, in_ld, out,
+                           out_ld, out_coff, (long)npix, C, G, gamma, beta, eps, relu, stats);
+        return vps_launch_status();
+    }
     const int ppb = 256 / C;
     long g = (npix + ppb - 1) / ppb; if (g > 1024) g = 1024;
     hipLaunchKernelGGL(groupnorm_stats_kernel, dim3((unsigned)g), dim3(256), 0, s, in, in_ld, (long)npix, C, G, stats);
