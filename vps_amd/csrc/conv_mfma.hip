@@ -89,37 +89,67 @@ __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&a
         const int tx = tile_m % tiles_x, tq = tile_m / tiles_x;
         t2_x0 = tx * 16; t2_y0 = (tq % tiles_y) * 8; t2_n = tq / tiles_y;
     }
+    // output / residual pixel index of accumulator row (a, r); rows past M are clamped to a valid row and not stored
+    auto row_pix = [&](const int a, const int r, size_t& opix, size_t& rpix) -> bool {
+        const int jl = wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + row_l;   // row of the block tile
+        const int m_raw = tile_m * BM + jl;
+        const int m = min(m_raw, M - 1);
+        if (simple_pix) {
+            opix = rpix = (size_t)m;
+        } else {
+            int qx, qy, n;
+            if constexpr (TILE2D) {
+                qx = t2_x0 + (jl & 15); qy = t2_y0 + (jl >> 4); n = t2_n;
+            } else {
+                qx = m % d.Qw;
+                const int tq = m / d.Qw;
+                qy = tq % d.Qh;
+                n = tq / d.Qh;
+            }
+            const int oy = qy * d.os_y + py, ox = qx * d.os_x + px;
+            opix = ((size_t)n * d.Ho + oy) * d.Wo + ox;
+            const int rs = d.res_shift;
+            rpix = ((size_t)n * (d.Ho >> rs) + (oy >> rs)) * (d.Wo >> rs) + (ox >> rs);
+        }
+        return m_raw < M;
+    };
+    // residual: all TM*16*TN values are requested (branch-free, clamped) before the first one is used. A load that sits
+    // behind `if (row valid) if (column valid)` gets an s_waitcnt vmcnt(0) of its own: 64 serial memory latencies per
+    // lane, which was most of the run time of the 1x1 bottleneck-expansion layers.
+    float rv[TM][16][TN];
+    if (d.res) {
+        int cco[TN];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) cco[b] = d.res_coff + min(tile_n * BN + wn * TN * 32 + b * 32 + col_l, d.cout - 1);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                size_t opix, rpix;
+                row_pix(a, r, opix, rpix);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) rv[a][r][b] = d.res[rpix * d.res_ld + cco[b]];
+            }
+    } else {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) rv[a][r][b] = 0.f;
+    }
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int jl = wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + row_l;   // row of the block tile
-            const int m = tile_m * BM + jl;
-            if (m >= M) continue;
             size_t opix, rpix;
-            if (simple_pix) {
-                opix = rpix = (size_t)m;
-            } else {
-                int qx, qy, n;
-                if constexpr (TILE2D) {
-                    qx = t2_x0 + (jl & 15); qy = t2_y0 + (jl >> 4); n = t2_n;
-                } else {
-                    qx = m % d.Qw;
-                    const int tq = m / d.Qw;
-                    qy = tq % d.Qh;
-                    n = tq / d.Qh;
-                }
-                const int oy = qy * d.os_y + py, ox = qx * d.os_x + px;
-                opix = ((size_t)n * d.Ho + oy) * d.Wo + ox;
-                const int rs = d.res_shift;
-                rpix = ((size_t)n * (d.Ho >> rs) + (oy >> rs)) * (d.Wo >> rs) + (ox >> rs);
-            }
+            if (!row_pix(a, r, opix, rpix)) continue;
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
                 if (!cok[b]) continue;
                 const int co = tile_n * BN + wn * TN * 32 + b * 32 + col_l;
                 float v = acc[a][b][r] * sc[b] + sh[b];
-                if (d.res) v += d.res[rpix * d.res_ld + d.res_coff + co];
+                if (d.res) v += rv[a][r][b];
                 d.out[opix * d.out_ld + d.out_coff + co] = vps_act(v, d.act, d.slope);
             }
         }
