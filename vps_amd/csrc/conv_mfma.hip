@@ -85,7 +85,7 @@ __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&a
     const bool simple_pix = !TILE2D && (d.nclass == 1 && d.os_y == 1 && d.os_x == 1 && d.res_shift == 0);
     int t2_n = 0, t2_y0 = 0, t2_x0 = 0;
     if constexpr (TILE2D) {
-        const int tiles_x = d.Qw >> 4, tiles_y = d.Qh >> 3;
+        const int tiles_x = (d.Qw + 15) >> 4, tiles_y = (d.Qh + 7) >> 3;
         const int tx = tile_m % tiles_x, tq = tile_m / tiles_x;
         t2_x0 = tx * 16; t2_y0 = (tq % tiles_y) * 8; t2_n = tq / tiles_y;
     }
@@ -94,12 +94,16 @@ __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&a
         const int jl = wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + row_l;   // row of the block tile
         const int m_raw = tile_m * BM + jl;
         const int m = min(m_raw, M - 1);
+        bool inside = m_raw < M;
         if (simple_pix) {
             opix = rpix = (size_t)m;
         } else {
             int qx, qy, n;
             if constexpr (TILE2D) {
+                // patches overhang the right / bottom edge when Qw % 16 or Qh % 8: those rows are computed and dropped
                 qx = t2_x0 + (jl & 15); qy = t2_y0 + (jl >> 4); n = t2_n;
+                inside = qx < d.Qw && qy < d.Qh;
+                qx = min(qx, d.Qw - 1); qy = min(qy, d.Qh - 1);
             } else {
                 qx = m % d.Qw;
                 const int tq = m / d.Qw;
@@ -111,7 +115,7 @@ __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&a
             const int rs = d.res_shift;
             rpix = ((size_t)n * (d.Ho >> rs) + (oy >> rs)) * (d.Wo >> rs) + (ox >> rs);
         }
-        return m_raw < M;
+        return inside;
     };
     // residual: all TM*16*TN values are requested (branch-free, clamped) before the first one is used. A load that sits
     // behind `if (row valid) if (column valid)` gets an s_waitcnt vmcnt(0) of its own: 64 serial memory latencies per
@@ -884,7 +888,7 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
 
     const int py = cls / d.os_x, px = cls - py * d.os_x;
     const int H = d.H, W = d.W, cin_pad = d.cin_pad;
-    const int tiles_x = d.Qw >> 4, tiles_y = d.Qh >> 3;
+    const int tiles_x = (d.Qw + 15) >> 4, tiles_y = (d.Qh + 7) >> 3;
     const int tx = tile_m % tiles_x, tq = tile_m / tiles_x;
     const int ty = tq % tiles_y, n = tq / tiles_y;
     const int iy_org = ty * 8 - d.pad_y[py], ix_org = tx * 16 - d.pad_x[px];   // input position of halo row 0, column 0
@@ -1270,8 +1274,12 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
     const long nblk = (long)tiles_m * tiles_n * d.nclass * d.ksplit;
     if (nblk <= 0 || nblk > 0x7fffffffL) return VPS_EARG(21);
     // stride-1 3x3 / 2x2-class layers on whole 8x16 output patches: halo-staged kernel
-    if (d.prec != VPS_PREC_F32 && !d.offset && d.stride == 1 && d.korder == 1 && d.ksplit == 1 && d.Qh % 8 == 0 && d.Qw % 16 == 0 &&
-        d.KH == d.KW && (d.KH == 3 || d.KH == 2)) {
+    // (patches may overhang the right / bottom edge; used when that wastes less than a third of the computed rows)
+    const long tiles2d = (long)d.N * ((d.Qh + 7) / 8) * ((d.Qw + 15) / 16);
+    if (d.prec != VPS_PREC_F32 && !d.offset && d.stride == 1 && d.korder == 1 && d.ksplit == 1 && d.KH == d.KW && (d.KH == 3 || d.KH == 2) &&
+        tiles2d * 128 * 2 <= (long)M * 3) {
+        const int tiles_m = (int)tiles2d;
+        const long nblk = (long)tiles_m * tiles_n * d.nclass;
 #define VPS_HALO_LAUNCH(NS, K)                                                                                                   \
     hipLaunchKernelGGL((conv_mfma_bf16h_kernel<TM, TN, WAVES_M, WAVES_N, NS, K, K>), dim3((unsigned)nblk), dim3(256), 0, s, d, tiles_m, \
                        tiles_n)
