@@ -56,13 +56,24 @@ __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&a
     const int col_l = lane & 31;
     const int row_l = 4 * (lane >> 5);
     if (d.ksplit > 1) {
-        float* __restrict__ ws = d.ws + ((size_t)(split * d.nclass + cls) * M) * d.cout_pad;
+        // partial sums [split][class][pixel][cout_pad]; pixel = linear (n, qy, qx) index whatever the tiling
+        const int Mpix = TILE2D ? d.N * d.Qh * d.Qw : M;
+        float* __restrict__ ws = d.ws + ((size_t)(split * d.nclass + cls) * Mpix) * d.cout_pad;
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = tile_m * BM + wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + row_l;
-                if (m < M) {
+                const int jl = wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+                int m = tile_m * BM + jl;
+                bool ok = m < M;
+                if constexpr (TILE2D) {
+                    const int tiles_x = (d.Qw + 15) >> 4, tiles_y = (d.Qh + 7) >> 3;
+                    const int tx = tile_m % tiles_x, tq = tile_m / tiles_x;
+                    const int qx = tx * 16 + (jl & 15), qy = (tq % tiles_y) * 8 + (jl >> 4), n = tq / tiles_y;
+                    ok = qx < d.Qw && qy < d.Qh;
+                    m = (n * d.Qh + qy) * d.Qw + qx;
+                }
+                if (ok) {
 #pragma unroll
                     for (int b = 0; b < TN; ++b) {
                         const int co = tile_n * BN + wn * TN * 32 + b * 32 + col_l;
@@ -867,7 +878,7 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
 // ================================================================================================
 template <int TM, int TN, int WAVES_M, int WAVES_N, int NS, int KH, int KW>
 __global__ __launch_bounds__(256, 2)
-void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int tiles_n) {
+void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int tiles_n, const int chunks_per_split) {
     constexpr int BN = WAVES_N * TN * 32;
     static_assert(WAVES_M * TM * 32 == BM, "block M tile must be 128");
     static_assert(WAVES_M * WAVES_N == 4, "4 wavefronts per block");
@@ -883,8 +894,9 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
     const int t = threadIdx.x;
     int swz = xcd_swizzle(blockIdx.x, gridDim.x);
     const int tile_n = swz % tiles_n; swz /= tiles_n;
-    const int tile_m = swz % tiles_m;
-    const int cls = swz / tiles_m;
+    const int tile_m = swz % tiles_m; swz /= tiles_m;
+    const int cls = swz % d.nclass;
+    const int split = swz / d.nclass;          // split-K over whole 32-channel chunks
 
     const int py = cls / d.os_x, px = cls - py * d.os_x;
     const int H = d.H, W = d.W, cin_pad = d.cin_pad;
@@ -895,7 +907,8 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
 
     const int k4 = t & 7;      // 4-channel group staged by this thread (8 lanes = one 128-byte line)
     const int r0 = t >> 3;     // halo rows r0 + 32 i
-    const int nchunks = d.kpad / (BK * NTAP);
+    const int chunk0 = split * chunks_per_split;
+    const int nchunks = min(chunks_per_split, d.kpad / (BK * NTAP) - chunk0);
     const int nsteps = nchunks * NTAP;
 
     const int lane = t & 63;
@@ -904,11 +917,11 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
     const int nbt = d.cout_pad >> 5, kst = d.kpad >> 4;
     const size_t wplane = (size_t)d.nclass * nbt * kst * 512;
     const __bf16* __restrict__ wfrag = reinterpret_cast<const __bf16*>(d.w_split) +
-        ((size_t)(cls * nbt + tile_n * (BN / 32) + wn * TN) * kst) * 512 + lane * 8;
+        ((size_t)(cls * nbt + tile_n * (BN / 32) + wn * TN) * kst + 2 * (size_t)chunk0 * NTAP) * 512 + lane * 8;
 
     f32x4 areg[NLD];
     unsigned aok = 0;
-    int achunk = 0;            // next chunk to load
+    int achunk = chunk0;       // next chunk to load
     bf16x8 bnext[2][NS][TN];
 
     auto load_A = [&]() {
@@ -1042,7 +1055,7 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
         }
         __syncthreads();
     }
-    conv_epilogue<TM, TN, BN, true>(d, acc, tiles_m * BM, tile_m, tile_n, cls, 0, py, px, wm, wn, lane);
+    conv_epilogue<TM, TN, BN, true>(d, acc, tiles_m * BM, tile_m, tile_n, cls, split, py, px, wm, wn, lane);
 }
 
 // ================================================================================================
@@ -1276,18 +1289,21 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
     // stride-1 3x3 / 2x2-class layers on whole 8x16 output patches: halo-staged kernel
     // (patches may overhang the right / bottom edge; used when that wastes less than a third of the computed rows)
     const long tiles2d = (long)d.N * ((d.Qh + 7) / 8) * ((d.Qw + 15) / 16);
-    if (d.prec != VPS_PREC_F32 && !d.offset && d.stride == 1 && d.korder == 1 && d.ksplit == 1 && d.KH == d.KW && (d.KH == 3 || d.KH == 2) &&
-        tiles2d * 128 * 2 <= (long)M * 3) {
-        const int tiles_m = (int)tiles2d;
-        const long nblk = (long)tiles_m * tiles_n * d.nclass;
-#define VPS_HALO_LAUNCH(NS, K)                                                                                                   \
-    hipLaunchKernelGGL((conv_mfma_bf16h_kernel<TM, TN, WAVES_M, WAVES_N, NS, K, K>), dim3((unsigned)nblk), dim3(256), 0, s, d, tiles_m, \
-                       tiles_n)
+    // split-K there is over whole 32-channel chunks: the k-steps of a split must be a whole number of chunks
+    const int ntap = d.KH * d.KW;
+    const bool halo = d.prec != VPS_PREC_F32 && !d.offset && d.stride == 1 && d.korder == 1 && d.KH == d.KW && (d.KH == 3 || d.KH == 2) &&
+                      tiles2d * 128 * 2 <= (long)M * 3 && (d.ksplit == 1 || (ksteps % d.ksplit == 0 && per_split % ntap == 0));
+    if (halo) {
+        const int tiles_m2 = (int)tiles2d;
+        const long nblk2 = (long)tiles_m2 * tiles_n * d.nclass * d.ksplit;
+        if (nblk2 > 0x7fffffffL) return VPS_EARG(21);
+#define VPS_HALO_LAUNCH(NS, K)                                                                                                    \
+    hipLaunchKernelGGL((conv_mfma_bf16h_kernel<TM, TN, WAVES_M, WAVES_N, NS, K, K>), dim3((unsigned)nblk2), dim3(256), 0, s, d, tiles_m2, \
+                       tiles_n, per_split / ntap)
         if (d.prec == VPS_PREC_BF16X3) { if (d.KH == 3) VPS_HALO_LAUNCH(2, 3); else VPS_HALO_LAUNCH(2, 2); }
         else { if (d.KH == 3) VPS_HALO_LAUNCH(3, 3); else VPS_HALO_LAUNCH(3, 2); }
 #undef VPS_HALO_LAUNCH
-        return vps_launch_status();
-    }
+    } else {
 #define VPS_CONV_LAUNCH(KERNEL)                                                                              \
     hipLaunchKernelGGL((KERNEL), dim3((unsigned)nblk), dim3(256), 0, s, d, M, tiles_m, tiles_n, per_split)
     if (d.prec == VPS_PREC_F32) {
@@ -1301,6 +1317,7 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
         else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, 3>));
     }
 #undef VPS_CONV_LAUNCH
+    }
     int st = vps_launch_status();
     if (st) return st;
     if (d.ksplit > 1) {

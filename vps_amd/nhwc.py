@@ -276,8 +276,16 @@ class PackedConv:
         ksplit = 1
         if tiles < 256 and ksteps >= 8 and not getattr(self, 'small', False):
             ksplit = max(1, min((512 + tiles - 1) // tiles, ksteps // 4, 32))
-            per = (ksteps + ksplit - 1) // ksplit
-            ksplit = (ksteps + per - 1) // per
+            ntap = self.KH * self.KW
+            halo = (self.prec != hip.PREC_F32 and not self.deform and self.stride == 1 and self.korder == 1 and self.KH == self.KW
+                    and self.KH in (2, 3) and x.N * ((d.Qh + 7) // 8) * ((d.Qw + 15) // 16) * 256 <= 3 * M)
+            if halo:
+                # the halo-staged kernel splits over whole 32-channel chunks: the largest divisor of the chunk count <= target
+                nch = ksteps // ntap
+                ksplit = max(k for k in range(1, ksplit + 1) if nch % k == 0)
+            else:
+                per = (ksteps + ksplit - 1) // ksplit
+                ksplit = (ksteps + per - 1) // per
         d.ksplit = ksplit
         if ksplit > 1:
             need = ksplit * d.nclass * M * self.cout_pad
