@@ -183,7 +183,7 @@ def main():
         nprod = {'f32': 1, 'bf16x3': 3, 'bf16x6': 6}[args.prec]
         peak = PEAK_BF16_MFMA_TFLOPS if args.prec == 'bf16x3' else PEAK_FP32_MFMA_TFLOPS
         pipe_peak = PEAK_FP32_MFMA_TFLOPS if args.prec == 'f32' else PEAK_BF16_MFMA_TFLOPS
-        roof = dict(bound='mfma', kernel='conv_mfma_f32_kernel' if args.prec == 'f32' else 'conv_mfma_bf16p_kernel',
+        roof = dict(bound='mfma', kernel='conv_mfma_f32_kernel' if args.prec == 'f32' else 'conv_mfma_bf16{h,p,s}_kernel (vps_conv2d family)',
                     achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
                     mfma_products_per_fp32_product=nprod, matrix_pipe_executed_tflops=round(ach * nprod, 1),
                     matrix_pipe_peak=pipe_peak, matrix_pipe_frac=round(ach * nprod / pipe_peak, 4),
