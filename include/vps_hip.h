@@ -263,6 +263,22 @@ int vps_panoptic_combine(const float* fcn_score, int score_ld, int Hs, int Ws, i
                          const vps_pan_inst* inst, int k, const float* mask_logits, int S,
                          uint8_t* pan, uint8_t* sem, int H, int W, void* stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Panoptic post-processing. Replaces the per-frame body of
+ * tools/dataset/cityscapes_vps.py:183-224 (CityscapesVPS.get_unified_pan_result): ~250 boolean masks + np.unique over
+ * 2 M pixels per frame on the host become three passes over the uint8 maps on the device. All integer, bit-exact.
+ *   pan, seg  uint8 [npix] (pan ids <= id_last_stuff are stuff classes, id_last_stuff+1+j = j-th instance, 255 = void)
+ *   hist      int32 [256][256] (instance rows only), pan_count int32 [256]; both zeroed by vps_unify_hist
+ *   cls_ind   int32 [k] (panoptic_cls_inds), obj_id int32 [nobj] or NULL (de-duplicated object ids, host side)
+ *   tables    uint8 [3][256]: output values of the three channels per pan id
+ *   status    int32 [1]: 0 ok, 1 = instance id without cls_ind entry, 2 = without obj_id entry (reference: IndexError)
+ *   out       uint8 [npix][3] = (pan_seg, pan_ins, pan_obj) */
+int vps_unify_hist(const uint8_t* pan, const uint8_t* seg, int64_t npix, int id_last_stuff, int32_t* hist, int32_t* pan_count,
+                   void* stream);
+int vps_unify_tables(const int32_t* hist, const int32_t* pan_count, const int32_t* cls_ind, int k, const int32_t* obj_id, int nobj,
+                     int id_last_stuff, int64_t stuff_area_limit, uint8_t* tables, int32_t* status, void* stream);
+int vps_unify_write(const uint8_t* pan, int64_t npix, const uint8_t* tables, uint8_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,96 @@
+"""Panoptic post-processing (get_unified_pan_result).
+CPU: the oracle restatement against golden outputs of the REAL reference function (tests/golden/make_unify_golden.py).
+GPU: the device path (vps_unify_* through the C-ABI) against the oracle and the golden outputs, bit for bit."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import postprocess as opp
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'unify_cases.npz')
+
+
+def _clips():
+    z = np.load(GOLD)
+    for ci in range(int(z['nclips'])):
+        n = int(z['clip%d_n' % ci]); with_obj = bool(z['clip%d_with_obj' % ci])
+        segs = [z['clip%d_f%d_seg' % (ci, f)] for f in range(n)]
+        pans = [z['clip%d_f%d_pan' % (ci, f)] for f in range(n)]
+        clss = [z['clip%d_f%d_cls' % (ci, f)] for f in range(n)]
+        objs = [z['clip%d_f%d_obj' % (ci, f)] for f in range(n)] if with_obj else None
+        outs = [z['clip%d_f%d_out' % (ci, f)] for f in range(n)]
+        yield ci, segs, pans, clss, objs, int(z['clip%d_limit' % ci]), ['f%d' % f for f in range(n)], outs
+
+
+def test_oracle_matches_reference_function_bit_for_bit():
+    ncase = 0
+    for ci, segs, pans, clss, objs, limit, names, outs in _clips():
+        res = opp.get_unified_pan_result(segs, pans, clss, objs, limit, names)
+        for n, o in zip(names, outs):
+            assert res[n].dtype == np.uint8 and res[n].shape == o.shape
+            assert np.array_equal(res[n], o), 'clip %d frame %s differs in %d pixels' % (ci, n, int((res[n] != o).any(-1).sum()))
+            ncase += 1
+    assert ncase >= 10
+
+
+def test_oracle_dedup_keeps_last_occurrence_and_counts_across_frames():
+    ids, mx = opp.dedup_obj_ids(np.array([5, 7, 5, 9, 5, 7]), 100)
+    assert ids.tolist() == [101, 102, 100, 9, 5, 7] and mx == 103
+
+
+def test_host_dedup_equals_the_reference_statements():
+    """vps_amd's own list-based de-duplication against the restated numpy statements of the reference, random id lists"""
+    from vps_amd import postprocess as pp
+    rng = np.random.default_rng(5)
+    mx_a = mx_b = 100
+    for _ in range(300):
+        ids = rng.integers(0, 12, size=int(rng.integers(0, 15))).astype(np.int64)
+        a, mx_a = pp.dedup_obj_ids(ids, mx_a)
+        b, mx_b = opp.dedup_obj_ids(ids, mx_b)
+        assert a.tolist() == list(b) and mx_a == mx_b
+
+
+@pytest.mark.gpu
+def test_device_unify_matches_reference_golden(dev):
+    from vps_amd import postprocess as pp
+    for ci, segs, pans, clss, objs, limit, names, outs in _clips():
+        u = pp.PanopticUnifier(dev)
+        res = u.get_unified_pan_result([torch.from_numpy(s).to(dev) for s in segs], [torch.from_numpy(p).to(dev) for p in pans],
+                                       clss, objs, limit, names)
+        for n, o in zip(names, outs):
+            assert res[n].dtype == np.uint8 and np.array_equal(res[n], o), 'clip %d frame %s' % (ci, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W,k,seed', [(1024, 2048, 100, 0), (1024, 2048, 3, 1), (37, 53, 17, 2), (8, 8, 0, 3)])
+def test_device_unify_matches_oracle_random(dev, H, W, k, seed):
+    """full-size and ragged maps: random instance rectangles over random stuff, repeated object ids, void pixels"""
+    from vps_amd import postprocess as pp
+    rng = np.random.default_rng(seed)
+    seg = rng.integers(0, 19, size=(H, W)).astype(np.uint8)
+    seg[: H // 2] = (np.arange(W) * 11 // max(W, 1)).astype(np.uint8)[None, :]      # large coherent stuff areas
+    pan = np.minimum(seg, 10).astype(np.uint8)
+    cls_ind = rng.integers(0, 8, size=k).astype(np.int64)
+    for i in range(k):
+        h, w = int(rng.integers(2, max(3, H // 4))), int(rng.integers(2, max(3, W // 4)))
+        y, x = int(rng.integers(0, max(1, H - h))), int(rng.integers(0, max(1, W - w)))
+        pan[y:y + h, x:x + w] = 11 + i
+        if i % 3 == 0:
+            seg[y:y + h, x:x + w] = 11 + cls_ind[i]
+        elif i % 3 == 1:
+            seg[y:y + h, x:x + w] = rng.integers(0, 11)
+    if H > 8:
+        pan[-2:, -3:] = 255
+    obj = rng.integers(0, 40, size=k).astype(np.int64) if k else np.zeros(0, np.int64)
+    ref = opp.get_unified_pan_result([seg, seg], [pan, pan], [cls_ind, cls_ind], [obj, obj], 4 * 64 * 64, ['a', 'b'])
+    u = pp.PanopticUnifier(dev)
+    sd, pd = torch.from_numpy(seg).to(dev), torch.from_numpy(pan).to(dev)
+    res = u.get_unified_pan_result([sd, sd], [pd, pd], [cls_ind, cls_ind], [obj, obj], 4 * 64 * 64, ['a', 'b'])
+    for n in ('a', 'b'):
+        assert np.array_equal(res[n], ref[n]), n
+    # without object ids
+    ref2 = opp.get_unified_pan_result([seg], [pan], [cls_ind], None, 500, ['a'])
+    res2 = u.get_unified_pan_result([sd], [pd], [cls_ind], None, 500, ['a'])
+    assert np.array_equal(res2['a'], ref2['a'])

@@ -1,0 +1,91 @@
+"""Device-side panoptic post-processing behind the reference's own method signature.
+
+`PanopticUnifier.get_unified_pan_result(segs, pans, cls_inds, obj_ids, stuff_area_limit, names)` takes what
+`tools/test_vpq.py:51-63` collects per frame (`fcn_outputs`, `panoptic_outputs`, `panoptic_cls_inds`,
+`panoptic_det_obj_ids`) and returns what `tools/dataset/cityscapes_vps.py:162-226` returns — `{name: uint8 [H,W,3]}` with
+channels (pan_seg, pan_ins, pan_obj) — but the maps stay on the GPU until the 3-channel result is ready: one histogram pass,
+the reference's per-instance decisions on one wavefront, one table-lookup pass (`vps_unify_*`, `csrc/post_ops.hip`).
+The only host work is the object-id de-duplication (`:170-181`, <= 100 integers, and stateful across frames).
+No CPU path: maps must be (or are uploaded to) device tensors and the HIP library must load."""
+from collections import Counter
+
+import numpy as np
+import torch
+
+from . import hip
+
+
+def dedup_obj_ids(obj_id, max_oid):
+    """cityscapes_vps.py:170-181: of every repeated object id, the LAST occurrence keeps it and the others get fresh ids
+    max_oid, max_oid+1, ... handed out from the end of the list backwards; repeated values are treated in ascending order.
+    Returns (ids, max_oid)."""
+    orig = [int(v) for v in obj_id]
+    work = orig[::-1]                                    # the reference edits a reversed copy
+    counts = Counter(orig)
+    for red in sorted(v for v, c in counts.items() if c > 1):
+        fresh = [red] + [max_oid + i for i in range(counts[red] - 1)]
+        max_oid += counts[red] - 1
+        where = [i for i, v in enumerate(work) if v == red]
+        if len(where) != len(fresh):                     # a fresh id collided with an existing one: numpy raises here too
+            raise ValueError('NumPy boolean array indexing assignment cannot assign %d input values to the %d output values '
+                             'where the mask is true' % (len(fresh), len(where)))
+        for i, v in zip(where, fresh):
+            work[i] = v
+    return np.asarray(work[::-1], dtype=np.int64), max_oid
+
+
+class PanopticUnifier:
+    def __init__(self, device='cuda', num_seg_classes=19, num_classes=9):
+        self.device = torch.device(device)
+        self.id_last_stuff = num_seg_classes - num_classes          # config.dataset.* (cityscapes_vps.py:186)
+        self.hist = torch.empty(256 * 256, dtype=torch.int32, device=self.device)
+        self.pan_count = torch.empty(256, dtype=torch.int32, device=self.device)
+        self.tables = torch.empty(3 * 256, dtype=torch.uint8, device=self.device)
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def _map(self, m):
+        t = torch.from_numpy(np.ascontiguousarray(m)) if isinstance(m, np.ndarray) else m
+        t = t.to(self.device)
+        if t.dtype != torch.uint8:
+            t = t.to(torch.uint8)                        # test_vpq.py:53,56 `.astype(np.uint8)`
+        return t.contiguous()
+
+    def unify_frame(self, seg, pan, cls_ind, obj_id, stuff_area_limit=4 * 64 * 64):
+        """one frame, object ids already de-duplicated. Returns a device uint8 tensor [H,W,3]."""
+        lib = hip.load()
+        seg, pan = self._map(seg), self._map(pan)
+        assert seg.shape == pan.shape and pan.dim() == 2
+        npix = pan.numel()
+        cls_t = torch.as_tensor(np.asarray(cls_ind.cpu() if torch.is_tensor(cls_ind) else cls_ind), dtype=torch.int32).to(self.device)
+        obj_t = None
+        if obj_id is not None:
+            obj_t = torch.as_tensor(np.asarray(obj_id), dtype=torch.int32).to(self.device)
+        out = torch.empty(pan.shape[0], pan.shape[1], 3, dtype=torch.uint8, device=self.device)
+        s = hip.stream_ptr()
+        hip.check(lib.vps_unify_hist(hip.ptr(pan), hip.ptr(seg), npix, self.id_last_stuff, hip.ptr(self.hist), hip.ptr(self.pan_count), s),
+                  'vps_unify_hist')
+        hip.check(lib.vps_unify_tables(hip.ptr(self.hist), hip.ptr(self.pan_count), hip.ptr(cls_t) if cls_t.numel() else None,
+                                       cls_t.numel(), hip.ptr(obj_t) if (obj_t is not None and obj_t.numel()) else None,
+                                       0 if obj_t is None else obj_t.numel(), self.id_last_stuff, int(stuff_area_limit),
+                                       hip.ptr(self.tables), hip.ptr(self.status), s), 'vps_unify_tables')
+        hip.check(lib.vps_unify_write(hip.ptr(pan), npix, hip.ptr(self.tables), hip.ptr(out), s), 'vps_unify_write')
+        self._keep = (seg, pan, cls_t, obj_t)            # alive until the stream has consumed them
+        return out
+
+    def get_unified_pan_result(self, segs, pans, cls_inds, obj_ids=None, stuff_area_limit=4 * 64 * 64, names=None):
+        if obj_ids is None:
+            obj_ids = [None for _ in range(len(cls_inds))]
+        results, outs = {}, []
+        max_oid = 100
+        for seg, pan, cls_ind, obj_id, name in zip(segs, pans, cls_inds, obj_ids, names):
+            if obj_id is not None:
+                obj_id = obj_id.cpu().numpy() if torch.is_tensor(obj_id) else np.asarray(obj_id)
+                obj_id, max_oid = dedup_obj_ids(obj_id, max_oid)
+            out = self.unify_frame(seg, pan, cls_ind, obj_id, stuff_area_limit)
+            st = int(self.status.item())                 # also orders the reuse of hist / tables by the next frame
+            if st:
+                raise IndexError('instance id without %s entry (cityscapes_vps.py:%s)' % (('cls_ind', '197') if st == 1 else ('obj_id', '201')))
+            outs.append((name, out))
+        for name, out in outs:
+            results[name] = out.cpu().numpy()
+        return results
