@@ -279,6 +279,15 @@ int vps_unify_tables(const int32_t* hist, const int32_t* pan_count, const int32_
                      int id_last_stuff, int64_t stuff_area_limit, uint8_t* tables, int32_t* status, void* stream);
 int vps_unify_write(const uint8_t* pan, int64_t npix, const uint8_t* tables, uint8_t* out, void* stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Input preparation: Normalize -> Pad(size_divisor) -> ImageToTensor of the test pipeline in one pass.
+ * Replaces mmdet/datasets/pipelines/transforms.py:258-269, :310-318 and formating.py:52-67 (mmcv 0.2.14 imnormalize,
+ * impad_to_multiple) for a decoded uint8 [H][W][3] image already on the device.
+ *   mean, std  HOST pointers to 3 floats (channel order of the OUTPUT, i.e. RGB when to_rgb)
+ *   out        fp32 [3][Hp][Wp], (c - mean) / std in fp32, bottom/right padding = pad_val. Bit-exact with NumPy. */
+int vps_image_prep(const uint8_t* img, int H, int W, int Hp, int Wp, const float* mean, const float* std, int to_rgb,
+                   float pad_val, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

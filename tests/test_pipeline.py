@@ -1,0 +1,50 @@
+"""Input preparation on the device against the NumPy restatement of Normalize -> Pad -> ImageToTensor."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pipeline as opl
+
+NORM = dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True)     # configs/cityscapes/fusetrack.py:153-154
+
+
+def test_oracle_normalize_pad_shapes_and_values():
+    img = np.arange(5 * 7 * 3, dtype=np.uint8).reshape(5, 7, 3)
+    x = opl.prepare(img, **NORM, size_divisor=4)
+    assert x.shape == (3, 8, 8) and x.dtype == np.float32
+    assert x[0, 0, 0] == np.float32((np.float32(2) - np.float32(123.675)) / np.float32(58.395))    # R = BGR channel 2
+    assert float(np.abs(x[:, 5:, :]).max()) == 0.0 and float(np.abs(x[:, :, 7:]).max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W', [(1024, 2048), (37, 53), (64, 96)])
+@pytest.mark.parametrize('to_rgb', [True, False])
+def test_device_image_prep_is_bit_exact(dev, H, W, to_rgb):
+    from vps_amd import pipeline as pl
+    rng = np.random.default_rng(H + W)
+    img = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    cfg = dict(NORM); cfg['to_rgb'] = to_rgb
+    prep = pl.DeviceImagePrep(**cfg, size_divisor=32, img_scale=(max(H, W), min(H, W)), device=dev)
+    out, img_shape, pad_shape, sf = prep.prep(img)
+    ref = opl.prepare(img, **cfg, size_divisor=32)
+    assert sf == 1.0 and img_shape == (H, W, 3) and pad_shape == (ref.shape[1], ref.shape[2], 3)
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+@pytest.mark.gpu
+def test_results_dict_and_pair_feeder(dev):
+    from vps_amd import pipeline as pl
+    rng = np.random.default_rng(1)
+    f0, f1 = (rng.integers(0, 256, size=(64, 128, 3), dtype=np.uint8) for _ in range(2))
+    prep = pl.DeviceImagePrep(**NORM, img_scale=(128, 64), device=dev)
+    res = prep(dict(img=f1.copy(), ref_img=f0.copy()))
+    assert res['pad_shape'] == (64, 128, 3) and res['pad_size_divisor'] == 32 and res['img_norm_cfg']['to_rgb']
+    assert np.array_equal(res['ref_img'].cpu().numpy(), opl.prepare(f0, **NORM))
+    feed = pl.PairFeeder(prep)
+    a, a_ref = feed(f0)
+    b, b_ref = feed(f1)
+    assert a.data_ptr() == a_ref.data_ptr()                     # the first frame is its own reference
+    assert b_ref.data_ptr() == a.data_ptr()                     # frame t's ref_img is frame t-1's tensor, prepared once
+    assert np.array_equal(b[0].cpu().numpy(), opl.prepare(f1, **NORM))
+    with pytest.raises(NotImplementedError):
+        pl.DeviceImagePrep(**NORM, img_scale=(2048, 1024), device=dev).prep(f0)     # a non-identity rescale is not on this path

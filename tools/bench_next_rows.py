@@ -1,5 +1,6 @@
-"""Throughput of the device-side panoptic post-processing at 1024x2048, k = 100 instances, next to
-the NumPy restatement of the reference function on the host (GPU box only). Prints one JSON line."""
+"""Throughput of the two widened rows of SURVEY §8(f) at 1024x2048 (GPU box only), one JSON line each:
+row 2, device-side panoptic post-processing (k = 100 instances), and row 1, device-side Normalize -> Pad -> ImageToTensor,
+each next to the NumPy restatement of the reference code on the host."""
 import json
 import os
 import sys
@@ -9,8 +10,39 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
+from oracle import pipeline as opl
 from oracle import postprocess as opp
+from vps_amd import pipeline as pl
 from vps_amd import postprocess as pp
+
+
+def bench_prep():
+    H, W = 1024, 2048
+    norm = dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True)
+    img = np.random.default_rng(0).integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    dev = torch.device('cuda:0')
+    prep = pl.DeviceImagePrep(**norm, device=dev)
+    imgd = torch.from_numpy(img).to(dev)
+    out = prep.prep(imgd)[0]
+    assert np.array_equal(out.cpu().numpy(), opl.prepare(img, **norm))
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    reps = 50
+    e0.record()
+    for _ in range(reps):
+        prep.prep(imgd)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    t0 = time.perf_counter()
+    for _ in range(3):
+        opl.prepare(img, **norm)
+    cpu_ms = (time.perf_counter() - t0) / 3 * 1e3
+    abytes = H * W * 3 * (1 + 4)
+    print(json.dumps({
+        'metric': 'images/sec Normalize+Pad+ImageToTensor 1024x2048', 'value': round(1e3 / ms, 1), 'unit': 'images/s',
+        'ms_per_image': round(ms, 4), 'dtype': 'u8 -> f32', 'data': 'synthetic', 'config': {'workload': 'decoded uint8 BGR 1024x2048 image resident in HBM'},
+        'roofline': {'bound': 'hbm', 'achieved': round(abytes / ms / 1e6, 2), 'peak': 8000.0, 'unit': 'GB/s',
+                     'frac': round(abytes / ms / 1e6 / 8000.0, 4), 'traffic': None, 'algorithmic_bytes': abytes},
+        'cpu_baseline': {'value': round(1e3 / cpu_ms, 2), 'unit': 'images/s', 'cores': 1, 'kind': 'port', 'sample': '3 images, NumPy restatement'}}))
 
 
 def main():
@@ -58,3 +90,4 @@ def main():
 
 if __name__ == '__main__':
     main()
+    bench_prep()

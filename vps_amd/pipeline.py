@@ -1,0 +1,90 @@
+"""Device-side tail of the reference's test pipeline.
+
+`configs/cityscapes/fusetrack.py:176-191` runs, per frame and per image of the (img, ref_img) pair, on 2 CPU workers:
+LoadRefImageFromFile -> Resize(keep_ratio, (2048,1024)) -> RandomFlip(off) -> Normalize -> Pad(32) -> ImageToTensor -> Collect,
+then ships two fp32 tensors (2 x 25 MB at 1024x2048) to the GPU. Here the decoded uint8 image is uploaded as it is (6 MB)
+and `Normalize -> Pad -> ImageToTensor` is one kernel (`vps_image_prep`); `PairFeeder` keeps the previous frame's tensor on
+the device, because frame t's `ref_img` IS frame t-1's `img` (`tools/dataset/cityscapes_vps.py:140`: the first frame of a
+video is its own reference) — the reference decodes and normalises every image twice.
+
+Resize: at the dataset's native 1024x2048 the keep-ratio rescale to (2048, 1024) has scale factor 1.0 and copies the image;
+any other size needs cv2's fixed-point bilinear resize, which is not reproduced here -> NotImplementedError (row 1 remainder).
+No CPU path: the HIP library must load."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import hip
+
+
+class DeviceImagePrep:
+    """Normalize(mean, std, to_rgb) + Pad(size_divisor, pad_val) + ImageToTensor, same constructor keywords as the reference
+    transforms (`transforms.py:228-236`, `:300-303`). __call__(results) mirrors their effect on the `results` dict."""
+
+    def __init__(self, mean, std, to_rgb=True, size_divisor=32, pad_val=0, img_scale=(2048, 1024), keep_ratio=True, device='cuda'):
+        self.mean = np.array(mean, dtype=np.float32)
+        self.std = np.array(std, dtype=np.float32)
+        self.to_rgb = to_rgb
+        self.size_divisor = size_divisor
+        self.pad_val = pad_val
+        self.img_scale = img_scale
+        self.keep_ratio = keep_ratio
+        self.device = torch.device(device)
+        self._mean_c = (ctypes.c_float * 3)(*[float(v) for v in self.mean])
+        self._std_c = (ctypes.c_float * 3)(*[float(v) for v in self.std])
+
+    def scale_factor(self, h, w):
+        """mmcv 0.2.14 imrescale: min(long_edge / max(h, w), short_edge / min(h, w)) for a (long, short) scale tuple."""
+        max_long, max_short = max(self.img_scale), min(self.img_scale)
+        return min(max_long / max(h, w), max_short / min(h, w))
+
+    def prep(self, img):
+        """uint8 [H,W,3] (numpy as cv2.imread returns it, or a device tensor) -> device fp32 [3,Hp,Wp]"""
+        t = torch.from_numpy(np.ascontiguousarray(img)) if isinstance(img, np.ndarray) else img
+        assert t.dtype == torch.uint8 and t.dim() == 3 and t.shape[2] == 3, 'decoded uint8 HWC image expected'
+        H, W = int(t.shape[0]), int(t.shape[1])
+        sf = self.scale_factor(H, W)
+        if int(W * sf + 0.5) != W or int(H * sf + 0.5) != H:
+            raise NotImplementedError('Resize to %s changes the size of a %dx%d image; only the identity rescale of the native '
+                                      'resolution is on the device path' % (self.img_scale, H, W))
+        t = t.to(self.device).contiguous()
+        d = self.size_divisor
+        Hp, Wp = (H + d - 1) // d * d, (W + d - 1) // d * d
+        out = torch.empty(3, Hp, Wp, dtype=torch.float32, device=self.device)
+        hip.check(hip.load().vps_image_prep(hip.ptr(t), H, W, Hp, Wp, self._mean_c, self._std_c, 1 if self.to_rgb else 0,
+                                            float(self.pad_val), hip.ptr(out), hip.stream_ptr()), 'vps_image_prep')
+        self._keep = t
+        return out, (H, W, 3), (Hp, Wp, 3), sf
+
+    def __call__(self, results):
+        els = ['ref_img', 'img'] if 'ref_img' in results else ['img']          # transforms.py:108, :261
+        for el in els:
+            out, img_shape, pad_shape, sf = self.prep(results[el])
+            results[el] = out
+        results['img_shape'] = img_shape                                         # transforms.py:118-121
+        results['pad_shape'] = pad_shape                                         # :270
+        results['scale_factor'] = sf
+        results['keep_ratio'] = self.keep_ratio
+        results['pad_fixed_size'] = None
+        results['pad_size_divisor'] = self.size_divisor
+        results['img_norm_cfg'] = dict(mean=self.mean, std=self.std, to_rgb=self.to_rgb)   # :316-317
+        return results
+
+
+class PairFeeder:
+    """Feeds (img, ref_img) pairs of one video in frame order, preparing every decoded image once: the reference of frame t
+    is the prepared tensor of frame t-1, the first frame is its own reference (cityscapes_vps.py:140)."""
+
+    def __init__(self, prep):
+        self.prep = prep
+        self.prev = None
+
+    def reset(self):
+        self.prev = None
+
+    def __call__(self, img_u8):
+        cur = self.prep.prep(img_u8)[0]
+        ref = cur if self.prev is None else self.prev
+        self.prev = cur
+        return cur.unsqueeze(0), ref.unsqueeze(0)            # [1,3,Hp,Wp] each, what model(img=[..], ref_img=[..]) takes
