@@ -6,6 +6,8 @@
 extern "C" int vps_abi_version(void) { return VPS_ABI_VERSION; }
 
 extern "C" const char* vps_build_info(void) {
-    return "libvpship abi=3 arch=gfx950 wave=64 mfma=f32_32x32x2,bf16_32x32x16(split x3/x6) "
-           "kernels=conv_mfma,flow_ops,nn_ops,det_ops,pan_ops";
+#define VPS_STR2(x) #x
+#define VPS_STR(x) VPS_STR2(x)
+    return "libvpship abi=" VPS_STR(VPS_ABI_VERSION) " arch=gfx950 wave=64 mfma=f32_32x32x2,bf16_32x32x16(split x3/x6) "
+           "kernels=conv_mfma,flow_ops,nn_ops,det_ops,pan_ops,post_ops";
 }
