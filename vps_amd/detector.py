@@ -87,7 +87,9 @@ class PanopticFuseTrack(HipModule):
         # options
         self.reuse_ref_features = True     # False: recompute extract_feat(ref_img) every frame like the reference
         self.int64_outputs = False         # True: panoptic/semantic maps as int64 like the reference (uint8 values otherwise)
-        self.profile = None                # set to {} to collect per-stage hip events
+        self.profile = None                # set to {} to collect per-stage hip events (stages then run on one stream)
+        self.overlap_streams = True        # independent branches of the frame on two HIP streams (see simple_test)
+        self._side = None
         self._ws = None
         self._flip = 0
         self._cache = None
@@ -177,8 +179,24 @@ class PanopticFuseTrack(HipModule):
         _, _, H, W = img.shape
         im_info = np.array([[float(H), float(W), 1.0]])
 
+        # Two independent pairs of branches run on two HIP streams (self.overlap_streams): FlowNet2 || backbone+FPN (both need
+        # only the images) and semantic head || RPN + box/track/mask heads (both need only the neck output). Their
+        # low-resolution layers launch fewer workgroups than the chip has CUs; side by side they fill it. Every branch is
+        # enqueued completely before the next one starts (the host only waits inside the detection branch), the side
+        # stream is ordered after the main stream at the fork and the main stream after the side stream at the join.
+        main, side = None, None
+        if self.overlap_streams and self.profile is None:
+            main = torch.cuda.current_stream(dev)
+            if self._side is None or self._side.device != dev:
+                self._side = torch.cuda.Stream(device=dev)
+            side = self._side
         # (1) flow ---------------------------------------------------------------------------------------------
-        flow = self.flownet2.run(img, ref_img, self._mean_t, self._std_t, ws)
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                flow = self.flownet2.run(img, ref_img, self._mean_t, self._std_t, ws)
+        else:
+            flow = self.flownet2.run(img, ref_img, self._mean_t, self._std_t, ws)
         self._mark('flownet2')
         # (2) backbone + FPN of the target frame -----------------------------------------------------------------
         self._flip ^= 1
@@ -186,6 +204,8 @@ class PanopticFuseTrack(HipModule):
         levels = self.neck.run(self.backbone.run(nhwc.from_nchw(img, ws, 'img_nhwc'), ws, 'bb.'), ws, 'fpn.')
         cat = self.extra_neck.gather(levels, ws, 'neck.cat' + tag)
         C = self.extra_neck.in_channels
+        if side is not None:
+            main.wait_stream(side)
         # flowR2T = F.interpolate(flow, 0.25, bilinear) * 0.25 written straight into the LiteFlowNet input buffer
         nhwc.resize(flow, cat.window(C + 81, 2), 'bilinear', 0.25)
         self._mark('backbone_fpn')
@@ -206,7 +226,12 @@ class PanopticFuseTrack(HipModule):
         x, aux = self.extra_neck.run(levels, cat, ref_bsf, ws, 'neck.')
         self._mark('extra_neck')
         # (4) semantic head --------------------------------------------------------------------------------------
-        fcn_score = self.panopticFPN.run(x[0:self.panopticFPN.num_levels], ws)
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                fcn_score = self.panopticFPN.run(x[0:self.panopticFPN.num_levels], ws)
+        else:
+            fcn_score = self.panopticFPN.run(x[0:self.panopticFPN.num_levels], ws)
         if inject is not None and 'fcn_score' in inject:
             fcn_score = nhwc.from_nchw(inject['fcn_score'].to(dev), ws, 'inj.fcn_score')
         self._mark('semantic_head')
@@ -236,6 +261,8 @@ class PanopticFuseTrack(HipModule):
         S = all_scores.shape[1]
         mask_score = all_scores.gather(3, cls_idx.view(-1, 1, 1, 1).expand(-1, S, S, 1)).squeeze(3).contiguous()
         self._mark('mask_head')
+        if side is not None:
+            main.wait_stream(side)         # the combine kernel reads fcn_score
         # (9)-(11) MaskRemoval + SegTerm + combine ---------------------------------------------------------------
         keep_inds, ref_boxes, masks_valid = self.mask_removal(mask_rois[:, 1:], cls_prob, mask_score, cls_idx, (H, W), ws)
         rois_np = mask_rois[:, 1:].cpu().numpy()

@@ -290,10 +290,12 @@ class PackedConv:
         if ksplit > 1:
             need = ksplit * d.nclass * M * self.cout_pad
             if ws is not None:
-                wsb = ws.bufs.get('__splitk_ws')
+                # one scratch buffer per stream: branches of the frame graph that run concurrently must not share it
+                key = '__splitk_ws_%x' % (getattr(hip.stream_ptr(), 'value', None) or 0)
+                wsb = ws.bufs.get(key)
                 if wsb is None or wsb.numel() < need:
                     wsb = torch.empty(max(need, 1 << 24), dtype=torch.float32, device=x.t.device)
-                    ws.bufs['__splitk_ws'] = wsb
+                    ws.bufs[key] = wsb
             else:
                 wsb = torch.empty(need, dtype=torch.float32, device=x.t.device)
             d.ws = wsb.data_ptr()
