@@ -210,6 +210,7 @@ def main():
                        'detections_per_frame': round(ndet / max(args.steps, 1), 1),
                        'parallelism': 'clip-shard x%d, 1 p2p feature hand-off per shard boundary' % world},
             'roofline': roof, 'stage_ms': stages,
+            'stage_ms_note': 'instrumented extra frame on ONE stream; the timed frames overlap FlowNet2 with backbone+FPN and the semantic head with the detection heads on two streams',
         }
         if not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.seed)
