@@ -1245,19 +1245,42 @@ void conv_small3x3_kernel(const vps_conv_desc d, const int G, const int logG, co
     }
 }
 
-// sum the split-K partials and apply the epilogue
+// sum the split-K partials (in split order, like one long accumulation) and apply the epilogue. V channels per thread
+// (float4 when cout, the leading dimensions and the channel offsets are multiples of 4); the partials of up to 8 splits are
+// requested before the first is added: a load inside the `for (split)` loop waited for itself, ksplit serial latencies.
+template <int V>
 __global__ __launch_bounds__(256)
 void conv_splitk_reduce_kernel(const vps_conv_desc d, const int M) {
-    const size_t total = (size_t)d.nclass * M * d.cout;
+    const int cv = d.cout / V;
+    const size_t total = (size_t)d.nclass * M * cv;
+    const size_t plane = (size_t)d.nclass * M * d.cout_pad;     // floats per split
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
-        const int co = (int)(idx % d.cout);
-        const size_t t2 = idx / d.cout;
+        const int co = (int)(idx % cv) * V;
+        const size_t t2 = idx / cv;
         const int m = (int)(t2 % M);
         const int cls = (int)(t2 / M);
-        float s = 0.f;
-        for (int sp = 0; sp < d.ksplit; ++sp)
-            s += d.ws[((size_t)(sp * d.nclass + cls) * M + m) * d.cout_pad + co];
+        const float* __restrict__ wp = d.ws + ((size_t)cls * M + m) * d.cout_pad + co;
+        float s[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) s[e] = 0.f;
+        for (int sp0 = 0; sp0 < d.ksplit; sp0 += 8) {
+            float v[8][V];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float* q = wp + (size_t)min(sp0 + j, d.ksplit - 1) * plane;
+                if constexpr (V == 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(q);
+                    v[j][0] = t[0]; v[j][1] = t[1]; v[j][2] = t[2]; v[j][3] = t[3];
+                } else {
+                    v[j][0] = q[0];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int e = 0; e < V; ++e) s[e] = (sp0 + j < d.ksplit) ? s[e] + v[j][e] : s[e];
+        }
         const int py = cls / d.os_x, px = cls - py * d.os_x;
         const int qx = m % d.Qw;
         const int tq = m / d.Qw;
@@ -1265,13 +1288,29 @@ void conv_splitk_reduce_kernel(const vps_conv_desc d, const int M) {
         const int n = tq / d.Qh;
         const int oy = qy * d.os_y + py, ox = qx * d.os_x + px;
         const size_t opix = ((size_t)n * d.Ho + oy) * d.Wo + ox;
-        float v = s * (d.scale ? d.scale[co] : 1.f) + (d.shift ? d.shift[co] : 0.f);
+        const int rs = d.res_shift;
+        const size_t rpix = ((size_t)n * (d.Ho >> rs) + (oy >> rs)) * (d.Wo >> rs) + (ox >> rs);
+        float r[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) r[e] = 0.f;
         if (d.res) {
-            const int rs = d.res_shift;
-            const size_t rpix = ((size_t)n * (d.Ho >> rs) + (oy >> rs)) * (d.Wo >> rs) + (ox >> rs);
-            v += d.res[rpix * d.res_ld + d.res_coff + co];
+            if constexpr (V == 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(d.res + rpix * d.res_ld + d.res_coff + co);
+                r[0] = t[0]; r[1] = t[1]; r[2] = t[2]; r[3] = t[3];
+            } else {
+                r[0] = d.res[rpix * d.res_ld + d.res_coff + co];
+            }
         }
-        d.out[opix * d.out_ld + d.out_coff + co] = vps_act(v, d.act, d.slope);
+        float o[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float v = s[e] * (d.scale ? d.scale[co + e] : 1.f) + (d.shift ? d.shift[co + e] : 0.f);
+            if (d.res) v += r[e];
+            o[e] = vps_act(v, d.act, d.slope);
+        }
+        float* op = d.out + opix * d.out_ld + d.out_coff + co;
+        if constexpr (V == 4) *reinterpret_cast<f32x4*>(op) = f32x4{o[0], o[1], o[2], o[3]};
+        else op[0] = o[0];
     }
 }
 
@@ -1322,7 +1361,10 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
     if (st) return st;
     if (d.ksplit > 1) {
         const size_t total = (size_t)d.nclass * M * d.cout;
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(stream_grid((long)total, 256)), dim3(256), 0, s, d, M);
+        const bool vec = !((d.cout | d.cout_pad | d.out_ld | d.out_coff) & 3) && !((uintptr_t)d.out & 15) &&
+                         (!d.res || (!((d.res_ld | d.res_coff) & 3) && !((uintptr_t)d.res & 15)));
+        if (vec) hipLaunchKernelGGL(conv_splitk_reduce_kernel<4>, dim3(stream_grid((long)(total / 4), 256)), dim3(256), 0, s, d, M);
+        else hipLaunchKernelGGL(conv_splitk_reduce_kernel<1>, dim3(stream_grid((long)total, 256)), dim3(256), 0, s, d, M);
         st = vps_launch_status();
     }
     return st;
