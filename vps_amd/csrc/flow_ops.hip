@@ -265,10 +265,18 @@ void flow_warp_kernel(const float* __restrict__ in, int in_ld, int in_coff,
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const bool xin0 = (unsigned)x0 < (unsigned)W, xin1 = (unsigned)x1 < (unsigned)W;
         const bool yin0 = (unsigned)y0 < (unsigned)H, yin1 = (unsigned)y1 < (unsigned)H;
-        if (yin0 && xin0) acc += *reinterpret_cast<const f32x4*>(base + (size_t)(y0 * W + x0) * in_ld) * nw;
-        if (yin0 && xin1) acc += *reinterpret_cast<const f32x4*>(base + (size_t)(y0 * W + x1) * in_ld) * ne;
-        if (yin1 && xin0) acc += *reinterpret_cast<const f32x4*>(base + (size_t)(y1 * W + x0) * in_ld) * sw;
-        if (yin1 && xin1) acc += *reinterpret_cast<const f32x4*>(base + (size_t)(y1 * W + x1) * in_ld) * se;
+        // the four corners are requested unconditionally at clamped coordinates and added under the same conditions and in
+        // the same order as before (a load behind `if` waits for itself: four serial latencies per pixel)
+        const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x1, 0), W - 1);
+        const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y1, 0), H - 1);
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + (size_t)(yc0 * W + xc0) * in_ld);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + (size_t)(yc0 * W + xc1) * in_ld);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + (size_t)(yc1 * W + xc0) * in_ld);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + (size_t)(yc1 * W + xc1) * in_ld);
+        acc = (yin0 && xin0) ? acc + v00 * nw : acc;
+        acc = (yin0 && xin1) ? acc + v01 * ne : acc;
+        acc = (yin1 && xin0) ? acc + v10 * sw : acc;
+        acc = (yin1 && xin1) ? acc + v11 * se : acc;
         *reinterpret_cast<f32x4*>(out + (size_t)pix * out_ld + out_coff + 4 * c4) = acc;
     }
 }

@@ -109,16 +109,18 @@ void bfp_gather_kernel(GatherArgs a, float* __restrict__ out, int out_ld, int ou
         const int x = (int)(pix % W0);
         const int y = (int)((pix / W0) % H0);
         const int n = (int)(pix / ((long)W0 * H0));
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        // all (up to 5) level values are requested first (absent levels re-read level 0), then summed in level order
+        f32x4 v[5];
 #pragma unroll
         for (int l = 0; l < 5; ++l) {
-            if (l < a.n) {
-                const int r = a.ratio[l];
-                const int Hl = H0 / r, Wl = W0 / r;
-                const float* p = a.lv[l] + (((size_t)n * Hl + y / r) * Wl + x / r) * a.ld[l] + 4 * c4;
-                s += *reinterpret_cast<const f32x4*>(p);
-            }
+            const int ll = l < a.n ? l : 0;
+            const int r = a.ratio[ll];
+            const int Hl = H0 / r, Wl = W0 / r;
+            v[l] = *reinterpret_cast<const f32x4*>(a.lv[ll] + (((size_t)n * Hl + y / r) * Wl + x / r) * a.ld[ll] + 4 * c4);
         }
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int l = 0; l < 5; ++l) s = l < a.n ? s + v[l] : s;
         *reinterpret_cast<f32x4*>(out + (size_t)pix * out_ld + out_coff + 4 * c4) = s / div;
     }
 }
@@ -137,11 +139,18 @@ void bfp_scatter_kernel(const float* __restrict__ bsf, int bsf_ld, const float* 
         const int y = (int)((pix / Wl) % Hl);
         const int n = (int)(pix / ((long)Wl * Hl));
         f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        // four window columns per step, requested together (a clamped duplicate does not change a maximum)
         for (int dy = 0; dy < r; ++dy)
-            for (int dx = 0; dx < r; ++dx) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(
-                    bsf + (((size_t)n * H0 + y * r + dy) * W0 + x * r + dx) * bsf_ld + 4 * c4);
-                m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+            for (int dx0 = 0; dx0 < r; dx0 += 4) {
+                f32x4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[j] = *reinterpret_cast<const f32x4*>(
+                        bsf + (((size_t)n * H0 + y * r + dy) * W0 + x * r + min(dx0 + j, r - 1)) * bsf_ld + 4 * c4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    m[0] = fmaxf(m[0], v[j][0]); m[1] = fmaxf(m[1], v[j][1]); m[2] = fmaxf(m[2], v[j][2]); m[3] = fmaxf(m[3], v[j][3]);
+                }
             }
         const f32x4 lv = *reinterpret_cast<const f32x4*>(level + (size_t)pix * lvl_ld + 4 * c4);
         *reinterpret_cast<f32x4*>(out + (size_t)pix * out_ld + 4 * c4) = m + lv;
