@@ -241,6 +241,17 @@ class PackedConv:
         if out is None:
             out = ws.fmap(name, x.N, Ho, Wo, self.cout)
         assert (out.N, out.H, out.W) == (x.N, Ho, Wo) and out.C == self.cout, ((out.N, out.H, out.W, out.C), (x.N, Ho, Wo, self.cout))
+        # The workspace is persistent, so a layer sees the same operand addresses every frame: the filled descriptor (and the
+        # split-K scratch it points to) is cached per operand set; a hit costs one dict lookup + the launch instead of ~50
+        # ctypes field stores (the low-resolution layers run for 10-20 us, less than it takes to describe them).
+        ckey = (x.t.data_ptr(), x.N, x.H, x.W, x.ld, x.coff, out.t.data_ptr(), out.ld, out.coff,
+                None if res is None else (res.t.data_ptr(), res.ld, res.coff, res_shift),
+                None if offset is None else (offset.t.data_ptr(), offset.ld), act, getattr(hip.stream_ptr(), 'value', None) or 0)
+        cache = self.__dict__.setdefault('_dcache', {})
+        hit = cache.get(ckey)
+        if hit is not None and CONV_TRACE is None:
+            hip.conv2d(hit[0])
+            return out
         d = hip.ConvDesc()
         d.inp = x.t.data_ptr(); d.N, d.H, d.W = x.N, x.H, x.W
         d.in_ld, d.in_coff, d.cin_pad = x.ld, x.coff, self.cin_pad
@@ -312,6 +323,9 @@ class PackedConv:
                                self.bytes(x.N, x.H, x.W, res is not None)))
         else:
             hip.conv2d(d)
+        if len(cache) >= 16:
+            cache.clear()
+        cache[ckey] = (d, wsb if ksplit > 1 else None, x.t, out.t, None if res is None else res.t, None if offset is None else offset.t)
         return out
 
     def bytes(self, x_N, x_H, x_W, has_res=False):
