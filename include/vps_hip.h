@@ -279,6 +279,14 @@ int vps_unify_tables(const int32_t* hist, const int32_t* pan_count, const int32_
                      int id_last_stuff, int64_t stuff_area_limit, uint8_t* tables, int32_t* status, void* stream);
 int vps_unify_write(const uint8_t* pan, int64_t npix, const uint8_t* tables, uint8_t* out, void* stream);
 
+/* Second half of the output path: tools/dataset/cityscapes_vps.py:97-159 (converter_2ch_track_core) without its per-segment
+ * boolean masks. pan_2ch uint8 [H][W][3] = (pan_seg, pan_ins, pan_obj); a segment is a (pan_seg, pan_obj) pair, key =
+ * seg*256 + obj (the reference's 1000*seg + obj).
+ *   stats  int32 [65536][5] = (pixel count, xmin, ymin, xmax, ymax), initialised by the call (count 0 = absent)
+ *   lut    uint8 [65536][3] colour per key (chosen on the host), out uint8 [npix][3] */
+int vps_segment_stats(const uint8_t* pan_2ch, int H, int W, int32_t* stats, void* stream);
+int vps_segment_paint(const uint8_t* pan_2ch, int64_t npix, const uint8_t* lut, uint8_t* out, void* stream);
+
 /* ----------------------------------------------------------------------------------------------
  * Input preparation: Normalize -> Pad(size_divisor) -> ImageToTensor of the test pipeline in one pass.
  * Replaces mmdet/datasets/pipelines/transforms.py:258-269, :310-318 and formating.py:52-67 (mmcv 0.2.14 imnormalize,

@@ -95,3 +95,62 @@ def get_unified_pan_result(segs, pans, cls_inds, obj_ids=None, stuff_area_limit=
             obj_id, max_oid = dedup_obj_ids(obj_id, max_oid)
         out[name] = unify_frame(seg, pan, cls_ind, obj_id, id_last_stuff, stuff_area_limit)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# cityscapes_vps.py:97-159 converter_2ch_track_core: (pan_seg, pan_ins, pan_obj) maps -> colour-coded panoptic PNG arrays +
+# COCO-panoptic `segments_info`. `panopticapi` (rgb2id, IdGenerator) is a third-party dependency that is NOT in
+# /root/reference: rgb2id is restated from its published source (panopticapi/utils.py: color[0] + 256*color[1] +
+# 256*256*color[2]); the colour generator is the caller's object (the reference passes its IdGenerator). PARITY UNPINNED
+# for those two; the statements below are the reference's.
+# ------------------------------------------------------------------------------------------------------------------------
+def rgb2id(color):
+    if isinstance(color, np.ndarray) and len(color.shape) == 3:
+        if color.dtype == np.uint8:
+            color = color.astype(np.int32)
+        return color[:, :, 0] + 256 * color[:, :, 1] + 256 * 256 * color[:, :, 2]
+    return int(color[0] + 256 * color[1] + 256 * 256 * color[2])
+
+
+def converter_2ch_track_core(pan_2ch_set, color_generator):
+    OFFSET = 1000
+    VOID = 255
+    annotations, pan_all = [], []
+    inst2color = {}
+    for idx in range(len(pan_2ch_set)):
+        pan_2ch = np.uint32(pan_2ch_set[idx])
+        pan = OFFSET * pan_2ch[:, :, 0] + pan_2ch[:, :, 2]
+        pan_format = np.zeros((pan_2ch.shape[0], pan_2ch.shape[1], 3), dtype=np.uint8)
+        segm_info = {}
+        for el in np.unique(pan):
+            sem = el // OFFSET
+            if sem == VOID:
+                continue
+            mask = pan == el
+            if el % OFFSET > 0:                      # things: one colour per (class, object id) for the whole clip
+                if el in inst2color:
+                    color = inst2color[el]
+                else:
+                    color = color_generator.get_color(sem)
+                    inst2color[el] = color
+            else:
+                color = color_generator.get_color(sem)
+            pan_format[mask] = color
+            index = np.where(mask)
+            x = index[1].min(); y = index[0].min()
+            width = index[1].max() - x; height = index[0].max() - y
+            dt = {"category_id": sem.item(), "iscrowd": 0, "id": int(rgb2id(color)),
+                  "bbox": [x.item(), y.item(), width.item(), height.item()], "area": mask.sum().item()}
+            segm_info[int(rgb2id(color))] = dt
+        pan_all.append(pan_format)
+        gt_pan = np.uint32(pan_format)
+        pan_gt = gt_pan[:, :, 0] + gt_pan[:, :, 1] * 256 + gt_pan[:, :, 2] * 256 * 256
+        labels, labels_cnt = np.unique(pan_gt, return_counts=True)
+        for label, area in zip(labels, labels_cnt):
+            if label == 0:
+                continue
+            if label not in segm_info.keys():
+                raise KeyError('label not in segm_info keys.')
+            segm_info[label]["area"] = int(area)
+        annotations.append({"segments_info": [v for k, v in segm_info.items()]})
+    return annotations, pan_all

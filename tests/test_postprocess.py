@@ -94,3 +94,50 @@ def test_device_unify_matches_oracle_random(dev, H, W, k, seed):
     ref2 = opp.get_unified_pan_result([seg], [pan], [cls_ind], None, 500, ['a'])
     res2 = u.get_unified_pan_result([sd], [pd], [cls_ind], None, 500, ['a'])
     assert np.array_equal(res2['a'], ref2['a'])
+
+
+class _Colors:
+    """deterministic stand-in for panopticapi's IdGenerator (which draws random shades of the category colour): distinct
+    colours in call order, with one deliberate repeat so that two segments share a colour id"""
+
+    def __init__(self):
+        self.n = 0
+
+    def get_color(self, cat_id):
+        self.n += 1
+        k = self.n if self.n != 7 else 3           # the 7th call repeats the 3rd colour
+        return [int(cat_id) * 7 % 256, k % 256, (k * 37) % 256]
+
+
+def _pan2ch_clip(rng, H, W, nfr):
+    clip = []
+    for f in range(nfr):
+        seg = np.ascontiguousarray(rng.integers(0, 11, size=((H + 7) // 8, (W + 7) // 8)).astype(np.uint8).repeat(8, 0).repeat(8, 1)[:H, :W])
+        ins = np.zeros((H, W), np.uint8); obj = seg.copy()
+        for i in range(6):
+            h, w = int(rng.integers(3, H // 2)), int(rng.integers(3, W // 2))
+            y, x = int(rng.integers(0, H - h)), int(rng.integers(0, W - w))
+            seg[y:y + h, x:x + w] = 11 + i % 3; ins[y:y + h, x:x + w] = i + 1; obj[y:y + h, x:x + w] = 1 + (i + f) % 5
+        seg[:2, :3] = 255; obj[:2, :3] = 255
+        clip.append(np.stack([seg, ins, obj], -1))
+    return clip
+
+
+def test_oracle_converter_runs_and_counts_by_colour():
+    clip = _pan2ch_clip(np.random.default_rng(3), 32, 48, 2)
+    ann, pans = opp.converter_2ch_track_core(clip, _Colors())
+    assert len(ann) == 2 and pans[0].shape == (32, 48, 3) and pans[0].dtype == np.uint8
+    tot = sum(s['area'] for s in ann[0]['segments_info'])
+    assert tot == int((clip[0][..., 0] != 255).sum())            # every non-void pixel is counted exactly once
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W', [(1024, 2048), (37, 53)])
+def test_device_converter_matches_oracle(dev, H, W):
+    from vps_amd import postprocess as pp
+    clip = _pan2ch_clip(np.random.default_rng(H), H, W, 3)
+    ann_r, pans_r = opp.converter_2ch_track_core(clip, _Colors())
+    ann_d, pans_d = pp.TrackConverter(dev).convert([torch.from_numpy(c).to(dev) for c in clip], _Colors())
+    for f in range(3):
+        assert np.array_equal(pans_d[f], pans_r[f]), f
+        assert ann_d[f] == ann_r[f], f

@@ -250,3 +250,64 @@ extern "C" int vps_image_prep(const uint8_t* img, int H, int W, int Hp, int Wp, 
                        mean[0], mean[1], mean[2], std[0], std[1], std[2], to_rgb, pad_val, out);
     return vps_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Second half of the output path: tools/dataset/cityscapes_vps.py:97-159 (converter_2ch_track_core). Per frame the reference
+// builds one boolean mask per segment (np.unique over 1000*seg + obj) to paint it, take its bounding box and count it.
+//   vps_segment_stats  per (seg, obj) pair: pixel count and bounding box, one pass (table [65536][5] int32)
+//   vps_segment_paint  out[p] = lut[seg, obj] (colours chosen on the host by the reference's own colour generator)
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256)
+void segment_stats_init_kernel(int32_t* __restrict__ stats) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;     // 65536 entries
+    stats[5 * i] = 0; stats[5 * i + 1] = 0x7fffffff; stats[5 * i + 2] = 0x7fffffff; stats[5 * i + 3] = -1; stats[5 * i + 4] = -1;
+}
+
+// one thread per 8-pixel run of a row: runs of one segment are folded into one update (count, x range) each
+__global__ __launch_bounds__(256)
+void segment_stats_kernel(const uint8_t* __restrict__ pan2, int H, int W, int32_t* __restrict__ stats) {
+    const int runs_per_row = (W + 7) >> 3;
+    const long total = (long)H * runs_per_row;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(idx / runs_per_row), x0 = (int)(idx % runs_per_row) * 8;
+        const int n = min(8, W - x0);
+        const uint8_t* p = pan2 + ((size_t)y * W + x0) * 3;
+        int key = -1, cnt = 0, xs = 0;
+        for (int i = 0; i <= n; ++i) {
+            const int k = i < n ? (p[3 * i] << 8 | p[3 * i + 2]) : -2;
+            if (k != key) {
+                if (cnt) {
+                    int32_t* s = stats + 5 * key;
+                    atomicAdd(&s[0], cnt); atomicMin(&s[1], xs); atomicMin(&s[2], y); atomicMax(&s[3], x0 + i - 1); atomicMax(&s[4], y);
+                }
+                key = k; cnt = 0; xs = x0 + i;
+            }
+            ++cnt;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256)
+void segment_paint_kernel(const uint8_t* __restrict__ pan2, long npix, const uint8_t* __restrict__ lut, uint8_t* __restrict__ out) {
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        const int key = pan2[3 * p] << 8 | pan2[3 * p + 2];
+        const uint8_t* c = lut + 3 * key;
+        out[3 * p] = c[0]; out[3 * p + 1] = c[1]; out[3 * p + 2] = c[2];
+    }
+}
+}  // namespace
+
+extern "C" int vps_segment_stats(const uint8_t* pan_2ch, int H, int W, int32_t* stats, void* stream) {
+    if (!pan_2ch || !stats || H <= 0 || W <= 0) return VPS_EARG(1);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(segment_stats_init_kernel, dim3(256), dim3(256), 0, s, stats);
+    hipLaunchKernelGGL(segment_stats_kernel, dim3(stream_grid((long)H * ((W + 7) >> 3), 256)), dim3(256), 0, s, pan_2ch, H, W, stats);
+    return vps_launch_status();
+}
+
+extern "C" int vps_segment_paint(const uint8_t* pan_2ch, int64_t npix, const uint8_t* lut, uint8_t* out, void* stream) {
+    if (!pan_2ch || !lut || !out || npix <= 0) return VPS_EARG(1);
+    hipLaunchKernelGGL(segment_paint_kernel, dim3(stream_grid((long)npix, 256)), dim3(256), 0, (hipStream_t)stream, pan_2ch, (long)npix, lut, out);
+    return vps_launch_status();
+}

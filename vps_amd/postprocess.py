@@ -89,3 +89,65 @@ class PanopticUnifier:
         for name, out in outs:
             results[name] = out.cpu().numpy()
         return results
+
+
+def _rgb2id(color):
+    return int(color[0]) + 256 * int(color[1]) + 256 * 256 * int(color[2])        # panopticapi.utils.rgb2id for one colour
+
+
+class TrackConverter:
+    """Device-side body of `converter_2ch_track_core(proc_id, pan_2ch_set, color_generator)` (cityscapes_vps.py:97-159): same
+    result — (annotations, pan_all) — from one statistics pass and one painting pass per frame instead of a boolean mask per
+    segment. Colours come from the caller's generator exactly as in the reference (one call per stuff segment and frame, one
+    per new (class, object id) pair and clip), in ascending order of 1000*seg + obj."""
+
+    def __init__(self, device='cuda'):
+        self.device = torch.device(device)
+        self.stats = torch.empty(65536 * 5, dtype=torch.int32, device=self.device)
+        self.lut = torch.zeros(65536 * 3, dtype=torch.uint8, device=self.device)
+
+    def convert(self, pan_2ch_set, color_generator):
+        lib = hip.load()
+        annotations, pan_all = [], []
+        inst2color = {}
+        for pan_2ch in pan_2ch_set:
+            t = torch.from_numpy(np.ascontiguousarray(pan_2ch)) if isinstance(pan_2ch, np.ndarray) else pan_2ch
+            t = t.to(self.device).contiguous()
+            assert t.dtype == torch.uint8 and t.dim() == 3 and t.shape[2] == 3
+            H, W = int(t.shape[0]), int(t.shape[1])
+            hip.check(lib.vps_segment_stats(hip.ptr(t), H, W, hip.ptr(self.stats), hip.stream_ptr()), 'vps_segment_stats')
+            st = self.stats.view(65536, 5)
+            keys = torch.nonzero(st[:, 0] > 0).flatten()
+            rows = st[keys].cpu().numpy()                       # a few dozen present segments
+            keys = keys.cpu().numpy()
+            seg, obj = keys >> 8, keys & 255
+            order = np.argsort(1000 * seg + obj, kind='stable')  # np.unique(1000*seg + obj) ascending
+            lut = np.zeros((65536, 3), dtype=np.uint8)
+            segm_info, painted = {}, {}
+            for i in order:
+                sem, ob = int(seg[i]), int(obj[i])
+                if sem == 255:
+                    continue
+                el = 1000 * sem + ob
+                if ob > 0:
+                    if el in inst2color:
+                        color = inst2color[el]
+                    else:
+                        color = color_generator.get_color(sem)
+                        inst2color[el] = color
+                else:
+                    color = color_generator.get_color(sem)
+                lut[keys[i]] = color
+                cnt, x0, y0, x1, y1 = (int(v) for v in rows[i])
+                sid = _rgb2id(color)
+                segm_info[sid] = {"category_id": sem, "iscrowd": 0, "id": sid, "bbox": [x0, y0, x1 - x0, y1 - y0], "area": cnt}
+                painted[sid] = painted.get(sid, 0) + cnt    # areas are re-counted per COLOUR (two segments may share one)
+            for sid, area in painted.items():
+                if sid != 0:
+                    segm_info[sid]["area"] = area
+            self.lut.copy_(torch.from_numpy(lut.reshape(-1)), non_blocking=False)
+            out = torch.empty(H, W, 3, dtype=torch.uint8, device=self.device)
+            hip.check(lib.vps_segment_paint(hip.ptr(t), H * W, hip.ptr(self.lut), hip.ptr(out), hip.stream_ptr()), 'vps_segment_paint')
+            pan_all.append(out.cpu().numpy())
+            annotations.append({"segments_info": [v for k, v in segm_info.items()]})
+        return annotations, pan_all
