@@ -287,6 +287,13 @@ int vps_unify_write(const uint8_t* pan, int64_t npix, const uint8_t* tables, uin
 int vps_segment_stats(const uint8_t* pan_2ch, int H, int W, int32_t* stats, void* stream);
 int vps_segment_paint(const uint8_t* pan_2ch, int64_t npix, const uint8_t* lut, uint8_t* out, void* stream);
 
+/* VPQ evaluation: confusion counts of tools/eval_vpq.py:150-157 for ONE frame.
+ *   gt_rgb, pred_rgb  uint8 [npix][3] panoptic PNGs (segment id = R + 256 G + 65536 B)
+ *   gt_ids, pred_ids  sorted unique uint32 ids (device), typically the ids of the frame's segments_info plus 0 (VOID)
+ *   counts            int32 [ngt+1][npred+1], zeroed by the call; row / column n collects the ids that are not listed */
+int vps_pair_count(const uint8_t* gt_rgb, const uint8_t* pred_rgb, int64_t npix, const uint32_t* gt_ids, int ngt,
+                   const uint32_t* pred_ids, int npred, int32_t* counts, void* stream);
+
 /* ----------------------------------------------------------------------------------------------
  * Input preparation: Normalize -> Pad(size_divisor) -> ImageToTensor of the test pipeline in one pass.
  * Replaces mmdet/datasets/pipelines/transforms.py:258-269, :310-318 and formating.py:52-67 (mmcv 0.2.14 imnormalize,

@@ -133,7 +133,57 @@ def bench_converter():
                          'sample': '1 frame, NumPy restatement (one boolean mask per segment, as the reference)'}}))
 
 
+def bench_vpq():
+    """row 3: tube statistics of an 8-frame 1024x2048 clip for the four window lengths of eval_vpq.py:main"""
+    from oracle import evaluate as oev
+    from vps_amd import evaluate as ev
+    H, W, nfr, ninst = 1024, 2048, 8, 40
+    rng = np.random.default_rng(2)
+    cats = {c: {'id': c, 'isthing': 1 if c >= 11 else 0} for c in range(19)}
+    base = rng.integers(0, 11, size=(H // 64, W // 64))
+    boxes = [(int(rng.integers(0, H - 200)), int(rng.integers(0, W - 300)), int(rng.integers(40, 200)), int(rng.integers(40, 300))) for _ in range(ninst)]
+    rgb = lambda m: np.stack([m % 256, (m // 256) % 256, m // 65536], -1).astype(np.uint8)
+    frames = []
+    for f in range(nfr):
+        st = base.repeat(64, 0).repeat(64, 1)
+        gt = (1000 + st).astype(np.int64); pr = gt.copy()
+        gseg = {int(1000 + c): int(c) for c in np.unique(st)}; pseg = dict(gseg)
+        for i, (y, x, h, w) in enumerate(boxes):
+            y = min(y + 2 * f, H - h); x = min(x + 3 * f, W - w)
+            gt[y:y + h, x:x + w] = 5000 + i; gseg[5000 + i] = 11 + i % 8
+            if i % 6 != 5:
+                pr[y + 3:y + h, x + 2:x + w] = 9000 + i; pseg[9000 + i] = 11 + i % 8
+        ginfo = [{'id': k, 'category_id': v, 'iscrowd': 0, 'area': int((gt == k).sum())} for k, v in gseg.items() if (gt == k).any()]
+        pinfo = [{'id': k, 'category_id': v, 'iscrowd': 0, 'area': int((pr == k).sum())} for k, v in pseg.items() if (pr == k).any()]
+        frames.append(({'segments_info': ginfo}, {'segments_info': pinfo}, rgb(gt), rgb(pr), {}))
+    dev = torch.device('cuda:0')
+    dframes = [(a, b, torch.from_numpy(c).to(dev), torch.from_numpy(d).to(dev), e) for a, b, c, d, e in frames]
+    ev.vpq_compute_single_core(dframes[:2], cats, nframes=1, device=dev)              # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cache, res = {}, {}
+    for nf in (1, 2, 3, 4):
+        res[nf] = ev.vpq_compute_single_core(dframes, cats, nframes=nf, device=dev, _cache=cache)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    ref = oev.vpq_compute_single_core(frames, cats, nframes=2)
+    cpu_ms_nf2 = (time.perf_counter() - t0) * 1e3
+    for c in cats:
+        assert (res[2][c].tp, res[2][c].fp, res[2][c].fn, res[2][c].iou) == (ref[c].tp, ref[c].fp, ref[c].fn, ref[c].iou)
+    abytes = nfr * H * W * 6
+    print(json.dumps({
+        'metric': 'clips/sec VPQ tube statistics (8 frames 1024x2048, window lengths 1-4)', 'value': round(1e3 / ms, 2), 'unit': 'clips/s',
+        'ms_per_clip': round(ms, 2), 'dtype': 'u8 / int', 'data': 'synthetic',
+        'config': {'workload': '8-frame clip, 40 instances + stuff, PNG arrays resident in HBM, wall clock incl. host matching'},
+        'roofline': {'bound': 'hbm', 'achieved': round(abytes / ms / 1e6, 2), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(abytes / ms / 1e6 / 8000.0, 5),
+                     'traffic': None, 'algorithmic_bytes': abytes},
+        'cpu_baseline': {'value': round(1e3 / (cpu_ms_nf2 * 4), 3), 'unit': 'clips/s', 'cores': 1, 'kind': 'port',
+                         'sample': 'window length 2 only (%.0f ms), x4 for the four lengths' % cpu_ms_nf2}}))
+
+
 if __name__ == '__main__':
     main()
     bench_prep()
     bench_converter()
+    bench_vpq()

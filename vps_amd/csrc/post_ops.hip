@@ -311,3 +311,75 @@ extern "C" int vps_segment_paint(const uint8_t* pan_2ch, int64_t npix, const uin
     hipLaunchKernelGGL(segment_paint_kernel, dim3(stream_grid((long)npix, 256)), dim3(256), 0, (hipStream_t)stream, pan_2ch, (long)npix, lut, out);
     return vps_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// VPQ evaluation: the confusion counts of tools/eval_vpq.py:150-157. The reference stacks the id maps of
+// every nframes-long window and runs np.unique on nframes x H x W uint64 keys, for every window and every window length.
+// Here every frame is counted ONCE into a dense (gt segment x predicted segment) table — the segment ids of a frame are
+// known from the two JSONs — and the host sums the per-frame tables of a window (vps_amd/evaluate.py).
+// ------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ int id_index(const uint32_t* __restrict__ ids, int n, uint32_t v) {
+    int lo = 0, hi = n - 1;
+    while (lo <= hi) {                      // sorted, unique
+        const int mid = (lo + hi) >> 1;
+        const uint32_t m = ids[mid];
+        if (m == v) return mid;
+        if (m < v) lo = mid + 1; else hi = mid - 1;
+    }
+    return n;                               // not listed
+}
+
+// 8 pixels per thread, runs of one (gt, pred) pair folded; LDS-private table when it fits
+__global__ __launch_bounds__(256)
+void pair_count_kernel(const uint8_t* __restrict__ gt, const uint8_t* __restrict__ pred, long npix, const uint32_t* __restrict__ gt_ids,
+                       int ngt, const uint32_t* __restrict__ pred_ids, int npred, int32_t* __restrict__ counts, int use_lds) {
+    extern __shared__ int32_t tab[];
+    const int cols = npred + 1, size = (ngt + 1) * cols;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < size; i += blockDim.x) tab[i] = 0;
+        __syncthreads();
+    }
+    const long nchunk = (npix + 7) >> 3;
+    for (long ch = (long)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunk; ch += (long)gridDim.x * blockDim.x) {
+        const long p0 = ch << 3;
+        const int n = (int)min(8L, npix - p0);
+        uint32_t lg = 0xffffffffu, lp = 0xffffffffu;
+        int gi = 0, pi = 0, run = 0, run_cell = -1;
+        for (int i = 0; i < n; ++i) {
+            const uint8_t* a = gt + 3 * (p0 + i);
+            const uint8_t* b = pred + 3 * (p0 + i);
+            const uint32_t g = a[0] | (a[1] << 8) | (a[2] << 16), q = b[0] | (b[1] << 8) | (b[2] << 16);
+            if (g != lg) { gi = id_index(gt_ids, ngt, g); lg = g; }
+            if (q != lp) { pi = id_index(pred_ids, npred, q); lp = q; }
+            const int cell = gi * cols + pi;
+            if (cell != run_cell) {
+                if (run) atomicAdd(use_lds ? &tab[run_cell] : &counts[run_cell], run);
+                run_cell = cell; run = 0;
+            }
+            ++run;
+        }
+        if (run) atomicAdd(use_lds ? &tab[run_cell] : &counts[run_cell], run);
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < size; i += blockDim.x)
+            if (tab[i]) atomicAdd(&counts[i], tab[i]);
+    }
+}
+}  // namespace
+
+extern "C" int vps_pair_count(const uint8_t* gt_rgb, const uint8_t* pred_rgb, int64_t npix, const uint32_t* gt_ids, int ngt,
+                              const uint32_t* pred_ids, int npred, int32_t* counts, void* stream) {
+    if (!gt_rgb || !pred_rgb || !counts || npix <= 0 || ngt < 0 || npred < 0 || (ngt > 0 && !gt_ids) || (npred > 0 && !pred_ids)) return VPS_EARG(1);
+    const long size = (long)(ngt + 1) * (npred + 1);
+    if (size > (1L << 26)) return VPS_EARG(2);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * size, s);
+    if (e != hipSuccess) return -(int)e;
+    const int use_lds = size <= 12288;
+    long g = ((npix + 7) >> 3) / (256 * 4); if (g > 512) g = 512; if (g < 1) g = 1;
+    hipLaunchKernelGGL(pair_count_kernel, dim3((unsigned)g), dim3(256), use_lds ? sizeof(int32_t) * size : 0, s, gt_rgb, pred_rgb, (long)npix,
+                       gt_ids, ngt, pred_ids, npred, counts, use_lds);
+    return vps_launch_status();
+}

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VPS_HIP_LIB: developer override to load an experimental build of the same ABI (kernel A/B timing)
 LIB_PATH = os.environ.get('VPS_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libvpship.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 2, 3
@@ -26,7 +26,7 @@ SYMBOLS = [
     'vps_bfp_scatter', 'vps_axpb', 'vps_flow_prep', 'vps_flow_stage', 'vps_groupnorm_relu', 'vps_tcea_temporal',
     'vps_tcea_modulate', 'vps_roi_align', 'vps_nms_batched', 'vps_delta2bbox', 'vps_bbox_overlaps',
     'vps_row_softmax', 'vps_mask_count', 'vps_mask_commit', 'vps_mask_removal', 'vps_mask_level', 'vps_panoptic_combine',
-    'vps_unify_hist', 'vps_unify_tables', 'vps_unify_write', 'vps_image_prep', 'vps_segment_stats', 'vps_segment_paint',
+    'vps_unify_hist', 'vps_unify_tables', 'vps_unify_write', 'vps_image_prep', 'vps_segment_stats', 'vps_segment_paint', 'vps_pair_count',
 ]
 
 
@@ -134,6 +134,7 @@ def load():
                                    ctypes.c_float, c_void_p, c_void_p]
     lib.vps_segment_stats.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.vps_segment_paint.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]
+    lib.vps_pair_count.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]
     _lib = lib
     return lib
 
