@@ -466,10 +466,13 @@ class FuseTrackOracle:
     """PanopticFuseTrack.simple_test restated (panoptic_fusetrack.py:502-606). `sd` uses the reference keys:
     backbone.*, neck.*, extra_neck.*, panopticFPN.*, rpn_head.*, bbox_head.*, track_head.*, mask_head.*, flownet2.*"""
 
-    def __init__(self, sd, cfg=CFG, depth=50):
+    def __init__(self, sd, cfg=CFG, depth=50, with_fusion=True, with_track=True):
+        """with_track=False: PanopticFuse (panoptic_fuse.py:399-472, no ids); with_fusion=False: PanopticTrack
+        (panoptic_track.py:443-536, the FPN outputs feed the heads directly)."""
         self.sd = {k: v.float() for k, v in sd.items()}
         self.cfg = cfg
         self.depth = depth
+        self.with_fusion, self.with_track = with_fusion, with_track
         self.prev_bboxes = self.prev_roi_feats = self.prev_det_labels = None
 
     def compute_flow(self, img, ref_img, scale_factor=0.25):
@@ -506,6 +509,10 @@ class FuseTrackOracle:
         det_labels = cls_idx - 1
         det_roi_feats = roi_extract(x, det_rois, 7, cfg)
         det_bboxes = det_rois[:, 1:]
+        if not self.with_track:
+            return dict(proposals=proposals, cls_score=cls_score, bbox_pred=bbox_pred, cls_prob=cls_prob, det_rois=det_rois,
+                        cls_idx=cls_idx, det_labels=det_labels, det_obj_ids=np.full((det_bboxes.size(0),), -1), comp_scores=None,
+                        det_roi_feats=det_roi_feats)
         if is_first or self.prev_bboxes is None:
             det_obj_ids = np.arange(det_bboxes.size(0))
             self.prev_bboxes = det_bboxes.clone(); self.prev_roi_feats = det_roi_feats.clone()
@@ -553,18 +560,23 @@ class FuseTrackOracle:
                     mask_score=mask_score)
 
     def simple_test(self, img, ref_img, is_first, ref_x=None, inject=None, return_aux=False):
-        flow = self.compute_flow(img, ref_img, 0.25)
         x = self.extract_feat(img)
-        if ref_x is None:
-            ref_x = self.extract_feat(ref_img)
         pre_neck = x
-        x = bfp_tcea(self.sd, 'extra_neck.', x, ref_x, flow)
+        flow = None
+        if self.with_fusion:
+            flow = self.compute_flow(img, ref_img, 0.25)
+            if ref_x is None:
+                ref_x = self.extract_feat(ref_img)
+            x = bfp_tcea(self.sd, 'extra_neck.', x, ref_x, flow)
         fcn_output, fcn_score = upsnet_fpn(self.sd, 'panopticFPN.', x[0:4])
         if inject is not None and 'fcn_score' in inject:
             fcn_score = inject['fcn_score']
             fcn_output = F.interpolate(fcn_score, scale_factor=4, mode='bilinear', align_corners=False)
         det = self.detect(x, tuple(img.shape[2:]), is_first, inject)
         pano = self.panoptic(x, fcn_output, det, inject)
+        if not self.with_track:
+            pano.pop('panoptic_det_labels'); pano.pop('panoptic_det_obj_ids')
         if return_aux:
-            pano.update(flow=flow, flow_full=self.last_flow_full, feats=x, pre_neck=pre_neck, fcn_score=fcn_score, det=det)
+            pano.update(flow=flow, flow_full=self.last_flow_full if self.with_fusion else None, feats=x, pre_neck=pre_neck,
+                        fcn_score=fcn_score, det=det)
         return pano

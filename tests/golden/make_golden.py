@@ -25,14 +25,15 @@ warnings.simplefilter('ignore')
 H, W, NFRAMES, SEED = 128, 256, 3, 0
 
 
-def main():
+def main(variant='fusetrack'):
     import ref_shims
     mods = ref_shims.install()
     from vps_amd import synth
     from vps_amd.registry import Config, ConfigDict
     import vps_amd
 
-    cfg = Config.fromfile('/root/reference/configs/cityscapes/fusetrack.py')
+    cfg = Config.fromfile('/root/reference/configs/cityscapes/%s.py' % variant)
+    has_flow, has_track = variant != 'track', variant != 'fuse'
     # --- shapes of every parameter, from OUR containers; the reference model must expose exactly the same keys ---
     ours = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
     shapes = {k: tuple(v.shape) for k, v in ours.state_dict().items()}
@@ -68,8 +69,9 @@ def main():
         def f(mod, inp, out):
             cap.setdefault(name, []).append(out)
         return f
-    ref.flownet2.register_forward_hook(hook('flownet2'))
-    ref.extra_neck.register_forward_hook(hook('extra_neck'))
+    if has_flow:
+        ref.flownet2.register_forward_hook(hook('flownet2'))
+        ref.extra_neck.register_forward_hook(hook('extra_neck'))
     ref.panopticFPN.register_forward_hook(hook('panopticFPN'))
     ref.bbox_head.register_forward_hook(hook('bbox_head'))
     ref.mask_head.register_forward_hook(hook('mask_head'))
@@ -96,27 +98,33 @@ def main():
             out[p + 'panoptic_outputs'] = pano['panoptic_outputs'].numpy().astype(np.uint8)
             out[p + 'panoptic_cls_inds'] = pano['panoptic_cls_inds'].numpy()
             out[p + 'panoptic_cls_prob'] = pano['panoptic_cls_prob'].numpy()
-            out[p + 'panoptic_det_labels'] = pano['panoptic_det_labels'].numpy()
-            out[p + 'panoptic_det_obj_ids'] = np.asarray(pano['panoptic_det_obj_ids'].numpy())
-            out[p + 'bbox_ids'] = np.array(sorted(int(k) for k in bbox_res.keys()), dtype=np.int64)
-            out[p + 'flow_full'] = cap['flownet2'][0][0][:, ::2, ::2].numpy()   # stride-2 subsample
+            if has_track:
+                out[p + 'panoptic_det_labels'] = pano['panoptic_det_labels'].numpy()
+                out[p + 'panoptic_det_obj_ids'] = np.asarray(pano['panoptic_det_obj_ids'].numpy())
+                out[p + 'bbox_ids'] = np.array(sorted(int(k) for k in bbox_res.keys()), dtype=np.int64)
+            else:
+                assert sorted(pano.keys()) == ['fcn_outputs', 'panoptic_cls_inds', 'panoptic_cls_prob', 'panoptic_outputs']
+                out[p + 'bbox_counts'] = np.array([len(b) for b in bbox_res], dtype=np.int64)
+            if has_flow:
+                out[p + 'flow_full'] = cap['flownet2'][0][0][:, ::2, ::2].numpy()   # stride-2 subsample
             # neck is called twice (img, ref_img): first call = target frame
             out[p + 'fpn_p2'] = cap['neck'][0][0][0, :8].numpy()          # first 8 channels of P2
             out[p + 'fpn_p5'] = cap['neck'][0][3][0].numpy()
-            out[p + 'neck_out_p2'] = cap['extra_neck'][0][0][0, :8].numpy()
-            out[p + 'neck_out_p6'] = cap['extra_neck'][0][4][0].numpy()
+            if has_flow:
+                out[p + 'neck_out_p2'] = cap['extra_neck'][0][0][0, :8].numpy()
+                out[p + 'neck_out_p6'] = cap['extra_neck'][0][4][0].numpy()
             out[p + 'fcn_score'] = cap['panopticFPN'][0][1][0].numpy()
             out[p + 'proposals'] = cap['proposals'][0].numpy()
             out[p + 'cls_score'] = cap['bbox_head'][0][0].numpy()
             out[p + 'bbox_pred'] = cap['bbox_head'][0][1].numpy()
             out[p + 'mask_pred'] = cap['mask_head'][0][:8].numpy()          # first 8 detections
-            print('frame %d: K=%d kept=%d ids=%s' % (t, cap['mask_head'][0].shape[0], len(out[p + 'panoptic_cls_inds']),
-                                                    out[p + 'panoptic_det_obj_ids'][:8]))
+            print('%s frame %d: K=%d kept=%d ids=%s' % (variant, t, cap['mask_head'][0].shape[0], len(out[p + 'panoptic_cls_inds']),
+                                                       out[p + 'panoptic_det_obj_ids'][:8] if has_track else None))
     out['meta'] = np.array([H, W, NFRAMES, SEED], dtype=np.int64)
-    path = os.path.join(HERE, 'fusetrack_clip.npz')
+    path = os.path.join(HERE, '%s_clip.npz' % variant)
     np.savez_compressed(path, **out)
     print('wrote', path, os.path.getsize(path) / 1e6, 'MB')
 
 
 if __name__ == '__main__':
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else 'fusetrack')

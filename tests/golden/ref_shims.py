@@ -256,6 +256,6 @@ def install():
     for name in ('backbones.resnet', 'necks.fpn', 'extra_necks.bfp_tcea', 'panoptic.upsnetFPN', 'anchor_heads.anchor_head',
                  'anchor_heads.rpn_head', 'roi_extractors.single_level', 'bbox_heads.convfc_bbox_head',
                  'track_heads.track_head', 'mask_heads.fcn_mask_head', 'detectors.base', 'detectors.test_mixins',
-                 'detectors.two_stage', 'detectors.panoptic_fusetrack'):
+                 'detectors.two_stage', 'detectors.panoptic_fusetrack', 'detectors.panoptic_fuse', 'detectors.panoptic_track'):
         mods[name] = importlib.import_module('mmdet.models.' + name)
     return mods

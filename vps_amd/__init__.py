@@ -10,6 +10,6 @@ from .registry import (BACKBONES, DETECTORS, EXTRA_NECKS, HEADS, NECKS, PANOPTIC
                        Registry, build_backbone, build_detector, build_extra_neck, build_from_cfg, build_head, build_neck,
                        build_panoptic, build_roi_extractor)
 from . import backbones, necks, heads, flownet2, panoptic_ops, detector  # noqa: F401,E402  (registration side effects)
-from .detector import PanopticFuseTrack  # noqa: F401,E402
+from .detector import PanopticFuse, PanopticFuseTrack, PanopticTrack  # noqa: F401,E402
 
 __version__ = '0.1.0'

@@ -27,6 +27,14 @@ from .flownet2 import FlowNet2
 from .panoptic_ops import MaskRemoval, MaskROI, panoptic_combine
 
 
+def bbox2result(bboxes, labels, num_classes):
+    """core/bbox/transforms.py:142-157: per-class list of [n, 5] arrays"""
+    if bboxes.shape[0] == 0:
+        return [np.zeros((0, 5), dtype=np.float32) for _ in range(num_classes - 1)]
+    bboxes = bboxes.cpu().numpy(); labels = labels.cpu().numpy()
+    return [bboxes[labels == i, :] for i in range(num_classes - 1)]
+
+
 def bbox2result_with_id(bboxes, labels, obj_ids, num_classes):
     """core/bbox/transforms.py:159-180"""
     if bboxes.shape[0] == 0:
@@ -37,6 +45,10 @@ def bbox2result_with_id(bboxes, labels, obj_ids, num_classes):
 
 @R.DETECTORS.register_module
 class PanopticFuseTrack(HipModule):
+    # the two sibling detectors of the reference reuse this class with one branch switched off (bottom of the file)
+    with_fusion = True        # FlowNet2 + flow-guided BFP-TCEA temporal fusion neck (panoptic_fusetrack.py:506-518)
+    with_track = True         # TrackHead + instance-id assignment (panoptic_fusetrack.py:400-469)
+
     def __init__(self, backbone, rpn_head, bbox_roi_extractor, bbox_head, mask_roi_extractor, mask_head, train_cfg,
                  test_cfg, neck=None, extra_neck=None, panoptic=None, track_head=None, shared_head=None, pretrained=None,
                  flownet_checkpoint=None):
@@ -45,12 +57,14 @@ class PanopticFuseTrack(HipModule):
         # attribute names follow two_stage.py:31-64 (they are the state_dict prefixes)
         self.backbone = R.build_backbone(backbone)
         self.neck = R.build_neck(neck)
-        self.extra_neck = R.build_extra_neck(extra_neck)
+        self.extra_neck = R.build_extra_neck(extra_neck) if self.with_fusion else None
+        assert (extra_neck is not None) == self.with_fusion and (track_head is not None) == self.with_track, \
+            '%s: extra_neck / track_head do not match the detector type' % type(self).__name__
         self.panopticFPN = R.build_panoptic(panoptic)
         self.rpn_head = R.build_head(rpn_head)
         self.bbox_roi_extractor = R.build_roi_extractor(bbox_roi_extractor)
         self.bbox_head = R.build_head(bbox_head)
-        self.track_head = R.build_head(track_head)
+        self.track_head = R.build_head(track_head) if self.with_track else None
         self.mask_roi_extractor = R.build_roi_extractor(mask_roi_extractor)
         self.mask_head = R.build_head(mask_head)
         self.train_cfg = R.ConfigDict.wrap(train_cfg) if train_cfg is not None else None
@@ -68,21 +82,23 @@ class PanopticFuseTrack(HipModule):
         self.mask_removal = MaskRemoval(fraction_threshold=0.3)
         has_flow = (self.train_cfg is not None and hasattr(self.train_cfg, 'flownet2')) or \
                    (self.test_cfg is not None and hasattr(self.test_cfg, 'flownet2'))
-        assert has_flow, 'Feature flow must be implemented.'
         self.mean = [123.675, 116.28, 103.53]
         self.std = [58.395, 57.12, 57.375]
+        self.flownet2 = None
+        if self.with_fusion:
+            assert has_flow, 'Feature flow must be implemented.'
 
-        class _Args(object):
-            rgb_max = 255.0
-            fp16 = False
-        self.flownet2 = FlowNet2(_Args())
-        # panoptic_fusetrack.py:100-106: FlowNet2 weights come from a separate cwd-relative file, loaded in __init__;
-        # load_checkpoint(model, latest.pth) afterwards may overwrite flownet2.* keys (kept: same order).
-        ck = flownet_checkpoint or osp.join(os.getcwd(), 'work_dirs', 'flownet', 'FlowNet2_checkpoint.pth.tar')
-        if osp.exists(ck):
-            self.flownet2.load_state_dict(torch.load(ck, map_location='cpu')['state_dict'])
-        else:
-            warnings.warn('FlowNet2 checkpoint %s not found: flownet2.* keeps its initial weights until a state_dict is loaded' % ck)
+            class _Args(object):
+                rgb_max = 255.0
+                fp16 = False
+            self.flownet2 = FlowNet2(_Args())
+            # panoptic_fusetrack.py:100-106: FlowNet2 weights come from a separate cwd-relative file, loaded in __init__;
+            # load_checkpoint(model, latest.pth) afterwards may overwrite flownet2.* keys (kept: same order).
+            ck = flownet_checkpoint or osp.join(os.getcwd(), 'work_dirs', 'flownet', 'FlowNet2_checkpoint.pth.tar')
+            if osp.exists(ck):
+                self.flownet2.load_state_dict(torch.load(ck, map_location='cpu')['state_dict'])
+            else:
+                warnings.warn('FlowNet2 checkpoint %s not found: flownet2.* keeps its initial weights until a state_dict is loaded' % ck)
         self.CLASSES = None
         # options
         self.reuse_ref_features = True     # False: recompute extract_feat(ref_img) every frame like the reference
@@ -104,7 +120,8 @@ class PanopticFuseTrack(HipModule):
     def pack(self, device):
         for m in (self.backbone, self.neck, self.extra_neck, self.panopticFPN, self.rpn_head, self.bbox_head,
                   self.track_head, self.mask_head, self.flownet2):
-            m.ensure_packed(device)
+            if m is not None:
+                m.ensure_packed(device)
         self._mean_t = torch.tensor(self.mean, dtype=torch.float32, device=device)
         self._std_t = torch.tensor(self.std, dtype=torch.float32, device=device)
 
@@ -173,8 +190,9 @@ class PanopticFuseTrack(HipModule):
         if ref_img is not None and isinstance(ref_img, (list, tuple)):
             ref_img = ref_img[0]
         meta = img_meta[0]
-        assert 'city' in meta['filename'] and 'iid' in meta
-        iid = meta['iid']
+        if self.with_track:
+            assert 'city' in meta['filename'] and 'iid' in meta
+        iid = meta.get('iid', -1)          # PanopticFuse runs on image pairs without a video index
         is_first = (iid % 10000) == 1
         _, _, H, W = img.shape
         im_info = np.array([[float(H), float(W), 1.0]])
@@ -190,41 +208,48 @@ class PanopticFuseTrack(HipModule):
             if self._side is None or self._side.device != dev:
                 self._side = torch.cuda.Stream(device=dev)
             side = self._side
-        # (1) flow ---------------------------------------------------------------------------------------------
-        if side is not None:
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
+        flow = cat = aux = None
+        if not self.with_fusion:
+            # PanopticTrack (panoptic_track.py:447): the FPN outputs feed the heads directly
+            levels = self.neck.run(self.backbone.run(nhwc.from_nchw(img, ws, 'img_nhwc'), ws, 'bb.'), ws, 'fpn.')
+            x = levels
+            self._mark('backbone_fpn')
+        else:
+            # (1) flow ---------------------------------------------------------------------------------------------
+            if side is not None:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    flow = self.flownet2.run(img, ref_img, self._mean_t, self._std_t, ws)
+            else:
                 flow = self.flownet2.run(img, ref_img, self._mean_t, self._std_t, ws)
-        else:
-            flow = self.flownet2.run(img, ref_img, self._mean_t, self._std_t, ws)
-        self._mark('flownet2')
-        # (2) backbone + FPN of the target frame -----------------------------------------------------------------
-        self._flip ^= 1
-        tag = 'AB'[self._flip]
-        levels = self.neck.run(self.backbone.run(nhwc.from_nchw(img, ws, 'img_nhwc'), ws, 'bb.'), ws, 'fpn.')
-        cat = self.extra_neck.gather(levels, ws, 'neck.cat' + tag)
-        C = self.extra_neck.in_channels
-        if side is not None:
-            main.wait_stream(side)
-        # flowR2T = F.interpolate(flow, 0.25, bilinear) * 0.25 written straight into the LiteFlowNet input buffer
-        nhwc.resize(flow, cat.window(C + 81, 2), 'bilinear', 0.25)
-        self._mark('backbone_fpn')
-        # reference-frame gathered feature: cached from the previous call when the frames are consecutive
-        cache = self._cache
-        if ref_feature is not None:
-            ref_bsf = nhwc.FMap(ref_feature.view(1, cat.H, cat.W, C))
-        elif self.reuse_ref_features and cache is not None and cache['iid'] + 1 == iid and not is_first and cache['shape'] == (H, W):
-            ref_bsf = cache['cat'].window(0, C)
-        elif self.reuse_ref_features and is_first:
-            ref_bsf = cat.window(0, C)        # datasets/cityscapes_vps.py:137-148: the first frame's ref is itself
-        else:
-            rl = self.neck.run(self.backbone.run(nhwc.from_nchw(ref_img, ws, 'ref_nhwc'), ws, 'rbb.'), ws, 'rfpn.')
-            ref_bsf = self.extra_neck.gather(rl, ws, 'neck.refcat').window(0, C)
-            self._mark('ref_backbone_fpn')
-        self._cache = dict(iid=iid, cat=cat, shape=(H, W))
-        # (3) temporal fusion neck -------------------------------------------------------------------------------
-        x, aux = self.extra_neck.run(levels, cat, ref_bsf, ws, 'neck.')
-        self._mark('extra_neck')
+            self._mark('flownet2')
+            # (2) backbone + FPN of the target frame -----------------------------------------------------------------
+            self._flip ^= 1
+            tag = 'AB'[self._flip]
+            levels = self.neck.run(self.backbone.run(nhwc.from_nchw(img, ws, 'img_nhwc'), ws, 'bb.'), ws, 'fpn.')
+            cat = self.extra_neck.gather(levels, ws, 'neck.cat' + tag)
+            C = self.extra_neck.in_channels
+            if side is not None:
+                main.wait_stream(side)
+            # flowR2T = F.interpolate(flow, 0.25, bilinear) * 0.25 written straight into the LiteFlowNet input buffer
+            nhwc.resize(flow, cat.window(C + 81, 2), 'bilinear', 0.25)
+            self._mark('backbone_fpn')
+            # reference-frame gathered feature: cached from the previous call when the frames are consecutive
+            cache = self._cache
+            if ref_feature is not None:
+                ref_bsf = nhwc.FMap(ref_feature.view(1, cat.H, cat.W, C))
+            elif self.reuse_ref_features and iid >= 0 and cache is not None and cache['iid'] + 1 == iid and not is_first and cache['shape'] == (H, W):
+                ref_bsf = cache['cat'].window(0, C)
+            elif self.reuse_ref_features and iid >= 0 and is_first:
+                ref_bsf = cat.window(0, C)        # datasets/cityscapes_vps.py:137-148: the first frame's ref is itself
+            else:
+                rl = self.neck.run(self.backbone.run(nhwc.from_nchw(ref_img, ws, 'ref_nhwc'), ws, 'rbb.'), ws, 'rfpn.')
+                ref_bsf = self.extra_neck.gather(rl, ws, 'neck.refcat').window(0, C)
+                self._mark('ref_backbone_fpn')
+            self._cache = dict(iid=iid, cat=cat, shape=(H, W))
+            # (3) temporal fusion neck -------------------------------------------------------------------------------
+            x, aux = self.extra_neck.run(levels, cat, ref_bsf, ws, 'neck.')
+            self._mark('extra_neck')
         # (4) semantic head --------------------------------------------------------------------------------------
         if side is not None:
             side.wait_stream(main)
@@ -246,9 +271,12 @@ class PanopticFuseTrack(HipModule):
         self._mark('bbox_track')
         det_bboxes, det_labels, det_obj_ids = det['det_bboxes'], det['det_labels'], det['det_obj_ids']
         cls_prob, mask_rois, cls_idx = det['cls_prob'], det['det_rois'], det['cls_idx']
-        if defer_tracking:
-            det_obj_ids = np.full((det_bboxes.size(0),), -1, dtype=np.int64)
-        bbox_results = bbox2result_with_id(det_bboxes, det_labels, det_obj_ids, self.bbox_head.num_classes)
+        if not self.with_track:
+            bbox_results = bbox2result(det_bboxes, det_labels, self.bbox_head.num_classes)      # panoptic_fuse.py:425-426
+        else:
+            if defer_tracking:
+                det_obj_ids = np.full((det_bboxes.size(0),), -1, dtype=np.int64)
+            bbox_results = bbox2result_with_id(det_bboxes, det_labels, det_obj_ids, self.bbox_head.num_classes)
         mask_results = [[] for _ in range(self.mask_head.num_classes - 1)]       # simple_test_mask: `or True` stub
         # (8) mask head ------------------------------------------------------------------------------------------
         mask_feats = self.mask_roi_extractor.run(x, mask_rois)
@@ -279,10 +307,11 @@ class PanopticFuseTrack(HipModule):
             'fcn_outputs': sem,
             'panoptic_cls_inds': cls_idx[keep_t],
             'panoptic_cls_prob': cls_prob[keep_t],
-            'panoptic_det_labels': det_labels[keep_t],
-            'panoptic_det_obj_ids': torch.from_numpy(np.asarray(det_obj_ids).astype(np.int64)).to(dev)[keep_t],
             'panoptic_outputs': pan,
         }
+        if self.with_track:                                    # panoptic_fuse.py:467-472 returns the four keys above only
+            pano_results['panoptic_det_labels'] = det_labels[keep_t]
+            pano_results['panoptic_det_obj_ids'] = torch.from_numpy(np.asarray(det_obj_ids).astype(np.int64)).to(dev)[keep_t]
         self._track_record = dict(det_bboxes=det_bboxes, det_labels=det_labels, cls_prob=cls_prob, emb=det['emb'],
                                   keep_inds=keep_inds)
         self._aux = dict(flow=flow, levels=levels, cat=cat, neck_out=x, neck_aux=aux, fcn_score=fcn_score, det=det,
@@ -386,10 +415,32 @@ class PanopticFuseTrack(HipModule):
         det_roi_feats = self.bbox_roi_extractor.run(x, det_rois)
         det_bboxes = det_rois[:, 1:]
         K = det_bboxes.size(0)
-        emb = self.track_head.embed(det_roi_feats, ws)
-        det_obj_ids, comp_scores = None, None
-        if not defer_tracking:
+        det_obj_ids, comp_scores, emb = None, None, None
+        if self.with_track:
+            emb = self.track_head.embed(det_roi_feats, ws)
+        if self.with_track and not defer_tracking:
             det_obj_ids, comp_scores = self._assign_ids(det_bboxes, det_labels, cls_prob, emb, is_first, ws)
         return dict(det_bboxes=det_bboxes, det_labels=det_labels, det_obj_ids=det_obj_ids, cls_score=cls_score,
                     bbox_pred=bbox_pred, cls_prob=cls_prob, det_rois=det_rois, cls_idx=cls_idx, comp_scores=comp_scores,
                     det_roi_feats=det_roi_feats, emb=emb)
+
+
+@R.DETECTORS.register_module
+class PanopticFuse(PanopticFuseTrack):
+    """mmdet/models/detectors/panoptic_fuse.py: the same path without the track head — per-class box
+    lists instead of id-keyed boxes, `pano_results` without `panoptic_det_labels` / `panoptic_det_obj_ids`
+    (panoptic_fuse.py:399-472). It runs on image pairs whose reference frame is arbitrary, so the reference-feature cache
+    is off by default."""
+    with_track = False
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.reuse_ref_features = False
+
+
+@R.DETECTORS.register_module
+class PanopticTrack(PanopticFuseTrack):
+    """mmdet/models/detectors/panoptic_track.py: no FlowNet2 and no temporal fusion neck — the FPN
+    outputs feed the semantic / RPN / box / track / mask heads directly (panoptic_track.py:443-536); tracking as in
+    PanopticFuseTrack (the two `simple_test_bboxes` are identical)."""
+    with_fusion = False
