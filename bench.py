@@ -62,6 +62,8 @@ def main():
     ap.add_argument('--height', type=int, default=H)
     ap.add_argument('--width', type=int, default=W)
     ap.add_argument('--prec', default='bf16x6', choices=['f32', 'bf16x3', 'bf16x6'], help='arithmetic of the dense contractions')
+    ap.add_argument('--variant', default='fusetrack', choices=['fusetrack', 'fuse', 'track'],
+                    help='detector (SURVEY 8(f) row 4): the headline metric is fusetrack; the variants are single-GPU only')
     ap.add_argument('--conv-table', default=None, help='write the per-layer-shape conv timing table of one frame here')
     args = ap.parse_args()
 
@@ -89,7 +91,8 @@ def main():
     from vps_amd import hip, nhwc, synth
     nhwc.DEFAULT_PREC = {'f32': hip.PREC_F32, 'bf16x3': hip.PREC_BF16X3, 'bf16x6': hip.PREC_BF16X6}[args.prec]
     Hh, Ww = args.height, args.width
-    cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', 'fusetrack.py'))
+    assert args.variant == 'fusetrack' or world == 1
+    cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', args.variant + '.py'))
     model = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
     synth.load_synth(model, args.seed)
 
@@ -104,7 +107,7 @@ def main():
         ref = frames[(t - 1) % len(frames)] if t else frames[0]
         return model(return_loss=False, rescale=True, img=[img], img_meta=[[metas[t]]], ref_img=[ref])
 
-    C = model.extra_neck.in_channels
+    C = model.extra_neck.in_channels if model.extra_neck is not None else 0
 
     def handoff():
         """clip sharding (vps_amd/clip_shard.py): every rank computes the gathered pre-neck feature of its LAST frame first
@@ -199,7 +202,7 @@ def main():
     if rank == 0:
         fps = world * args.steps / dt
         line = {
-            'metric': 'frames/sec FuseTrack 1024x2048', 'value': round(fps, 3), 'unit': 'frames/s', 'n_gpus': world,
+            'metric': 'frames/sec %s 1024x2048' % {'fusetrack': 'FuseTrack', 'fuse': 'PanopticFuse', 'track': 'PanopticTrack'}[args.variant], 'value': round(fps, 3), 'unit': 'frames/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'f32': 'f32', 'bf16x6': 'f32-grade: bf16x6 split operands on MFMA, f32 accumulate',
