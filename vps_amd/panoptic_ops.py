@@ -197,7 +197,9 @@ def panoptic_combine(fcn_score, mask_rois_np, cls_idx_np, ref_boxes, keep_inds, 
     pan = ws.get('pan.out', (1, H, W), dtype=torch.uint8, zero=False)
     sem = ws.get('sem.out', (1, H, W), dtype=torch.uint8, zero=False)
     S = mask_prob.shape[-1]
-    hip.check(hip.load().vps_panoptic_combine(fcn_score.ptr(), fcn_score.ld, fcn_score.H, fcn_score.W, num_classes, num_stuff,
-                                              hip.ptr(inst_d), k, hip.ptr(mask_prob), S, hip.ptr(pan), hip.ptr(sem), H, W,
-                                              hip.stream_ptr()), 'vps_panoptic_combine')
+    rc = hip.load().vps_panoptic_combine(fcn_score.ptr(), fcn_score.ld, fcn_score.H, fcn_score.W, num_classes, num_stuff,
+                                         hip.ptr(inst_d), k, hip.ptr(mask_prob), S, hip.ptr(pan), hip.ptr(sem), H, W,
+                                         hip.stream_ptr())
+    hip.check(rc, 'vps_panoptic_combine(k=%d, S=%d, mask_prob %s, score %dx%d ld %d, out %dx%d, classes %d/%d)' % (
+        k, S, tuple(mask_prob.shape), fcn_score.H, fcn_score.W, fcn_score.ld, H, W, num_stuff, num_classes))
     return pan, sem
