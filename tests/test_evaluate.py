@@ -36,6 +36,34 @@ def test_oracle_matches_reference_function():
     assert n == 9 and int(np.load(GOLD)['clip1_nf2_counts'][:, 1].sum()) > 0        # the golden clips do contain matches
 
 
+def test_host_matching_logic_with_numpy_counts(monkeypatch):
+    """CPU coverage of vps_amd/evaluate.py's host side (segment bookkeeping, window sums, matching): the per-frame device count
+    is replaced by its NumPy definition and the result must still equal the reference function's statistics"""
+    from vps_amd import evaluate as ev
+
+    def count(self, gt_json, pred_json, gt_pan, pred_pan, categories):
+        ids = lambda q: (lambda u: u[:, :, 0] + u[:, :, 1] * 256 + u[:, :, 2] * 65536)(np.asarray(q).astype(np.int64))
+        g, p = ids(gt_pan), ids(pred_pan)
+        gt_segms, pred_segms = ev._merged(gt_json), ev._merged(pred_json)
+        labels, cnt = np.unique(p, return_counts=True)
+        pred_set = set(el['id'] for el in pred_json['segments_info'])
+        for label, c in zip(labels, cnt):
+            label = int(label)
+            if label not in pred_segms:
+                assert label == 0
+                continue
+            pred_segms[label]['area'] = int(c); pred_set.remove(label)
+        assert not pred_set
+        listed_g = set([0] + [el['id'] for el in gt_json['segments_info']])
+        lab, c2 = np.unique(g * (1 << 24) + p, return_counts=True)
+        pairs = {(int(l >> 24), int(l & ((1 << 24) - 1))): int(c) for l, c in zip(lab, c2) if int(l >> 24) in listed_g}
+        return gt_segms, pred_segms, pairs
+    monkeypatch.setattr(ev.FrameCounts, 'count', count)
+    monkeypatch.setattr(ev.FrameCounts, '__init__', lambda self, device='cuda': None)
+    for ci, nf, frames, counts, iou in _clips():
+        _check(ev.vpq_compute_single_core(frames, CATS, nframes=nf, device='cpu'), counts, iou, (ci, nf))
+
+
 @pytest.mark.gpu
 def test_device_counted_vpq_matches_reference_function(dev):
     from vps_amd import evaluate as ev
