@@ -7,6 +7,7 @@ zero (buffers come from `Workspace.get(..., zero=True)` once and pads are never 
 """
 import ctypes
 import math
+import os
 from ctypes import c_float, c_int, c_void_p
 
 import torch
@@ -18,8 +19,13 @@ def _ceil(a, b):
     return (a + b - 1) // b * b
 
 
-# arithmetic of every PackedConv created without an explicit `prec` (hip.PREC_F32 exact / PREC_BF16X3 / PREC_BF16X6)
-DEFAULT_PREC = hip.PREC_F32
+# arithmetic of every PackedConv created without an explicit `prec` (hip.PREC_F32 exact / PREC_BF16X3 / PREC_BF16X6).
+# The library default is the exact fp32 mode; VPS_PREC=bf16x6 (fp32-grade, what bench.py measures) / bf16x3 / f32 selects it
+# for an unmodified caller such as tools/test_vpq.py.
+_PREC_NAMES = {'f32': hip.PREC_F32, 'bf16x3': hip.PREC_BF16X3, 'bf16x6': hip.PREC_BF16X6}
+if os.environ.get('VPS_PREC', 'f32') not in _PREC_NAMES:
+    raise ValueError('VPS_PREC must be one of %s' % sorted(_PREC_NAMES))
+DEFAULT_PREC = _PREC_NAMES[os.environ.get('VPS_PREC', 'f32')]
 
 # bench.py sets this to a list to time every vps_conv2d launch with HIP events on the launch stream:
 # entries (algorithmic_flops, start_event, end_event, shape tag, algorithmic_bytes). None = no instrumentation (the default).
