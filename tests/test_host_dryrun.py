@@ -1,0 +1,92 @@
+"""CPU coverage of the HOST side of the HIP path: the three detectors run a 3-frame clip with every kernel launch replaced by a
+recording stub (outputs are meaningless; there is no CPU compute path in the product — the stubs live in this test only).
+Checks: the Python control flow of simple_test (fusion / tracking branches, reference-feature cache, MaskROI / MaskRemoval /
+tracker host logic, result assembly) executes, results have the reference's keys and shapes, every symbol the host calls is
+declared in include/vps_hip.h, and the persistent workspace stops growing after the first frames (up to the small per-detection buffers)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import vps_amd
+from vps_amd import hip, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _RecordingLib:
+    def __init__(self):
+        self.called = set()
+
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        self.called.add(name)
+        impl = type(self).__dict__.get('_' + name)
+        return (lambda *a, **k: impl(self, *a, **k)) if impl is not None else (lambda *a, **k: 0)
+
+    # the few launches whose results steer host control flow get plausible values
+    def _vps_nms_batched(self, boxes, nb, nmax, counts, thr, mask, keep, nkeep, stream):
+        cnt = (ctypes.c_int32 * nb).from_address(counts.value)
+        kp = (ctypes.c_int32 * (nb * nmax)).from_address(keep.value)
+        nk = (ctypes.c_int32 * nb).from_address(nkeep.value)
+        for b in range(nb):
+            k = min(cnt[b], 40)
+            nk[b] = k
+            for i in range(k):
+                kp[b * nmax + i] = i
+        return 0
+
+    def _vps_row_softmax(self, inp, out, rows, cols, mode, stream):
+        r = np.random.default_rng(rows).random((rows, cols)).astype(np.float32)
+        r /= r.sum(1, keepdims=True)
+        r[:, min(3, cols - 1)] += (np.arange(rows) % 7 == 0) * 0.9
+        if mode == 1:
+            r = np.log(r)
+        ctypes.memmove(out.value, r.ctypes.data, r.nbytes)
+        return 0
+
+    def _vps_mask_level(self, *a):
+        flags, nlevel, level = a[-2], a[6], a[5]
+        lv = (ctypes.c_int32 * nlevel).from_address(level.value)
+        for i in range(nlevel):
+            (ctypes.c_int32 * 1).from_address(flags.value + 4 * lv[i])[0] = 1
+        return 0
+
+
+class _FakeCuda(torch.Tensor):
+    is_cuda = property(lambda s: True)
+
+
+@pytest.mark.parametrize('variant,keys', [
+    ('fusetrack', ['fcn_outputs', 'panoptic_cls_inds', 'panoptic_cls_prob', 'panoptic_det_labels', 'panoptic_det_obj_ids', 'panoptic_outputs']),
+    ('fuse', ['fcn_outputs', 'panoptic_cls_inds', 'panoptic_cls_prob', 'panoptic_outputs']),
+    ('track', ['fcn_outputs', 'panoptic_cls_inds', 'panoptic_cls_prob', 'panoptic_det_labels', 'panoptic_det_obj_ids', 'panoptic_outputs'])])
+def test_host_control_flow_with_stubbed_launches(monkeypatch, variant, keys):
+    lib = _RecordingLib()
+    monkeypatch.setattr(hip, 'load', lambda: lib)
+    monkeypatch.setattr(hip, 'ptr', lambda t: None if t is None else ctypes.c_void_p(t.data_ptr()))
+    monkeypatch.setattr(hip, 'stream_ptr', lambda: None)
+    monkeypatch.setattr(hip, 'conv2d', lambda d: lib.called.add('vps_conv2d'))
+    cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', variant + '.py'))
+    m = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    m.overlap_streams = False                      # torch.cuda streams need a device
+    synth.load_synth(m, 0)
+    H, W = 128, 256
+    fr = synth.synth_clip(H, W, 3, 0)
+    sizes = []
+    for t in range(3):
+        out = m(return_loss=False, rescale=True, img=[fr[t].as_subclass(_FakeCuda)], img_meta=[[synth.img_meta(H, W, 10001 + t)]],
+                ref_img=[fr[t - 1 if t else 0]])
+        assert len(out) == 3 and sorted(out[2].keys()) == keys
+        assert tuple(out[2]['panoptic_outputs'].shape) == (1, H, W) and tuple(out[2]['fcn_outputs'].shape) == (1, H, W)
+        n = out[2]['panoptic_cls_inds'].numel()
+        assert all(out[2][k].numel() == n for k in keys if k.startswith('panoptic_') and k != 'panoptic_outputs')
+        assert isinstance(out[0], list if variant == 'fuse' else dict)
+        sizes.append(m._ws.nbytes())
+    assert abs(sizes[2] - sizes[1]) < 1e-3 * sizes[1], 'the workspace must be persistent (only the per-detection buffers may resize)'
+    undeclared = sorted(n for n in lib.called if n not in hip.SYMBOLS)
+    assert not undeclared, undeclared
+    assert 'vps_conv2d' in lib.called and ('vps_correlation' in lib.called) == (variant != 'track')
