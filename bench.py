@@ -3,16 +3,22 @@
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one frame of PanopticFuseTrack.simple_test (target frame + previous frame: FlowNet2, ResNet-50-FPN, BFP-TCEA
-fusion, UPSNet semantic head, RPN, RoIAlign, bbox / track / mask heads, MaskRemoval, panoptic combine) with inputs
-already resident in HBM. Weights are synthetic (vps_amd.synth; no checkpoints offline) and scaled so the heads emit the
-configured maximum of ~100 detections per frame. One process per GPU; each rank runs its own contiguous shard of the clip
-(weak scaling, no data-path collective inside a shard; the shard-boundary feature hand-off is in vps_amd/clip_shard.py).
+A "step" is one frame of PanopticFuseTrack.simple_test per GPU (target frame + previous frame: FlowNet2, ResNet-50-FPN,
+BFP-TCEA fusion, UPSNet semantic head, RPN, RoIAlign, bbox / track / mask heads, MaskRemoval, panoptic combine, instance-id
+assignment) with inputs already resident in HBM. Weights are synthetic (vps_amd.synth; no checkpoints offline).
+
+The timed region drives the product's clip pipeline, vps_amd.clip_shard.ClipShardRunner (BASELINE config 4): ONE synthetic
+clip of N*K frames is sharded contiguously over the N ranks (K frames each: per-GPU work fixed as N grows -> "weak"), every
+shard boundary costs one point-to-point RCCL send/recv of the 134 MB gathered pre-neck feature, and the sequential tracker
+replay on rank 0 plus the gather of all per-frame results are INSIDE the timed region. At N=1 it is the plain sequential
+path. After the timed region (untimed extras, rank 0): an instrumented frame for the roofline numbers, micro-timings of the
+HBM-bound kernels, the fixed 30-frame clip of config 4 (strong scaling, field `clip30`), and the CPU baseline.
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 import warnings
@@ -26,30 +32,121 @@ warnings.simplefilter('ignore')
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA dense peak (not the 2:1-sparse headline)
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured with a float4 copy)
 H, W = 1024, 2048
+WORKLOADS = {
+    'fusetrack': 'FlowNet2 + ResNet50-FPN + BFP-TCEA + UPSNet panoptic head + RPN / bbox / track / mask heads',
+    'fuse': 'PanopticFuse: FlowNet2 + ResNet50-FPN (both frames) + BFP-TCEA + UPSNet panoptic head + RPN / bbox / mask heads, no track head',
+    'track': 'PanopticTrack: ResNet50-FPN + UPSNet panoptic head + RPN / bbox / track / mask heads, no FlowNet2 / temporal fusion',
+}
 
 
 def cpu_baseline(seed):
-    """the oracle (CPU restatement of the reference path) on a bounded sample of the same workload, rank 0 only"""
+    """the oracle (CPU restatement of the reference path, kind "port") on the host cores of this box, rank 0 only:
+    ONE real 1024x2048 frame pair (the benched size, timed once: ~10-40 s) and, for the spread, the median of 3 runs of a
+    256x512 pair scaled by pixel count."""
     from oracle.fusetrack import FuseTrackOracle
     import vps_amd
     from vps_amd import synth
-    h, w = 256, 512
     cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', 'fusetrack.py'))
     model = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
     sd = synth.synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, seed)
     o = FuseTrackOracle(sd)
-    frames = synth.synth_clip(h, w, 2, seed)
-    cores = torch.get_num_threads()
-    with torch.no_grad():
-        o.simple_test(frames[0], frames[0], True)                 # warm-up (first frame of the clip)
-        t0 = time.perf_counter()
-        o.simple_test(frames[1], frames[0], False)
-        dt = time.perf_counter() - t0
-    frac = (h * w) / float(H * W)
-    return dict(value=round(frac / dt, 5), unit='frames/s', cores=cores, kind='port',
-                sample='1 FuseTrack frame pair at %dx%d (=%.4f of the %dx%d frame, scaled by pixel count), oracle/ on '
-                       'PyTorch-CPU fp32, %.1f s' % (h, w, frac, H, W, dt))
+    old = torch.get_num_threads()
+    cores = max(1, min(64, (os.cpu_count() or 2) // 2))        # one thread per physical core; SMT siblings slow the small convs
+    torch.set_num_threads(cores)
+    try:
+        h, w = 256, 512
+        frames = synth.synth_clip(h, w, 2, seed)
+        small = []
+        with torch.no_grad():
+            o.simple_test(frames[0], frames[0], True)                 # warm-up (first frame of the clip)
+            for _ in range(3):
+                o.prev_bboxes = None
+                o.simple_test(frames[0], frames[0], True)
+                t0 = time.perf_counter()
+                o.simple_test(frames[1], frames[0], False)
+                small.append(time.perf_counter() - t0)
+            frames = synth.synth_clip(H, W, 2, seed)
+            o.prev_bboxes = None
+            o.simple_test(frames[0], frames[0], True)                 # untimed: builds the tracker memory (K = 100)
+            t0 = time.perf_counter()
+            o.simple_test(frames[1], frames[0], False)
+            dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(old)
+    med = statistics.median(small)
+    return dict(value=round(1.0 / dt, 5), unit='frames/s', cores=cores, kind='port',
+                sample='1 real FuseTrack frame pair at %dx%d (the benched size), oracle/ on PyTorch-CPU fp32, %d threads, timed once: %.1f s; '
+                       'spread: 256x512 pair x3, median %.2f s (min %.2f max %.2f) = %.5f frames/s scaled by pixel count'
+                       % (H, W, cores, dt, med, min(small), max(small), (h * w) / float(H * W) / med))
+
+
+def hbm_kernels(dev):
+    """achieved GB/s of the HBM-bound warp / gather kernels at the BASELINE shapes: algorithmic bytes divided by
+    the average launch duration, HIP events on the launch stream (torch's current stream), 20 launches after 3 warm-ups."""
+    from vps_amd import hip, nhwc
+    from vps_amd.pipeline import DeviceImagePrep
+    ws = nhwc.Workspace(dev)
+    torch.manual_seed(0)
+
+    def fm(name, h, w, c, ld=None, scale=1.0):
+        m = ws.fmap(name, 1, h, w, c, ld)
+        m.t.copy_(torch.randn(m.t.shape, device=dev) * scale)
+        return m
+
+    def timed(fn, n=20):
+        for _ in range(3):
+            fn()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e-3
+
+    out = {}
+
+    def add(name, nbytes, fn, note):
+        dt = timed(fn)
+        out[name] = dict(us=round(dt * 1e6, 1), algorithmic_MB=round(nbytes / 1e6, 1), achieved_GBs=round(nbytes / dt / 1e9, 1),
+                         frac_of_8TBs=round(nbytes / dt / 1e9 / PEAK_HBM_GBS, 4), shape=note)
+
+    h4, w4 = H // 4, W // 4
+    # flow-guided feature warp (flow_modules.py:126-148) @P2: read 256 ch + 2 ch flow, write 256 ch
+    x = fm('x', h4, w4, 256); fl = fm('fl', h4, w4, 2, 4, 3.0); o = fm('o', h4, w4, 256)
+    add('flow_warp', 4.0 * h4 * w4 * (256 + 2 + 256), lambda: nhwc.flow_warp(x, fl, o), '256ch @%dx%d' % (h4, w4))
+    # correlation, LiteFlowNetCorr: 2x256 ch in, 81 ch out @P2; FlowNetC: 2x256 ch in, 441 out @128x256
+    b = fm('b', h4, w4, 256); c81 = ws.fmap('c81', 1, h4, w4, 81)
+    add('correlation_lite_81ch', 4.0 * h4 * w4 * (512 + 81), lambda: nhwc.correlation(x, b, c81, 4, 1), '2x256ch -> 81ch @%dx%d' % (h4, w4))
+    h8, w8 = H // 8, W // 8
+    a8 = fm('a8', h8, w8, 256); b8 = fm('b8', h8, w8, 256); c441 = ws.fmap('c441', 1, h8, w8, 441)
+    add('correlation_flownetc_441ch', 4.0 * h8 * w8 * (512 + 441), lambda: nhwc.correlation(a8, b8, c441, 20, 2), '2x256ch -> 441ch @%dx%d' % (h8, w8))
+    # FlowNet2 stage kernel (upsample x4 + resample2d + 2x channelnorm + concat, flownet2.py:142-187): ~8 ch read + <=7 ch written @full res
+    lib = hip.load()
+    x6 = fm('x6', H, W, 6, 8); flo = fm('flo', h4, w4, 2, 4, 0.2); cc = ws.fmap('cc', 1, H, W, 12)
+    add('flow_stage', 4.0 * (H * W * (6 + 6) + h4 * w4 * 2), lambda: hip.check(lib.vps_flow_stage(
+        x6.ptr(), x6.ld, flo.ptr(), flo.ld, flo.coff, H, W, 0, 20.0, 0, cc.ptr(), cc.ld, 9, 20.0, 6, 11, -1, -1, hip.stream_ptr()), 'stage'),
+        'x6 + flow/4 -> 6 of 12 concat channels @%dx%d' % (H, W))
+    # RoIAlign 1000 x 7x7 x 256 over P2..P5 (output-bound)
+    lv = [fm('l%d' % s, H // s, W // s, 256) for s in (4, 8, 16, 32)]
+    rg = np.random.default_rng(0)
+    cx = rg.uniform(0, W, 1000); cy = rg.uniform(0, H, 1000); s = np.exp(rg.uniform(np.log(16), np.log(512), 1000))
+    rois = torch.tensor(np.stack([np.zeros(1000), np.clip(cx - s / 2, 0, W - 1), np.clip(cy - s / 2, 0, H - 1), np.clip(cx + s / 2, 0, W - 1),
+                                  np.clip(cy + s / 2, 0, H - 1)], 1), dtype=torch.float32, device=dev)
+    ro = torch.empty(1000, 7, 7, 256, device=dev)
+    add('roi_align_1000x7x7', 4.0 * 1000 * 49 * 256, lambda: nhwc.roi_align(lv, [4, 8, 16, 32], rois, 7, out=ro), '1000 rois x 7x7 x 256ch, 4 levels')
+    # BFP gather (bfp_tcea.py:96-109): 5 levels read, 1 written @P2
+    lv5 = lv + [fm('l64', H // 64, W // 64, 256)]
+    go = ws.fmap('go', 1, h4, w4, 256)
+    add('bfp_gather', 4.0 * 256 * (sum((H // s) * (W // s) for s in (4, 8, 16, 32, 64)) + h4 * w4), lambda: nhwc.bfp_gather(lv5, go), '5 levels -> 256ch @%dx%d' % (h4, w4))
+    # image prep (Normalize + Pad + ImageToTensor): uint8 HWC in, fp32 CHW out
+    img = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device=dev)
+    prep = DeviceImagePrep(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True, size_divisor=32, device=dev)
+    add('image_prep', 1.0 * H * W * 3 + 4.0 * H * W * 3, lambda: prep.prep(img), 'uint8 %dx%dx3 -> fp32 3x%dx%d' % (H, W, H, W))
+    return out
 
 
 def main():
@@ -59,12 +156,14 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the untimed extras (hbm kernel table, 30-frame clip)')
     ap.add_argument('--height', type=int, default=H)
     ap.add_argument('--width', type=int, default=W)
     ap.add_argument('--prec', default='bf16x6', choices=['f32', 'bf16x3', 'bf16x6'], help='arithmetic of the dense contractions')
     ap.add_argument('--variant', default='fusetrack', choices=['fusetrack', 'fuse', 'track'],
                     help='detector (SURVEY 8(f) row 4): the headline metric is fusetrack; the variants are single-GPU only')
     ap.add_argument('--conv-table', default=None, help='write the per-layer-shape conv timing table of one frame here')
+    ap.add_argument('--single-stream', action='store_true', help='run every frame on one stream (for kernel traces whose durations add up)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -79,6 +178,7 @@ def main():
         local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get('VPS_BENCH_BACKEND', 'nccl')      # 'nccl' IS RCCL on ROCm
@@ -89,62 +189,58 @@ def main():
 
     import vps_amd
     from vps_amd import hip, nhwc, synth
+    from vps_amd.clip_shard import ClipShardRunner, DetectorBackend, partition
     nhwc.DEFAULT_PREC = {'f32': hip.PREC_F32, 'bf16x3': hip.PREC_BF16X3, 'bf16x6': hip.PREC_BF16X6}[args.prec]
     Hh, Ww = args.height, args.width
     assert args.variant == 'fusetrack' or world == 1
     cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', args.variant + '.py'))
     model = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
     synth.load_synth(model, args.seed)
+    if args.single_stream:
+        model.overlap_streams = False
 
-    # this rank's shard of the synthetic clip: warmup + steps consecutive frames, resident in HBM before timing
-    nfr = args.warmup + args.steps + 1
-    base = rank * 100
-    frames = [f.to(dev) for f in synth.synth_clip(Hh, Ww, min(nfr, 8), args.seed + rank)]
-    metas = [synth.img_meta(Hh, Ww, 10000 * (rank + 1) + t + 1) for t in range(nfr)]
+    # the synthetic clip: 8 distinct frames resident in HBM before timing, cycled (frame t = pool[t % 8])
+    pool = [f.to(dev) for f in synth.synth_clip(Hh, Ww, 8, args.seed)]
 
-    def step(t):
-        img = frames[t % len(frames)]
-        ref = frames[(t - 1) % len(frames)] if t else frames[0]
-        return model(return_loss=False, rescale=True, img=[img], img_meta=[[metas[t]]], ref_img=[ref])
+    def load_frame(t):
+        return pool[t % len(pool)]
 
-    C = model.extra_neck.in_channels if model.extra_neck is not None else 0
+    def plain_step(t, vid):
+        img = load_frame(t)
+        ref = load_frame(t - 1) if t else img
+        return model(return_loss=False, rescale=True, img=[img], img_meta=[[synth.img_meta(Hh, Ww, 10000 * vid + t + 1)]], ref_img=[ref])
 
-    def handoff():
-        """clip sharding (vps_amd/clip_shard.py): every rank computes the gathered pre-neck feature of its LAST frame first
-        and passes it to the next rank with ONE point-to-point send/recv (RCCL over the direct xGMI link); the receiver
-        uses it as ref_bsf of its first frame instead of recomputing ResNet+FPN on the previous image."""
-        if world == 1:
-            return None
-        ops, buf, feat = [], None, None
-        if rank < world - 1:
-            feat = model.gathered_feature(frames[(nfr - 1) % len(frames)])
-            ops.append(dist.P2POp(dist.isend, feat, rank + 1))
-        if rank > 0:
-            buf = torch.empty(1, Hh // 4, Ww // 4, C, dtype=torch.float32, device=dev)
-            ops.append(dist.P2POp(dist.irecv, buf, rank - 1))
-        for r in dist.batch_isend_irecv(ops):
-            r.wait()
-        return buf
+    use_runner = args.variant == 'fusetrack'
+    runner = ClipShardRunner(DetectorBackend(model, Hh, Ww), rank, world, dist, dev) if use_runner else None
 
-    t = 0
-    handoff()                                       # untimed: RCCL p2p communicator setup
-    for _ in range(args.warmup):
-        step(t); t += 1
+    def reset():
+        model._cache = None; model._handoff = None
+        model.reset_tracker()
+
+    # ---- warm-up: W frames per rank through the same pipeline (also sets up the RCCL p2p communicators) -------------------------
+    if use_runner:
+        reset()
+        runner.run(load_frame, max(args.warmup, 1) * world, video_id=1)
+    else:
+        for t in range(args.warmup):
+            plain_step(t, 1)
+    reset()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # ---- timed region: exactly K frames per rank --------------------------------------------------------------------------------
     t0 = time.perf_counter()
     ndet = 0
-    ref_feature = handoff()                         # timed: one hand-off per shard (rank > 0 receives)
-    for i in range(args.steps):
-        if i == 0 and ref_feature is not None:
-            img = frames[t % len(frames)]
-            out = model.simple_test(img, [metas[t]], ref_img=[frames[(t - 1) % len(frames)]], ref_feature=ref_feature)
-        else:
-            out = step(t)
-        t += 1
-        ndet += int(out[2]['panoptic_cls_inds'].numel())
+    if use_runner:
+        outs = runner.run(load_frame, args.steps * world, video_id=2)
+        if rank == 0:
+            assert len(outs) == args.steps * world
+            ndet = sum(int(o['panoptic_cls_inds'].numel()) for o in outs)
+    else:
+        for t in range(args.steps):
+            out = plain_step(t, 2)
+            ndet += int(out[2]['panoptic_cls_inds'].numel())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -154,13 +250,40 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    total_frames = args.steps * world
 
-    # ---- instrumented extra frame (outside the timed region): per-stage and per-conv-launch HIP events ----------
-    roof, stages = None, None
+    # ---- untimed: BASELINE config 4 as stated — the fixed 30-frame clip over N GPUs (strong scaling) ----------------------------
+    clip30 = None
+    if use_runner and not args.no_extras:
+        reset()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        c0 = time.perf_counter()
+        o30 = runner.run(load_frame, 30, video_id=3)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        c30 = time.perf_counter() - c0
+        if world > 1:
+            tm = torch.tensor([c30], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            c30 = float(tm.item())
+        if rank == 0:
+            sig = [int(np.asarray(o['panoptic_det_obj_ids']).astype(np.int64).sum()) for o in o30]
+            clip30 = dict(frames=30, seconds=round(c30, 4), frames_per_s=round(30.0 / c30, 3), scaling='strong',
+                          shards=[b - a for a, b in partition(30, world)],
+                          note='one 30-frame synthetic clip over %d GPU(s): %d feature hand-off(s), tracker replay on rank 0 and result gather inside' % (world, world - 1),
+                          id_checksum=int(sum(sig)))
+
+    # ---- instrumented extra frame (outside the timed region): per-stage and per-conv-launch HIP events, ONE stream ---------------
+    roof, stages, hbm = None, None, None
     if rank == 0:
+        reset()
+        plain_step(0, 4); plain_step(1, 4)
         model.profile = {}
         nhwc.CONV_TRACE = []
-        step(t)
+        plain_step(2, 4)
         torch.cuda.synchronize()
         stages = {k: round(v, 3) for k, v in model.stage_times_ms()}
         fl = sum(c[0] for c in nhwc.CONV_TRACE)
@@ -178,43 +301,55 @@ def main():
         nhwc.CONV_TRACE = None
         model.profile = None
         ach = fl / (ms * 1e-3) / 1e12
-        # achieved = algorithmic FLOPs (2*MAC, unpadded) / summed launch time of the conv kernel.
-        # f32 and bf16x6 deliver fp32-grade arithmetic, so they are priced against the fp32 matrix peak (157.3): that is the
-        # roofline of an fp32 convolution on this chip. bf16x6 reaches it by executing 6 bf16 MFMA products per fp32 product;
-        # the utilisation of the bf16 matrix pipe itself is reported next to it (matrix_pipe_*). bf16x3 is not fp32-grade
-        # and is priced against the bf16 peak directly.
+        # achieved = ALGORITHMIC FLOPs (2*MAC, unpadded: SURVEY 8(d)) / summed launch time of the conv family (HIP events around
+        # every launch of the instrumented single-stream frame). peak = what the matrix pipe the kernels ISSUE TO can deliver for
+        # that arithmetic: an fp32-grade product costs `nprod` bf16 MFMA products, so peak = dense bf16 MFMA peak / nprod
+        # (2500 / 6 = 416.7 for bf16x6, 2500 / 3 for bf16x3); the exact mode issues to the fp32 MFMA pipe (157.3).
+        # frac therefore equals executed MFMA TFLOP/s / 2500 (matrix_pipe_*).
         nprod = {'f32': 1, 'bf16x3': 3, 'bf16x6': 6}[args.prec]
-        peak = PEAK_BF16_MFMA_TFLOPS if args.prec == 'bf16x3' else PEAK_FP32_MFMA_TFLOPS
         pipe_peak = PEAK_FP32_MFMA_TFLOPS if args.prec == 'f32' else PEAK_BF16_MFMA_TFLOPS
+        peak = pipe_peak / nprod
         roof = dict(bound='mfma', kernel='conv_mfma_f32_kernel' if args.prec == 'f32' else 'conv_mfma_bf16{h,p,s}_kernel (vps_conv2d family)',
-                    achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
+                    achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
                     mfma_products_per_fp32_product=nprod, matrix_pipe_executed_tflops=round(ach * nprod, 1),
                     matrix_pipe_peak=pipe_peak, matrix_pipe_frac=round(ach * nprod / pipe_peak, 4),
-                    algorithmic_bytes_per_frame=round(abytes), launches_per_frame=nl, gflop_per_frame=round(fl / 1e9, 1), conv_ms_per_frame=round(ms, 3))
-
-    if rank == 0 and roof is not None:
-        # HBM traffic of the conv kernels per frame: measured by separate rocprofv3 --pmc passes (tools/pmc_traffic.py), not
-        # collectable from inside this process; the committed measurement is attached when it is for this arithmetic mode
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic_%s.json' % args.prec)
-        if os.path.exists(pmc):
-            roof['traffic'] = round(json.load(open(pmc))['conv_hbm_bytes_per_frame'])
-            roof['traffic_source'] = 'profiles/' + os.path.basename(pmc) + ' (bytes per frame over all conv launches, like algorithmic_bytes_per_frame)'
+                    algorithmic_bytes_per_frame=round(abytes), launches_per_frame=nl, gflop_per_frame=round(fl / 1e9, 1),
+                    conv_ms_per_frame=round(ms, 3), avg_launch_us=round(1e3 * ms / max(nl, 1), 2))
+        # HBM traffic of the conv kernels per frame: separate rocprofv3 --pmc passes (tools/pmc_traffic.py), not collectable from
+        # inside this process; the newest committed measurement for this arithmetic mode is attached
+        for rnd in ('r02', 'r01'):
+            pmc = os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s.json' % (rnd, args.prec))
+            if os.path.exists(pmc):
+                roof['traffic'] = round(json.load(open(pmc))['conv_hbm_bytes_per_frame'])
+                roof['traffic_over_algorithmic'] = round(roof['traffic'] / max(abytes, 1), 3)
+                roof['traffic_source'] = 'profiles/' + os.path.basename(pmc) + ' (bytes per frame over all conv launches, like algorithmic_bytes_per_frame)'
+                break
+        if not args.no_extras and (Hh, Ww) == (H, W):
+            hbm = hbm_kernels(dev)
+            roof['hbm_kernels'] = hbm
     if rank == 0:
-        fps = world * args.steps / dt
+        fps = total_frames / dt
         line = {
-            'metric': 'frames/sec %s 1024x2048' % {'fusetrack': 'FuseTrack', 'fuse': 'PanopticFuse', 'track': 'PanopticTrack'}[args.variant], 'value': round(fps, 3), 'unit': 'frames/s', 'n_gpus': world,
+            'metric': 'frames/sec %s 1024x2048' % {'fusetrack': 'FuseTrack', 'fuse': 'PanopticFuse', 'track': 'PanopticTrack'}[args.variant],
+            'value': round(fps, 3), 'unit': 'frames/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'f32': 'f32', 'bf16x6': 'f32-grade: bf16x6 split operands on MFMA, f32 accumulate',
                       'bf16x3': 'bf16x3 split operands on MFMA, f32 accumulate'}[args.prec], 'data': 'synthetic',
-            'config': {'workload': '2-frame pair FuseTrack (FlowNet2 + ResNet50-FPN + BFP-TCEA + UPSNet panoptic + track head), '
-                                   'synthetic %dx%d clip, batch 1, one clip shard per GPU' % (Hh, Ww),
+            'config': {'workload': '2-frame pair %s (%s), synthetic %dx%d clip of %d frames, batch 1' % (
+                           {'fusetrack': 'FuseTrack', 'fuse': 'PanopticFuse', 'track': 'PanopticTrack'}[args.variant], WORKLOADS[args.variant],
+                           Hh, Ww, total_frames),
                        'weights': 'synthetic (vps_amd.synth seed %d)' % args.seed,
-                       'detections_per_frame': round(ndet / max(args.steps, 1), 1),
-                       'parallelism': 'clip-shard x%d, 1 p2p feature hand-off per shard boundary' % world},
+                       'detections_per_frame': round(ndet / max(total_frames, 1), 1),
+                       'parallelism': ('clip-shard x%d (contiguous shards of %d frames), 1 p2p feature hand-off per shard boundary, tracker replay '
+                                       'on rank 0 + result gather inside the timed region' % (world, args.steps)) if use_runner else 'single GPU',
+                       'timed_region': 'inputs resident in HBM; excludes the H2D of the two 25 MB frames and the D2H of the two uint8 maps that '
+                                       'tools/test_vpq.py:46-56 pays (~0.4 ms per frame over PCIe 5 x16 when not overlapped)'},
             'roofline': roof, 'stage_ms': stages,
             'stage_ms_note': 'instrumented extra frame on ONE stream; the timed frames overlap FlowNet2 with backbone+FPN and the semantic head with the detection heads on two streams',
         }
+        if clip30 is not None:
+            line['clip30'] = clip30
         if not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.seed)
         print(json.dumps(line))

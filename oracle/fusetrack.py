@@ -542,7 +542,7 @@ class FuseTrackOracle:
         mask_feats = roi_extract(x, mask_rois, 14, cfg)
         mask_score = mask_head(sd, 'mask_head.', mask_feats)
         if inject is not None and 'mask_score' in inject:
-            mask_score = inject['mask_score']
+            mask_score = inject['mask_score'][:mask_rois.size(0)]          # a bank of >= K rows
         nobj, _, H, W = mask_score.shape
         mask_score = mask_score.gather(1, cls_idx.view(-1, 1, 1, 1).expand(-1, -1, H, W))
         keep_inds, mask_logits = mask_removal(mask_rois[:, 1:], cls_prob, mask_score, cls_idx, tuple(fcn_output.shape[2:]),

@@ -2,7 +2,8 @@
 (/root/reference/mmdet/models/detectors/panoptic_fusetrack.py and everything it builds) on the CPU of the build
 container, with the import shims of ref_shims.py (third-party stubs + oracle-backed stand-ins for the CUDA-only ops).
 
-    python tests/golden/make_golden.py            # needs /root/reference; writes tests/golden/fusetrack_clip.npz etc.
+    python tests/golden/make_golden.py [fusetrack|fuse|track]   # needs /root/reference; writes tests/golden/<variant>_clip.npz
+    python tests/golden/make_golden.py fullsize                  # 2 frames at 1024x2048 -> tests/golden/fusetrack_fullsize.npz
 
 The reference cannot travel to the GPU box; the vectors do. tests/test_oracle_golden.py checks the oracle against them
 (CPU), tests/test_fusetrack_gpu.py checks the HIP path against the oracle and against these vectors (GPU).
@@ -23,9 +24,11 @@ sys.path.insert(0, HERE)
 warnings.simplefilter('ignore')
 
 H, W, NFRAMES, SEED = 128, 256, 3, 0
+FULL_H, FULL_W, FULL_NFRAMES = 1024, 2048, 2          # `fullsize`: the BASELINE frame size (configs[1]), FuseTrack only
 
 
-def main(variant='fusetrack'):
+def main(variant='fusetrack', H=H, W=W, NFRAMES=NFRAMES, out_name=None, full=False):
+    """full=True: the 1024x2048 golden — same quantities, the dense stage tensors strided so the file stays a few MB"""
     import ref_shims
     mods = ref_shims.install()
     from vps_amd import synth
@@ -61,6 +64,10 @@ def main(variant='fusetrack'):
     assert not bad, ('shape mismatch', bad[:10])
     print('state_dict: %d keys identical to the reference module tree' % len(shapes))
     ref.load_state_dict(sd)
+    # the key/shape manifest of the REFERENCE module tree travels in the .npz: tests/test_oracle_golden.py compares it
+    # with vps_amd's state_dict on every run (the drop-in checkpoint contract)
+    import json
+    manifest = json.dumps({k: list(v) for k, v in sorted(ref_shapes.items())})
 
     # --- hooks on the stage boundaries ---
     cap = {}
@@ -105,15 +112,17 @@ def main(variant='fusetrack'):
             else:
                 assert sorted(pano.keys()) == ['fcn_outputs', 'panoptic_cls_inds', 'panoptic_cls_prob', 'panoptic_outputs']
                 out[p + 'bbox_counts'] = np.array([len(b) for b in bbox_res], dtype=np.int64)
+            s1, s2 = (8, 4) if full else (2, 1)                              # spatial strides of the stored stage tensors
+            c5 = 32 if full else None                                        # channels kept of the low-resolution levels
             if has_flow:
-                out[p + 'flow_full'] = cap['flownet2'][0][0][:, ::2, ::2].numpy()   # stride-2 subsample
+                out[p + 'flow_full'] = cap['flownet2'][0][0][:, ::s1, ::s1].numpy()
             # neck is called twice (img, ref_img): first call = target frame
-            out[p + 'fpn_p2'] = cap['neck'][0][0][0, :8].numpy()          # first 8 channels of P2
-            out[p + 'fpn_p5'] = cap['neck'][0][3][0].numpy()
+            out[p + 'fpn_p2'] = cap['neck'][0][0][0, :8, ::s2, ::s2].numpy()          # first 8 channels of P2
+            out[p + 'fpn_p5'] = cap['neck'][0][3][0, :c5].numpy()
             if has_flow:
-                out[p + 'neck_out_p2'] = cap['extra_neck'][0][0][0, :8].numpy()
-                out[p + 'neck_out_p6'] = cap['extra_neck'][0][4][0].numpy()
-            out[p + 'fcn_score'] = cap['panopticFPN'][0][1][0].numpy()
+                out[p + 'neck_out_p2'] = cap['extra_neck'][0][0][0, :8, ::s2, ::s2].numpy()
+                out[p + 'neck_out_p6'] = cap['extra_neck'][0][4][0, :c5].numpy()
+            out[p + 'fcn_score'] = cap['panopticFPN'][0][1][0, :, ::s2, ::s2].numpy()
             out[p + 'proposals'] = cap['proposals'][0].numpy()
             out[p + 'cls_score'] = cap['bbox_head'][0][0].numpy()
             out[p + 'bbox_pred'] = cap['bbox_head'][0][1].numpy()
@@ -121,10 +130,16 @@ def main(variant='fusetrack'):
             print('%s frame %d: K=%d kept=%d ids=%s' % (variant, t, cap['mask_head'][0].shape[0], len(out[p + 'panoptic_cls_inds']),
                                                        out[p + 'panoptic_det_obj_ids'][:8] if has_track else None))
     out['meta'] = np.array([H, W, NFRAMES, SEED], dtype=np.int64)
-    path = os.path.join(HERE, '%s_clip.npz' % variant)
+    out['strides'] = np.array([s1, s2, c5 or 0], dtype=np.int64)
+    out['state_dict_manifest'] = np.frombuffer(manifest.encode(), dtype=np.uint8)
+    path = os.path.join(HERE, out_name or '%s_clip.npz' % variant)
     np.savez_compressed(path, **out)
     print('wrote', path, os.path.getsize(path) / 1e6, 'MB')
 
 
 if __name__ == '__main__':
-    main(sys.argv[1] if len(sys.argv) > 1 else 'fusetrack')
+    v = sys.argv[1] if len(sys.argv) > 1 else 'fusetrack'
+    if v == 'fullsize':
+        main('fusetrack', FULL_H, FULL_W, FULL_NFRAMES, 'fusetrack_fullsize.npz', full=True)
+    else:
+        main(v)

@@ -131,6 +131,21 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_short(rank, world, port, q):
+    """nframes < world: trailing ranks own no frames; the run must finish (no send without a matching recv)"""
+    import torch.distributed as dist
+    torch.set_num_threads(2)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sd, frames = _make()
+    runner = ClipShardRunner(OracleBackend(sd), rank, world, dist)
+    outs = runner.run(lambda t: frames[t], 1)
+    if rank == 0:
+        q.put([o['t'] for o in outs])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
     return p
@@ -169,3 +184,18 @@ def test_two_rank_clip_shard_equals_sequential():
         # maps: identical up to CPU-thread-count dependent rounding of the convolutions (argmax flips on a few pixels)
         assert (a['panoptic_outputs'] != b['panoptic_outputs'].numpy()).mean() < 2e-3
         assert (a['fcn_outputs'] != b['fcn_outputs'].numpy()).mean() < 2e-3
+
+
+@pytest.mark.timeout(600)
+def test_clip_shorter_than_world_does_not_deadlock():
+    assert partition(1, 2) == [(0, 1), (1, 1)] and partition(3, 4)[-1] == (3, 3)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_short, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    assert q.get(timeout=500) == [0]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0

@@ -1,5 +1,7 @@
-"""Parity at BASELINE's full frame size (1024x2048), where the oracle is too slow to run: size-independent properties.
+"""Parity at BASELINE's full frame size (1024x2048): the reference golden + size-independent properties.
 
+* the HIP path (both fp32-grade arithmetic modes) reproduces the golden vectors of the REAL reference detector run at
+  1024x2048 (ids / classes / labels identical, stage tensors within the fp32 tolerance, maps within 0.1 % of the pixels);
 * two arithmetically independent kernel families agree: the default split-bf16 path (halo-staged / pipelined bf16 MFMA kernels,
   split-K over chunks) against the exact-fp32 MFMA kernel (validated against the oracle at the golden size) — identical
   instance ids / classes, stage tensors within the fp32 tolerance, maps within 0.1 % of the pixels;
@@ -118,3 +120,63 @@ def test_full_size_reference_feature_cache_equals_recompute(dev, clip, default_r
     for t, (a, b) in enumerate(zip(default_run, rec)):
         for k in b:
             assert np.array_equal(a[k], b[k]), (t, k)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# HIP path vs the golden vectors of the REAL reference detector at the BASELINE size (tests/golden/make_golden.py fullsize:
+# 2 frames at 1024x2048, K = 100 detections per frame), in both fp32-grade arithmetic modes. tests/test_oracle_golden.py
+# checks the oracle against the same file on the CPU.
+# Tolerances: stage tensors 2e-3 * max|ref|; maps < 0.1 % differing pixels; ids / classes / labels identical.
+# ---------------------------------------------------------------------------------------------------------------------
+GOLD_FULL = os.path.join(ROOT, 'tests', 'golden', 'fusetrack_fullsize.npz')
+
+
+@pytest.mark.parametrize('prec_name', ['f32', 'bf16x6'])
+def test_full_size_outputs_match_reference_golden(dev, prec_name):
+    g = np.load(GOLD_FULL)
+    gh, gw, n, seed = [int(v) for v in g['meta']]
+    assert (gh, gw) == (H, W)
+    s1, s2, c5 = [int(v) for v in g['strides']]
+    frames = [f.to(dev) for f in synth.synth_clip(H, W, n, seed)]
+    m = _model({'f32': hip.PREC_F32, 'bf16x6': hip.PREC_BF16X6}[prec_name])
+    lines, fails = [], []
+    for t in range(n):
+        out = m(return_loss=False, rescale=True, img=[frames[t]], img_meta=[[synth.img_meta(H, W, 10000 + t + 1)]],
+                ref_img=[frames[t - 1 if t else 0]])
+        torch.cuda.synchronize()
+        p = 'f%d.' % t
+        a = m._aux
+        stage = dict(
+            flow=_rel(a['flow'].to_nchw().cpu().numpy()[0][:, ::s1, ::s1], g[p + 'flow_full']),
+            fpn_p2=_rel(a['levels'][0].to_nchw().cpu().numpy()[0, :8, ::s2, ::s2], g[p + 'fpn_p2']),
+            fpn_p5=_rel(a['levels'][3].to_nchw().cpu().numpy()[0, :c5], g[p + 'fpn_p5']),
+            neck_p2=_rel(a['neck_out'][0].to_nchw().cpu().numpy()[0, :8, ::s2, ::s2], g[p + 'neck_out_p2']),
+            neck_p6=_rel(a['neck_out'][4].to_nchw().cpu().numpy()[0, :c5], g[p + 'neck_out_p6']),
+            fcn_score=_rel(a['fcn_score'].to_nchw().cpu().numpy()[0, :, ::s2, ::s2], g[p + 'fcn_score']))
+        ph, pg = a['proposals'].cpu(), torch.from_numpy(g[p + 'proposals'])
+        dist = torch.maximum((ph[:, None, :4] - pg[None, :, :4]).abs().amax(2), 500.0 * (ph[:, None, 4] - pg[None, :, 4]).abs())
+        match = dist.argmin(1)
+        good = dist.gather(1, match[:, None])[:, 0] < 0.05
+        stage['cls_score'] = _rel(a['det']['cls_score'].cpu()[good].numpy(), g[p + 'cls_score'][match.numpy()][good.numpy()])
+        stage['bbox_pred'] = _rel(a['det']['bbox_pred'].cpu()[good].numpy(), g[p + 'bbox_pred'][match.numpy()][good.numpy()])
+        r = {k: v.cpu().numpy() for k, v in out[2].items()}
+        same = {k: bool(np.array_equal(r[k], g[p + k])) for k in ('panoptic_cls_inds', 'panoptic_det_labels', 'panoptic_det_obj_ids')}
+        same['bbox_ids'] = sorted(int(k) for k in out[0].keys()) == [int(k) for k in g[p + 'bbox_ids']]
+        dpan = float((r['panoptic_outputs'] != g[p + 'panoptic_outputs']).mean()) if r['panoptic_outputs'].shape == g[p + 'panoptic_outputs'].shape else 1.0
+        dsem = float((r['fcn_outputs'] != g[p + 'fcn_outputs']).mean())
+        lines.append('%s frame %d: stage %s | unmatched proposals %d | identical %s | kept %d (golden %d) | pan mismatch %.5f%% sem mismatch %.5f%%' % (
+            prec_name, t, {k: '%.2e' % v for k, v in stage.items()}, int((~good).sum()), same, len(r['panoptic_cls_inds']),
+            len(g[p + 'panoptic_cls_inds']), 100 * dpan, 100 * dsem))
+        print(lines[-1])
+        fails += ['f%d %s %.2e' % (t, k, v) for k, v in stage.items() if not v < 2e-3]
+        fails += ['f%d %s differs' % (t, k) for k, v in same.items() if not v]
+        if int((~good).sum()) > ph.shape[0] // 100:
+            fails.append('f%d proposals: %d unmatched' % (t, int((~good).sum())))
+        if not (dpan < 1e-3 and dsem < 1e-3):
+            fails.append('f%d maps: pan %.5f sem %.5f' % (t, dpan, dsem))
+        if same['panoptic_cls_inds']:
+            assert np.allclose(r['panoptic_cls_prob'], g[p + 'panoptic_cls_prob'], rtol=1e-3, atol=1e-4)
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(ROOT, 'gpurun_out', 'fullsize_golden_report.txt'), 'a') as f:
+        f.write('\n'.join(lines) + '\n')
+    assert not fails, fails

@@ -2,7 +2,9 @@
 (tests/golden/make_golden.py, run in the build container with /root/reference + import shims).
 
 Scope of the pin: all Python-level reference logic (module wiring, RPN/MaskROI/MaskRemoval/SegTerm/tracking host
-logic, torch op semantics). The CUDA-only operators were oracle-backed in that run, so they stay "parity unpinned".
+logic, torch op semantics), at 128x256 (3 frames) and at the BASELINE size 1024x2048 (2 frames). The CUDA-only operators
+were oracle-backed in those runs; they are pinned separately against the reference's own kernels compiled for gfx950
+(oracle/_ref, tests/test_ref_native_gpu.py).
 """
 import os
 
@@ -45,9 +47,21 @@ def _close(a, b, rtol=1e-4, atol=1e-4):
     assert (err <= atol + rtol * np.abs(b)).all(), 'max err %.3e (ref max %.3e)' % (err.max(), np.abs(b).max())
 
 
-def test_state_dict_keys_match_reference_module_tree(gold):
-    """make_golden.py asserted key/shape equality against the reference's own module tree before writing the file"""
-    assert 'meta' in gold.files
+@pytest.mark.parametrize('variant,gold_file', [('fusetrack', 'fusetrack_clip.npz'), ('fuse', 'fuse_clip.npz'), ('track', 'track_clip.npz'),
+                                               ('fusetrack', 'fusetrack_fullsize.npz')])
+def test_state_dict_keys_match_reference_module_tree(variant, gold_file):
+    """the drop-in checkpoint contract: the key -> shape manifest of the REAL reference module tree, stored in the
+    golden file by make_golden.py, equals the state_dict of the vps_amd detector built from the same config"""
+    import json
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', gold_file))
+    manifest = json.loads(bytes(g['state_dict_manifest']).decode())
+    cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', variant + '.py'))
+    model = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    ours = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert sorted(ours) == sorted(manifest), (sorted(set(manifest) - set(ours))[:5], sorted(set(ours) - set(manifest))[:5])
+    bad = [k for k in ours if ours[k] != manifest[k]]
+    assert not bad, bad[:5]
+    assert len(ours) == {'fusetrack': 629, 'fuse': 625, 'track': 381}[variant]
 
 
 @pytest.mark.parametrize('t', [0, 1, 2])
@@ -74,3 +88,53 @@ def test_oracle_outputs_identical_to_reference(gold, oracle_run, t):
     pan = r['panoptic_outputs'].numpy().astype(np.uint8); sem = r['fcn_outputs'].numpy().astype(np.uint8)
     assert (pan != gold[p + 'panoptic_outputs']).mean() < 1e-4
     assert (sem != gold[p + 'fcn_outputs']).mean() < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the BASELINE frame size: the oracle against the golden vectors the REAL reference detector produced at 1024x2048
+# (tests/golden/make_golden.py fullsize; 2 frames, K = 100 detections per frame). ~70 s of CPU.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def full_gold():
+    return np.load(os.path.join(ROOT, 'tests', 'golden', 'fusetrack_fullsize.npz'))
+
+
+@pytest.fixture(scope='module')
+def full_oracle_run(full_gold):
+    H, W, n, seed = [int(v) for v in full_gold['meta']]
+    assert (H, W) == (1024, 2048)
+    cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', 'fusetrack.py'))
+    model = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    sd = synth.synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, seed)
+    o = FuseTrackOracle(sd)
+    frames = synth.synth_clip(H, W, n, seed)
+    res = []
+    with torch.no_grad():
+        for t in range(n):
+            r = o.simple_test(frames[t], frames[t - 1] if t else frames[0], t == 0, return_aux=True)
+            r.pop('mask_score', None)
+            res.append(r)
+    return res
+
+
+@pytest.mark.parametrize('t', [0, 1])
+def test_fullsize_oracle_matches_reference(full_gold, full_oracle_run, t):
+    g, r = full_gold, full_oracle_run[t]
+    p = 'f%d.' % t
+    s1, s2, c5 = [int(v) for v in g['strides']]
+    _close(r['flow_full'][0][:, ::s1, ::s1].numpy(), g[p + 'flow_full'])
+    _close(r['pre_neck'][0][0, :8, ::s2, ::s2].numpy(), g[p + 'fpn_p2'])
+    _close(r['pre_neck'][3][0, :c5].numpy(), g[p + 'fpn_p5'])
+    _close(r['feats'][0][0, :8, ::s2, ::s2].numpy(), g[p + 'neck_out_p2'], 2e-4, 2e-4)
+    _close(r['feats'][4][0, :c5].numpy(), g[p + 'neck_out_p6'], 2e-4, 2e-4)
+    _close(r['fcn_score'][0, :, ::s2, ::s2].numpy(), g[p + 'fcn_score'], 5e-4, 5e-4)
+    _close(r['det']['proposals'].numpy(), g[p + 'proposals'], 1e-4, 1e-3)
+    _close(r['det']['cls_score'].numpy(), g[p + 'cls_score'], 5e-4, 5e-4)
+    _close(r['det']['bbox_pred'].numpy(), g[p + 'bbox_pred'], 5e-4, 5e-4)
+    assert np.array_equal(r['panoptic_cls_inds'].numpy(), g[p + 'panoptic_cls_inds'])
+    assert np.array_equal(r['panoptic_det_labels'].numpy(), g[p + 'panoptic_det_labels'])
+    assert np.array_equal(r['panoptic_det_obj_ids'].numpy(), g[p + 'panoptic_det_obj_ids'])
+    _close(r['panoptic_cls_prob'].numpy(), g[p + 'panoptic_cls_prob'], 1e-5, 1e-6)
+    pan = r['panoptic_outputs'].numpy().astype(np.uint8); sem = r['fcn_outputs'].numpy().astype(np.uint8)
+    assert (pan != g[p + 'panoptic_outputs']).mean() < 1e-4
+    assert (sem != g[p + 'fcn_outputs']).mean() < 1e-4

@@ -46,14 +46,17 @@ class ClipShardRunner:
         Returns on rank 0 the list of per-frame outputs for the WHOLE clip (frame order), elsewhere this rank's outputs
         without ids."""
         dist, rank, world = self.dist, self.rank, self.world
-        s, e = partition(nframes, world)[rank]
+        parts = partition(nframes, world)
+        s, e = parts[rank]
         be = self.backend
         recv_buf = None
         reqs = []
-        # 1) hand-off: last frame's gathered feature -> next rank (computed first: it only needs that image)
+        # 1) hand-off: last frame's gathered feature -> next rank (computed first: it only needs that image).
+        # A clip shorter than the node (nframes < world) leaves the trailing ranks without frames: a send is posted only when
+        # the NEXT rank owns frames (it is the one that posts the matching recv), otherwise the last busy rank would wait forever.
         if world > 1 and e > s:
             ops = []
-            if rank < world - 1:
+            if rank < world - 1 and parts[rank + 1][1] > parts[rank + 1][0]:
                 feat = be.ref_feature(load_frame(e - 1))
                 ops.append(dist.P2POp(dist.isend, feat, rank + 1))
             if rank > 0:
@@ -93,7 +96,6 @@ class ClipShardRunner:
             for r in allrec:
                 r = {k: (v.to(self.device) if torch.is_tensor(v) and self.device is not None else v) for k, v in r.items()}
                 ids[r['t']] = np.asarray(be.assign(r, r['t'] == 0))
-            parts = partition(nframes, world)
             ids_per_rank = [{t: ids[t] for t in range(a, b)} for a, b in parts]
         mine = [None]
         dist.scatter_object_list(mine, ids_per_rank, src=0)

@@ -109,6 +109,7 @@ class PanopticFuseTrack(HipModule):
         self._ws = None
         self._flip = 0
         self._cache = None
+        self._handoff = None
         self.reset_tracker()
 
     # ------------------------------------------------------------------------------------------------------
@@ -226,8 +227,14 @@ class PanopticFuseTrack(HipModule):
             # (2) backbone + FPN of the target frame -----------------------------------------------------------------
             self._flip ^= 1
             tag = 'AB'[self._flip]
-            levels = self.neck.run(self.backbone.run(nhwc.from_nchw(img, ws, 'img_nhwc'), ws, 'bb.'), ws, 'fpn.')
-            cat = self.extra_neck.gather(levels, ws, 'neck.cat' + tag)
+            pre = self._handoff
+            if pre is not None and pre['key'] == (img.data_ptr(), tuple(img.shape), img._version):
+                # clip sharding: this frame's ResNet+FPN+gather already ran for the hand-off to the next GPU (gathered_feature)
+                levels, cat = pre['levels'], pre['cat']
+                self._handoff = None
+            else:
+                levels = self.neck.run(self.backbone.run(nhwc.from_nchw(img, ws, 'img_nhwc'), ws, 'bb.'), ws, 'fpn.')
+                cat = self.extra_neck.gather(levels, ws, 'neck.cat' + tag)
             C = self.extra_neck.in_channels
             if side is not None:
                 main.wait_stream(side)
@@ -283,7 +290,8 @@ class PanopticFuseTrack(HipModule):
         logits = self.mask_head.run(mask_feats, ws)
         nc = self.mask_head.num_classes
         if inject is not None and 'mask_score' in inject:
-            all_scores = inject['mask_score'].to(dev).permute(0, 2, 3, 1).contiguous()       # [K,28,28,nc]
+            # a bank of >= K rows: the number of detections is decided by MaskROI
+            all_scores = inject['mask_score'][:mask_rois.size(0)].to(dev).permute(0, 2, 3, 1).contiguous()       # [K,28,28,nc]
         else:
             all_scores = logits.t[..., :nc]
         S = all_scores.shape[1]
@@ -315,7 +323,7 @@ class PanopticFuseTrack(HipModule):
         self._track_record = dict(det_bboxes=det_bboxes, det_labels=det_labels, cls_prob=cls_prob, emb=det['emb'],
                                   keep_inds=keep_inds)
         self._aux = dict(flow=flow, levels=levels, cat=cat, neck_out=x, neck_aux=aux, fcn_score=fcn_score, det=det,
-                         mask_score=mask_score, keep_inds=keep_inds, proposals=proposals)
+                         mask_score=mask_score, keep_inds=keep_inds, proposals=proposals, masks_valid=masks_valid)
         return bbox_results, mask_results, pano_results
 
     # ------------------------------------------------------------------------------------------------------
@@ -329,6 +337,9 @@ class PanopticFuseTrack(HipModule):
         lv = self.neck.run(self.backbone.run(nhwc.from_nchw(img, ws, 'ho_nhwc'), ws, 'hbb.'), ws, 'hfpn.')
         cat = self.extra_neck.gather(lv, ws, 'neck.handoff')
         C = self.extra_neck.in_channels
+        # kept for this frame's own simple_test call (its buffers have their own workspace names): the sender does not run
+        # ResNet+FPN on its last frame twice
+        self._handoff = dict(key=(img.data_ptr(), tuple(img.shape), img._version), levels=lv, cat=cat)
         return cat.t[..., :C].contiguous()
 
     def track_assign(self, rec, is_first):
