@@ -74,6 +74,8 @@ def make_inject(seed, K, tie_from=None, masks='random', jitter_of=None, extra_sa
     # scores: distinct probabilities in (0.62, 0.99) for the objects, background rows below the threshold
     p = 0.62 + 0.37 * torch.rand(NPROP, generator=g)
     if tie_from is not None:
+        # one class for the tied rows: the softmax of identical logit vectors is bitwise identical, whatever the summation order
+        cls[tie_from:nobj] = cls[tie_from]
         p[tie_from:nobj] = 0.75
         p[:tie_from] = 0.80 + 0.19 * torch.rand(tie_from, generator=g)
     cls_score = torch.randn(NPROP, 9, generator=g)
@@ -191,6 +193,11 @@ def test_more_than_244_instances_is_refused_loudly(dev, model):
     m, sd, frames = model
     m._cache = None; m.reset_tracker()
     inj = make_inject(5, 300, tie_from=10)
+    o = OF.FuseTrackOracle(sd)
+    x = [torch.zeros(1, 256, H // s, W // s) for s in (4, 8, 16, 32, 64)]
+    with torch.no_grad():
+        det = o.detect(x, (H, W), True, _public(inj))
+    assert det['cls_idx'].numel() > 244, 'the case must produce more than 244 detections (got %d)' % det['cls_idx'].numel()
     with pytest.raises(hip.VpsHipError):
         m.simple_test(frames[0], [synth.img_meta(H, W, 10001)], ref_img=[frames[0]], inject=_public(inj))
         torch.cuda.synchronize()

@@ -110,7 +110,10 @@ def test_roi_align_three_way_four_levels(dev, R, Pz):
     _close(ours, ref, 2e-6, 'roi_align libvpship vs reference kernel (%d rois, %dx%d, 4 levels)' % (R, Pz, Pz))
     sub = torch.arange(0, R, max(R // 40, 1))           # the CPU restatement loops over rois: a strided subset
     ora = OF.roi_extract(feats, rois[sub], Pz)
-    _close(ora, ref[sub], 2e-6, 'roi_align oracle vs reference kernel (subset of %d rois)' % sub.numel())
+    # the compiled reference kernel contracts `roi_start + ph * bin_size + ...` into FMAs (nvcc and hipcc both do by default):
+    # sampling coordinates differ from the unfused CPU restatement in the last bit, values by ~1e-5 of the feature range.
+    # libvpship reproduces the compiled kernel to 1 ulp (above); the oracle is within 2e-5.
+    _close(ora, ref[sub], 2e-5, 'roi_align oracle vs reference kernel (subset of %d rois)' % sub.numel())
 
 
 # UPSNetFPN tower (upsnetFPN.py:39-52): DeformConv 3x3 pad 1 on P2 (256x512) / P3; offsets from the 18-channel conv

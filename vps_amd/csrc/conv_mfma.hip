@@ -47,127 +47,149 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-// ---- shared epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+// ---- shared epilogue.
+// The kernels feed the WEIGHT fragment as the MFMA's A operand and the ACTIVATION fragment as its B operand (the two
+// fragment layouts of the 32x32 shapes are mirror images, so this is an argument swap), i.e. every accumulator holds the
+// TRANSPOSED 32x32 tile: C/D layout row = (r&3) + 8*(r>>2) + 4*(lane>>5) = output channel, col = lane&31 = pixel. A lane
+// therefore owns ONE pixel per 32-row sub-tile and, per register group g = r>>2, FOUR CONSECUTIVE channels
+//     co = tile_n*BN + wn*TN*32 + b*32 + 8*g + 4*(lane>>5) + (r&3)
+// -> the output position / residual position is computed once per sub-tile (not once per register), and outputs, residuals,
+// scale and shift move as float4 (16 B per lane: a quarter of the store instructions of the row-per-register layout; the
+// epilogue of the short-K layers - 1x1 bottleneck convolutions - was store-issue bound).
 // TILE2D: the block's 128 rows are an 8x16 patch of output positions (halo kernel), tile_m = (n*Qh/8 + ty)*Qw/16 + tx
 template <int TM, int TN, int BN, bool TILE2D = false>
 __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&acc)[TM][TN], const int M, const int tile_m,
                                               const int tile_n, const int cls, const int split, const int py, const int px,
                                               const int wm, const int wn, const int lane) {
-    const int col_l = lane & 31;
-    const int row_l = 4 * (lane >> 5);
-    if (d.ksplit > 1) {
-        // partial sums [split][class][pixel][cout_pad]; pixel = linear (n, qy, qx) index whatever the tiling
-        const int Mpix = TILE2D ? d.N * d.Qh * d.Qw : M;
-        float* __restrict__ ws = d.ws + ((size_t)(split * d.nclass + cls) * Mpix) * d.cout_pad;
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int jl = wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + row_l;
-                int m = tile_m * BM + jl;
-                bool ok = m < M;
-                if constexpr (TILE2D) {
-                    const int tiles_x = (d.Qw + 15) >> 4, tiles_y = (d.Qh + 7) >> 3;
-                    const int tx = tile_m % tiles_x, tq = tile_m / tiles_x;
-                    const int qx = tx * 16 + (jl & 15), qy = (tq % tiles_y) * 8 + (jl >> 4), n = tq / tiles_y;
-                    ok = qx < d.Qw && qy < d.Qh;
-                    m = (n * d.Qh + qy) * d.Qw + qx;
-                }
-                if (ok) {
-#pragma unroll
-                    for (int b = 0; b < TN; ++b) {
-                        const int co = tile_n * BN + wn * TN * 32 + b * 32 + col_l;
-                        ws[(size_t)m * d.cout_pad + co] = acc[a][b][r];
-                    }
-                }
-            }
-        return;
-    }
+    const int prow = lane & 31;
+    const int cq = 4 * (lane >> 5);
+    const int cbase = tile_n * BN + wn * TN * 32 + cq;       // + b*32 + 8*g: first of this lane's 4 channels
 
-    float sc[TN], sh[TN];
-    bool cok[TN];
+    // ---- one output position per sub-tile a. Rows past the end are clamped to a valid position and not stored.
+    size_t opix[TM], rpix[TM];
+    int mlin[TM];
+    bool inside[TM];
+    {
+        int t2_n = 0, t2_y0 = 0, t2_x0 = 0;
+        if constexpr (TILE2D) {
+            const int tiles_x = (d.Qw + 15) >> 4, tiles_y = (d.Qh + 7) >> 3;
+            const int tx = tile_m % tiles_x, tq = tile_m / tiles_x;
+            t2_x0 = tx * 16; t2_y0 = (tq % tiles_y) * 8; t2_n = tq / tiles_y;
+        }
+        const bool simple_pix = !TILE2D && (d.nclass == 1 && d.os_y == 1 && d.os_x == 1 && d.res_shift == 0);
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int co = tile_n * BN + wn * TN * 32 + b * 32 + col_l;
-        cok[b] = co < d.cout;
-        sc[b] = (cok[b] && d.scale) ? d.scale[co] : 1.f;
-        sh[b] = (cok[b] && d.shift) ? d.shift[co] : 0.f;
-    }
-    const bool simple_pix = !TILE2D && (d.nclass == 1 && d.os_y == 1 && d.os_x == 1 && d.res_shift == 0);
-    int t2_n = 0, t2_y0 = 0, t2_x0 = 0;
-    if constexpr (TILE2D) {
-        const int tiles_x = (d.Qw + 15) >> 4, tiles_y = (d.Qh + 7) >> 3;
-        const int tx = tile_m % tiles_x, tq = tile_m / tiles_x;
-        t2_x0 = tx * 16; t2_y0 = (tq % tiles_y) * 8; t2_n = tq / tiles_y;
-    }
-    // output / residual pixel index of accumulator row (a, r); rows past M are clamped to a valid row and not stored
-    auto row_pix = [&](const int a, const int r, size_t& opix, size_t& rpix) -> bool {
-        const int jl = wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + row_l;   // row of the block tile
-        const int m_raw = tile_m * BM + jl;
-        const int m = min(m_raw, M - 1);
-        bool inside = m_raw < M;
-        if (simple_pix) {
-            opix = rpix = (size_t)m;
-        } else {
+        for (int a = 0; a < TM; ++a) {
+            const int jl = wm * TM * 32 + a * 32 + prow;       // row of the block tile
             int qx, qy, n;
             if constexpr (TILE2D) {
                 // patches overhang the right / bottom edge when Qw % 16 or Qh % 8: those rows are computed and dropped
                 qx = t2_x0 + (jl & 15); qy = t2_y0 + (jl >> 4); n = t2_n;
-                inside = qx < d.Qw && qy < d.Qh;
+                inside[a] = qx < d.Qw && qy < d.Qh;
                 qx = min(qx, d.Qw - 1); qy = min(qy, d.Qh - 1);
+                mlin[a] = (n * d.Qh + qy) * d.Qw + qx;
             } else {
-                qx = m % d.Qw;
-                const int tq = m / d.Qw;
+                const int m_raw = tile_m * BM + jl;
+                inside[a] = m_raw < M;
+                mlin[a] = min(m_raw, M - 1);
+                if (simple_pix) {
+                    opix[a] = rpix[a] = (size_t)mlin[a];
+                    continue;
+                }
+                qx = mlin[a] % d.Qw;
+                const int tq = mlin[a] / d.Qw;
                 qy = tq % d.Qh;
                 n = tq / d.Qh;
             }
             const int oy = qy * d.os_y + py, ox = qx * d.os_x + px;
-            opix = ((size_t)n * d.Ho + oy) * d.Wo + ox;
+            opix[a] = ((size_t)n * d.Ho + oy) * d.Wo + ox;
             const int rs = d.res_shift;
-            rpix = ((size_t)n * (d.Ho >> rs) + (oy >> rs)) * (d.Wo >> rs) + (ox >> rs);
+            rpix[a] = ((size_t)n * (d.Ho >> rs) + (oy >> rs)) * (d.Wo >> rs) + (ox >> rs);
         }
-        return inside;
-    };
-    // residual: all TM*16*TN values are requested (branch-free, clamped) before the first one is used. A load that sits
-    // behind `if (row valid) if (column valid)` gets an s_waitcnt vmcnt(0) of its own: 64 serial memory latencies per
-    // lane, which was most of the run time of the 1x1 bottleneck-expansion layers.
-    float rv[TM][16][TN];
-    if (d.res) {
-        int cco[TN];
-#pragma unroll
-        for (int b = 0; b < TN; ++b) cco[b] = d.res_coff + min(tile_n * BN + wn * TN * 32 + b * 32 + col_l, d.cout - 1);
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                size_t opix, rpix;
-                row_pix(a, r, opix, rpix);
-#pragma unroll
-                for (int b = 0; b < TN; ++b) rv[a][r][b] = d.res[rpix * d.res_ld + cco[b]];
-            }
-    } else {
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-#pragma unroll
-                for (int b = 0; b < TN; ++b) rv[a][r][b] = 0.f;
     }
+
+    if (d.ksplit > 1) {
+        // partial sums [split][class][pixel][cout_pad]; pixel = linear (n, qy, qx) index whatever the tiling. cout_pad is a
+        // multiple of 32 and the scratch buffer is 16-byte aligned: always float4
+        const int Mpix = TILE2D ? d.N * d.Qh * d.Qw : M;
+        float* __restrict__ ws = d.ws + ((size_t)(split * d.nclass + cls) * Mpix) * d.cout_pad;
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+        for (int a = 0; a < TM; ++a) {
+            if (!inside[a]) continue;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            size_t opix, rpix;
-            if (!row_pix(a, r, opix, rpix)) continue;
+            for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                if (!cok[b]) continue;
-                const int co = tile_n * BN + wn * TN * 32 + b * 32 + col_l;
-                float v = acc[a][b][r] * sc[b] + sh[b];
-                if (d.res) v += rv[a][r][b];
-                d.out[opix * d.out_ld + d.out_coff + co] = vps_act(v, d.act, d.slope);
-            }
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(&ws[(size_t)mlin[a] * d.cout_pad + cbase + b * 32 + 8 * g]) = v;
+                }
         }
+        return;
+    }
+
+    const bool vec = !((d.cout | d.out_ld | d.out_coff) & 3) && !((uintptr_t)d.out & 15) &&
+                     (!d.res || (!((d.res_ld | d.res_coff) & 3) && !((uintptr_t)d.res & 15)));
+    if (vec) {
+        // residual: all TM*TN*4 float4 values are requested (branch-free, clamped) before the first one is used. A load that
+        // sits behind `if (row valid) if (column valid)` gets an s_waitcnt vmcnt(0) of its own.
+        f32x4 rv[TM][TN][4];
+        if (d.res) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int cc = min(cbase + b * 32 + 8 * g, d.cout - 4);
+                        rv[a][b][g] = *reinterpret_cast<const f32x4*>(d.res + rpix[a] * d.res_ld + d.res_coff + cc);
+                    }
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = cbase + b * 32 + 8 * g;
+                const bool cok = co < d.cout;                    // cout % 4 == 0: a group is valid or invalid as a whole
+                const int cc = min(co, d.cout - 4);
+                f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                if (d.scale) sc = *reinterpret_cast<const f32x4*>(d.scale + cc);
+                if (d.shift) sh = *reinterpret_cast<const f32x4*>(d.shift + cc);
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    if (!inside[a] || !cok) continue;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc[a][b][4 * g + e] * sc[e] + sh[e];
+                        if (d.res) t += rv[a][b][g][e];
+                        v[e] = vps_act(t, d.act, d.slope);
+                    }
+                    *reinterpret_cast<f32x4*>(d.out + opix[a] * d.out_ld + d.out_coff + co) = v;
+                }
+            }
+        return;
+    }
+    // scalar path: a channel count / window that is not a multiple of 4 (19-, 18-, 9-channel heads, odd concat offsets)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = cbase + b * 32 + 8 * g + e;
+                const bool cok = co < d.cout;
+                const int cc = min(co, d.cout - 1);
+                const float sc = d.scale ? d.scale[cc] : 1.f;
+                const float sh = d.shift ? d.shift[cc] : 0.f;
+                float rvs[TM];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) rvs[a] = d.res ? d.res[rpix[a] * d.res_ld + d.res_coff + cc] : 0.f;
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    if (!inside[a] || !cok) continue;
+                    const float t = acc[a][b][4 * g + e] * sc + sh + rvs[a];
+                    d.out[opix[a] * d.out_ld + d.out_coff + co] = vps_act(t, d.act, d.slope);
+                }
+            }
 }
 
 template <int TM, int TN, int WAVES_M, int WAVES_N, bool DEFORM>
@@ -362,7 +384,7 @@ void conv_mfma_f32_kernel(const vps_conv_desc d, const int M, const int tiles_m,
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[b][j], af[a][j], acc[a][b], 0, 0, 0);
         }
         __syncthreads();
         if (more) {
@@ -618,7 +640,7 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[q]][a], bf[PB[q]][b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[PB[q]][b], af[PA[q]][a], acc[a][b], 0, 0, 0);
         }
         __syncthreads();
         if (more) {
@@ -846,7 +868,7 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b) {
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][PA[q]][a], bcur[m][PB[q]][b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bcur[m][PB[q]][b], af[m][PA[q]][a], acc[a][b], 0, 0, 0);
                         ++mf;
                         // item w runs after MFMA number max(1, (w+1)*NMF/(NW+1)): evenly spread, and the slab-1 fragment
                         // reads (item 2) always land in the first quarter of the stream, well before their consumers
@@ -1040,7 +1062,7 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
                     for (int a = 0; a < TM; ++a)
 #pragma unroll
                         for (int b = 0; b < TN; ++b) {
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][PA[q]][a], bcur[m][PB[q]][b], acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bcur[m][PB[q]][b], af[m][PA[q]][a], acc[a][b], 0, 0, 0);
                             ++mf;
 #pragma unroll
                             for (int w = 0; w < NW; ++w) {

@@ -228,7 +228,7 @@ class PanopticFuseTrack(HipModule):
             self._flip ^= 1
             tag = 'AB'[self._flip]
             pre = self._handoff
-            if pre is not None and pre['key'] == (img.data_ptr(), tuple(img.shape), img._version):
+            if pre is not None and pre['img'] is img and pre['version'] == img._version:
                 # clip sharding: this frame's ResNet+FPN+gather already ran for the hand-off to the next GPU (gathered_feature)
                 levels, cat = pre['levels'], pre['cat']
                 self._handoff = None
@@ -339,7 +339,8 @@ class PanopticFuseTrack(HipModule):
         C = self.extra_neck.in_channels
         # kept for this frame's own simple_test call (its buffers have their own workspace names): the sender does not run
         # ResNet+FPN on its last frame twice
-        self._handoff = dict(key=(img.data_ptr(), tuple(img.shape), img._version), levels=lv, cat=cat)
+        # (matched by tensor IDENTITY: a data_ptr can be recycled by the allocator for a different frame)
+        self._handoff = dict(img=img, version=img._version, levels=lv, cat=cat)
         return cat.t[..., :C].contiguous()
 
     def track_assign(self, rec, is_first):
