@@ -159,7 +159,7 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='skip the untimed extras (hbm kernel table, 30-frame clip)')
     ap.add_argument('--height', type=int, default=H)
     ap.add_argument('--width', type=int, default=W)
-    ap.add_argument('--prec', default='bf16x6', choices=['f32', 'bf16x3', 'bf16x6'], help='arithmetic of the dense contractions')
+    ap.add_argument('--prec', default='bf16x6', choices=['f32', 'bf16x3', 'bf16x6', 'f16x3'], help='arithmetic of the dense contractions')
     ap.add_argument('--variant', default='fusetrack', choices=['fusetrack', 'fuse', 'track'],
                     help='detector (SURVEY 8(f) row 4): the headline metric is fusetrack; the variants are single-GPU only')
     ap.add_argument('--conv-table', default=None, help='write the per-layer-shape conv timing table of one frame here')
@@ -190,7 +190,7 @@ def main():
     import vps_amd
     from vps_amd import hip, nhwc, synth
     from vps_amd.clip_shard import ClipShardRunner, DetectorBackend, partition
-    nhwc.DEFAULT_PREC = {'f32': hip.PREC_F32, 'bf16x3': hip.PREC_BF16X3, 'bf16x6': hip.PREC_BF16X6}[args.prec]
+    nhwc.DEFAULT_PREC = nhwc.PREC_NAMES[args.prec]
     Hh, Ww = args.height, args.width
     assert args.variant == 'fusetrack' or world == 1
     cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', args.variant + '.py'))
@@ -306,10 +306,10 @@ def main():
         # that arithmetic: an fp32-grade product costs `nprod` bf16 MFMA products, so peak = dense bf16 MFMA peak / nprod
         # (2500 / 6 = 416.7 for bf16x6, 2500 / 3 for bf16x3); the exact mode issues to the fp32 MFMA pipe (157.3).
         # frac therefore equals executed MFMA TFLOP/s / 2500 (matrix_pipe_*).
-        nprod = {'f32': 1, 'bf16x3': 3, 'bf16x6': 6}[args.prec]
+        nprod = nhwc.MFMA_PRODUCTS[nhwc.PREC_NAMES[args.prec]]
         pipe_peak = PEAK_FP32_MFMA_TFLOPS if args.prec == 'f32' else PEAK_BF16_MFMA_TFLOPS
         peak = pipe_peak / nprod
-        roof = dict(bound='mfma', kernel='conv_mfma_f32_kernel' if args.prec == 'f32' else 'conv_mfma_bf16{h,p,s}_kernel (vps_conv2d family)',
+        roof = dict(bound='mfma', kernel='conv_mfma_f32_kernel' if args.prec == 'f32' else 'conv_mfma_bf16{h,p,s}_kernel<%s> (vps_conv2d family)' % args.prec,
                     achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
                     mfma_products_per_fp32_product=nprod, matrix_pipe_executed_tflops=round(ach * nprod, 1),
                     matrix_pipe_peak=pipe_peak, matrix_pipe_frac=round(ach * nprod / pipe_peak, 4),
@@ -335,6 +335,7 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'f32': 'f32', 'bf16x6': 'f32-grade: bf16x6 split operands on MFMA, f32 accumulate',
+                      'f16x3': 'f32-grade: f16x3 split operands (fp16 pair with scaled residual, 22 significand bits) on MFMA, f32 accumulate',
                       'bf16x3': 'bf16x3 split operands on MFMA, f32 accumulate'}[args.prec], 'data': 'synthetic',
             'config': {'workload': '2-frame pair %s (%s), synthetic %dx%d clip of %d frames, batch 1' % (
                            {'fusetrack': 'FuseTrack', 'fuse': 'PanopticFuse', 'track': 'PanopticTrack'}[args.variant], WORKLOADS[args.variant],

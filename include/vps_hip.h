@@ -46,8 +46,14 @@ enum { VPS_ACT_NONE = 0, VPS_ACT_RELU = 1, VPS_ACT_LEAKY = 2 };
 /* arithmetic of the contraction (accumulation is always fp32):
  *   VPS_PREC_F32    exact fp32 MFMA (v_mfma_f32_32x32x2_f32), needs `w`
  *   VPS_PREC_BF16X3 fp32 operands split into 2 bf16 terms, 3 bf16 MFMAs per product (~2^-16 relative), needs `w_split`
- *   VPS_PREC_BF16X6 3 bf16 terms, 6 bf16 MFMAs per product (~2^-23 relative, fp32-grade), needs `w_split` */
-enum { VPS_PREC_F32 = 0, VPS_PREC_BF16X3 = 2, VPS_PREC_BF16X6 = 3 };
+ *   VPS_PREC_BF16X6 3 bf16 terms, 6 bf16 MFMAs per product (~2^-23 relative, fp32-grade), needs `w_split`
+ *   VPS_PREC_F16X3  fp32 operands split into 2 fp16 terms with a scaled residual, 3 fp16 MFMAs per product, needs `w_split`:
+ *                     x = h0 + 2^-11*h1,  h0 = fp16(x), h1 = fp16((x - h0) * 2^11)        (22 significand bits)
+ *                     w = g0 + g1,        g0 = fp16(w), g1 = fp16(w - g0),  g2 = 2^-11*g0 (exact), w pre-scaled per output channel
+ *                     x*w ~ h0*g0 + h0*g1 + h1*g2   (dropped: 2^-11*h1*g1 and the two residual roundings, <= 3*2^-22 relative)
+ *                   full precision for 2^-14 <= |x| <= 65504 (below: absolute error <= 2^-36; above: fp16 overflow, reported
+ *                   through `status`); weights within 2^-15 of their channel's largest keep 22 bits. */
+enum { VPS_PREC_F32 = 0, VPS_PREC_BF16X3 = 2, VPS_PREC_BF16X6 = 3, VPS_PREC_F16X3 = 4 };
 
 typedef struct vps_conv_desc {
     /* input activation, NHWC */
@@ -82,15 +88,19 @@ typedef struct vps_conv_desc {
     int32_t tile_n;     /* 32, 64 or 128 */
     int32_t ksplit;     /* >=1; >1 needs ws of ksplit*M*cout_pad floats (M = nclass*N*Qh*Qw) */
     float* ws;
-    /* split-bf16 modes: bf16 weight planes (plane p = bf16 RNE of the residual after p terms), no `w`.
-     *   with `offset` (deformable):  [prec][nclass][cout_pad][kpad]
+    /* split modes: 16-bit weight planes, no `w`. P planes: bf16x3 2, bf16x6 3 (plane p = bf16 RNE of the residual after p
+     * terms), f16x3 3 (g0, g1, 2^-11*g0 of the per-channel pre-scaled weight; the scale's inverse is folded into `scale`).
+     *   with `offset` (deformable):  [P][nclass][cout_pad][kpad]
      *   otherwise, MFMA-fragment order (weights go straight to registers, one coalesced 1 KB load per fragment):
-     *                               [prec][nclass][cout_pad/32][kpad/16][lane 0..63][8], lane = 32*((k/8)%2) + cout%32 */
+     *                               [P][nclass][cout_pad/32][kpad/16][lane 0..63][8], lane = 32*((k/8)%2) + cout%32 */
     int32_t prec;       /* VPS_PREC_* */
     const void* w_split;
     /* k ordering of the packed weights: 0 = tap-major k = (ky*KW+kx)*cin_pad + ci;
      * 1 = chunk-major k = ((ci/32)*KH*KW + ky*KW+kx)*32 + ci%32, kpad = KH*KW*ceil(cin_pad/32)*32 (L2-friendly) */
     int32_t korder;
+    /* VPS_PREC_F16X3: device word that gets bit 0 OR-ed in when an activation beyond the fp16 range (|x| > 65504) was staged
+     * (the result of that launch is then not fp32-grade); NULL = not reported. Never written in the other modes. */
+    int32_t* status;
 } vps_conv_desc;
 
 int vps_conv2d(const vps_conv_desc* d, void* stream);

@@ -145,14 +145,14 @@ def _class_map(pan, cls_inds):
     return lut[np.asarray(pan).astype(np.int64)]
 
 
-@pytest.mark.parametrize('prec_name', ['f32', 'bf16x6'])
+@pytest.mark.parametrize('prec_name', ['f32', 'bf16x6', 'f16x3'])
 def test_full_size_outputs_match_reference_golden(dev, prec_name):
     g = np.load(GOLD_FULL)
     gh, gw, n, seed = [int(v) for v in g['meta']]
     assert (gh, gw) == (H, W)
     s1, s2, c5 = [int(v) for v in g['strides']]
     frames = [f.to(dev) for f in synth.synth_clip(H, W, n, seed)]
-    m = _model({'f32': hip.PREC_F32, 'bf16x6': hip.PREC_BF16X6}[prec_name])
+    m = _model(nhwc.PREC_NAMES[prec_name])
     lines, fails = [], []
     id_map, id_back, consistent = {}, {}, True
     for t in range(n):

@@ -25,16 +25,16 @@ def _relmax(got, ref):
     return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12))
 
 
-@pytest.fixture(scope='module', params=['f32', 'bf16x6'])
+@pytest.fixture(scope='module', params=['f32', 'bf16x6', 'f16x3'])
 def setup(dev, request):
-    """every test of this module runs in BOTH fp32-grade arithmetic modes: the exact-fp32 MFMA kernels (library default) and
-    the split-bf16x6 kernels (what bench.py measures, VPS_PREC=bf16x6)"""
+    """every test of this module runs in ALL fp32-grade arithmetic modes: the exact-fp32 MFMA kernels (library default), the
+    split-bf16x6 kernels and the split-fp16x3 kernels (VPS_PREC=bf16x6 / f16x3)"""
     from vps_amd import hip, nhwc
     gold = np.load(GOLD)
     H, W, n, seed = [int(v) for v in gold['meta']]
     cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', 'fusetrack.py'))
     old = nhwc.DEFAULT_PREC
-    nhwc.DEFAULT_PREC = {'f32': hip.PREC_F32, 'bf16x6': hip.PREC_BF16X6}[request.param]
+    nhwc.DEFAULT_PREC = nhwc.PREC_NAMES[request.param]
     try:
         model = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
         sd = synth.load_synth(model, seed)

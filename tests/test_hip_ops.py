@@ -64,10 +64,10 @@ CONV_CASES = [
 ]
 
 
-PRECS = [(hip.PREC_F32, 2e-5), (hip.PREC_BF16X3, 4e-4), (hip.PREC_BF16X6, 2e-5)]
+PRECS = [(hip.PREC_F32, 2e-5), (hip.PREC_BF16X3, 4e-4), (hip.PREC_BF16X6, 2e-5), (hip.PREC_F16X3, 2e-5)]
 
 
-@pytest.mark.parametrize('prec,tol', PRECS, ids=['f32', 'bf16x3', 'bf16x6'])
+@pytest.mark.parametrize('prec,tol', PRECS, ids=['f32', 'bf16x3', 'bf16x6', 'f16x3'])
 @pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'ci%d_co%d_k%d_s%d' % c[:4])
 def test_conv2d_matches_torch_cpu(dev, case, prec, tol):
     cin, cout, k, stride, pad, H, W, act, bn, res = case
@@ -117,7 +117,7 @@ def test_conv_writes_into_concat_window_and_reads_padded_window(dev):
     _cmp(out.to_nchw(), F.conv2d(full, w2, p2.shift.cpu(), padding=1), what='predict_flow on concat')
 
 
-@pytest.mark.parametrize('prec,tol', PRECS, ids=['f32', 'bf16x3', 'bf16x6'])
+@pytest.mark.parametrize('prec,tol', PRECS, ids=['f32', 'bf16x3', 'bf16x6', 'f16x3'])
 @pytest.mark.parametrize('cin,cout,k,pad,H,W', [(1024, 512, 4, 1, 4, 8), (386, 64, 4, 1, 16, 24), (2, 2, 4, 1, 8, 12),
                                                 (256, 256, 2, 0, 14, 14), (162, 16, 4, 1, 20, 28),
                                                 # whole 8x16 patches per parity class: halo-staged kernel
@@ -132,7 +132,7 @@ def test_conv_transpose_matches_torch_cpu(dev, cin, cout, k, pad, H, W, prec, to
     _cmp(out.to_nchw(), ref, rtol=tol, atol=tol * max(1.0, float(ref.abs().max()) / 4), what='deconv')
 
 
-@pytest.mark.parametrize('prec,tol', PRECS[1:], ids=['bf16x3', 'bf16x6'])
+@pytest.mark.parametrize('prec,tol', PRECS[1:], ids=['bf16x3', 'bf16x6', 'f16x3'])
 def test_halo_conv_batch_and_concat_window(dev, prec, tol):
     """halo-staged kernel with N=2 images, reading a channel window of a wider buffer and writing into a concat window"""
     N, H, W = 2, 16, 32
@@ -172,7 +172,7 @@ def test_linear_as_conv_with_nhwc_flatten(dev):
     _cmp(out.t.view(R, 24), ref, what='linear')
 
 
-@pytest.mark.parametrize('prec,tol', PRECS, ids=['f32', 'bf16x3', 'bf16x6'])
+@pytest.mark.parametrize('prec,tol', PRECS, ids=['f32', 'bf16x3', 'bf16x6', 'f16x3'])
 @pytest.mark.parametrize('cin,cout,H,W', [(256, 256, 12, 20), (256, 128, 9, 13), (128, 128, 16, 16)])
 def test_deform_conv_matches_oracle(dev, cin, cout, H, W, prec, tol):
     x = _rand(1, cin, H, W, seed=1)
@@ -182,6 +182,28 @@ def test_deform_conv_matches_oracle(dev, cin, cout, H, W, prec, tol):
     pc = nhwc.PackedConv(w, None, None, 1, 1, device=dev, deform=True, prec=prec)
     out = pc(nhwc.from_nchw(x.to(dev)), ws=nhwc.Workspace(dev), name='o', offset=nhwc.from_nchw(off.to(dev)))
     _cmp(out.to_nchw(), ref, rtol=tol, atol=tol * max(1.0, float(ref.abs().max()) / 4), what='deform conv')
+
+
+def test_f16x3_reports_operands_beyond_the_fp16_range(dev):
+    """VPS_PREC_F16X3: activations above 65504 overflow fp16 -> the launch ORs bit 0 into vps_conv_desc.status and
+    nhwc.check_f16_range raises; in range, wide dynamic range (1e-4 .. 3e4) and per-channel weight scales stay fp32-grade"""
+    x = _rand(1, 64, 16, 32, seed=1) * torch.logspace(-4, 3.9, 64).view(1, 64, 1, 1)      # |x| up to ~3e4
+    w = _rand(96, 64, 3, 3, seed=2, scale=0.05) * torch.logspace(-3, 2, 96).view(96, 1, 1, 1)
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    den = F.conv2d(x.double().abs(), w.double().abs(), padding=1)
+    pc = nhwc.PackedConv(w, None, None, 1, 1, device=dev, prec=hip.PREC_F16X3)
+    nhwc.check_f16_range(dev)
+    out = pc(nhwc.from_nchw(x.to(dev)), ws=nhwc.Workspace(dev), name='o').to_nchw().cpu().double()
+    nhwc.check_f16_range(dev)                                   # in range: no report
+    rel = float(((out - ref).abs() / den).max())
+    f32 = float(((F.conv2d(x, w, padding=1).double() - ref).abs() / den).max())
+    print('f16x3 error / sum|x||w| = %.2e (plain fp32 CPU conv: %.2e)' % (rel, f32))
+    assert rel < 4e-7
+    xb = x.clone(); xb[0, 5, 3, 7] = 7.0e4
+    pc(nhwc.from_nchw(xb.to(dev)), ws=nhwc.Workspace(dev), name='o')
+    with pytest.raises(hip.VpsHipError):
+        nhwc.check_f16_range(dev)
+    nhwc.check_f16_range(dev)                                   # the report clears the word
 
 
 # ------------------------------------------------------------------------------------------------ flow ops

@@ -408,27 +408,78 @@ void conv_mfma_f32_kernel(const vps_conv_desc d, const int M, const int tiles_m,
 // ================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int LDS_LDH = 32;   // bf16 elements per LDS row = 64 bytes, no padding: the four 16-byte chunks of a row are
+template <class T> using vec8 = T __attribute__((ext_vector_type(8)));
+template <class T> using vec4 = T __attribute__((ext_vector_type(4)));
+constexpr int LDS_LDH = 32;   // 16-bit elements per LDS row = 64 bytes, no padding: the four 16-byte chunks of a row are
                               // XOR-swizzled with (row>>2)&3, which makes the 8-byte/16-byte staging writes of two consecutive
                               // rows cover all 32 banks once and the 16-lane groups of the fragment ds_read_b128 hit 16
                               // distinct 16-byte slots (the padded 80-byte layout measured 33 % conflict cycles)
 __device__ __forceinline__ int lds_swz(int row) { return (row >> 2) & 3; }
 
-template <int NS>
-__device__ __forceinline__ void split_bf16(const f32x4 v, bf16x4 (&out)[NS]) {
-    f32x4 r = v;
-#pragma unroll
-    for (int p = 0; p < NS; ++p) {
+// The split arithmetics (vps_conv_desc.prec). NSA activation planes (staged in LDS), NSB weight planes (packed on the host),
+// NT products per k-slab: term q multiplies activation plane PA[q] with weight plane PB[q], smallest magnitude first.
+template <int MODE> struct Split;
+template <> struct Split<VPS_PREC_BF16X3> {
+    typedef __bf16 elem;
+    static constexpr int NSA = 2, NSB = 2, NT = 3;
+    static constexpr int PA[6] = {1, 0, 0, 0, 0, 0};
+    static constexpr int PB[6] = {0, 1, 0, 0, 0, 0};
+};
+template <> struct Split<VPS_PREC_BF16X6> {
+    typedef __bf16 elem;
+    static constexpr int NSA = 3, NSB = 3, NT = 6;
+    static constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    static constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+};
+// fp16 with a scaled residual: x = h0 + 2^-11 h1 (planes 0, 1); weights g0, g1, g2 = 2^-11 g0 (planes 0, 1, 2):
+// x*w ~ h0*g1 + h1*g2 + h0*g0. See VPS_PREC_F16X3 in vps_hip.h for the error / range statement.
+template <> struct Split<VPS_PREC_F16X3> {
+    typedef _Float16 elem;
+    static constexpr int NSA = 2, NSB = 3, NT = 3;
+    static constexpr int PA[6] = {0, 1, 0, 0, 0, 0};
+    static constexpr int PB[6] = {1, 2, 0, 0, 0, 0};
+};
+
+template <int MODE>
+__device__ __forceinline__ f32x16 split_mfma(const vec8<typename Split<MODE>::elem> a, const vec8<typename Split<MODE>::elem> b, const f32x16 c) {
+    if constexpr (MODE == VPS_PREC_F16X3) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// fp32 float4 -> NSA planes of 4 elements. `amax` tracks max |x| of the staged values in the fp16 mode (range report).
+template <int MODE>
+__device__ __forceinline__ void split_act(const f32x4 v, vec4<typename Split<MODE>::elem> (&out)[Split<MODE>::NSA], float& amax) {
+    if constexpr (MODE == VPS_PREC_F16X3) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const __bf16 h = (__bf16)r[e];
-            out[p][e] = h;
-            r[e] -= (float)h;
+            const _Float16 h0 = (_Float16)v[e];
+            out[0][e] = h0;
+            out[1][e] = (_Float16)((v[e] - (float)h0) * 2048.f);
+        }
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    } else {
+        f32x4 r = v;
+#pragma unroll
+        for (int p = 0; p < Split<MODE>::NSA; ++p) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const __bf16 h = (__bf16)r[e];
+                out[p][e] = h;
+                r[e] -= (float)h;
+            }
         }
     }
 }
 
-template <int TM, int TN, int WAVES_M, int WAVES_N, int NS, bool DEFORM>
+// fp16 mode: an activation beyond the fp16 range was staged by this thread -> OR bit 0 into the caller's status word
+template <int MODE>
+__device__ __forceinline__ void report_range(const vps_conv_desc& d, const float amax) {
+    if constexpr (MODE == VPS_PREC_F16X3) {
+        if (d.status && !(amax <= 65504.f)) atomicOr(d.status, 1);
+    }
+}
+
+template <int TM, int TN, int WAVES_M, int WAVES_N, int MODE, bool DEFORM>
 __global__ __launch_bounds__(256, 2)
 void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_m, const int tiles_n,
                             const int ksteps_per_split) {
@@ -436,9 +487,14 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
     static_assert(WAVES_M * TM * 32 == BM, "block M tile must be 128");
     static_assert(WAVES_M * WAVES_N == 4, "4 wavefronts per block");
     constexpr int NBCH = (BN * 4 + 255) / 256;   // 16-byte weight chunks per thread per plane per k-step
+    typedef Split<MODE> SM;
+    typedef typename SM::elem elem_t;
+    typedef vec8<elem_t> x8;
+    typedef vec4<elem_t> x4;
+    constexpr int NSA = SM::NSA, NSB = SM::NSB;
 
-    __shared__ __attribute__((aligned(16))) __bf16 As[NS][BM * LDS_LDH];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[NS][BN * LDS_LDH];
+    __shared__ __attribute__((aligned(16))) elem_t As[NSA][BM * LDS_LDH];
+    __shared__ __attribute__((aligned(16))) elem_t Bs[NSB][BN * LDS_LDH];
 
     const int t = threadIdx.x;
     int swz = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -450,7 +506,7 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
     const int py = cls / d.os_x, px = cls - py * d.os_x;
     const int pad_y = d.pad_y[py], pad_x = d.pad_x[px];
     const size_t plane = (size_t)d.nclass * d.cout_pad * d.kpad;   // elements per weight plane
-    const __bf16* __restrict__ wcls = reinterpret_cast<const __bf16*>(d.w_split) + (size_t)cls * d.cout_pad * d.kpad;
+    const elem_t* __restrict__ wcls = reinterpret_cast<const elem_t*>(d.w_split) + (size_t)cls * d.cout_pad * d.kpad;
 
     const int H = d.H, W = d.W, KH = d.KH, KW = d.KW, cin_pad = d.cin_pad;
     const int k4 = t & 7;
@@ -499,11 +555,12 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
     }
     // weight chunk of this thread: row bw_r (+64 per extra chunk), 8 bf16 starting at k = 8*bw_c
     const int bw_c = t & 3, bw_r = t >> 2;
-    const __bf16* __restrict__ wrow = wcls + (size_t)(tile_n * BN + bw_r) * d.kpad + (size_t)kstep0 * BK + bw_c * 8;
+    const elem_t* __restrict__ wrow = wcls + (size_t)(tile_n * BN + bw_r) * d.kpad + (size_t)kstep0 * BK + bw_c * 8;
 
     f32x4 areg[4];
     unsigned aok = 0;   // bit i: staged row i of the tile in flight is inside the image
-    bf16x8 breg[NS][NBCH];
+    x8 breg[NSB][NBCH];
+    float amax = 0.f;
     f32x4 dcv[DEFORM ? 4 : 1][4];
     float dcw[DEFORM ? 4 : 1][4];
 
@@ -552,11 +609,11 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
             }
         }
 #pragma unroll
-        for (int p = 0; p < NS; ++p)
+        for (int p = 0; p < NSB; ++p)
 #pragma unroll
             for (int j = 0; j < NBCH; ++j)
                 if (BN * 4 >= 256 || t < BN * 4)
-                    breg[p][j] = *reinterpret_cast<const bf16x8*>(wrow + (size_t)p * plane + (size_t)(64 * j) * d.kpad + (size_t)step * BK);
+                    breg[p][j] = *reinterpret_cast<const x8*>(wrow + (size_t)p * plane + (size_t)(64 * j) * d.kpad + (size_t)step * BK);
         if (korder == 0) {
             ci += BK;
             while (ci >= cin_pad) {
@@ -579,18 +636,18 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 v = ((aok >> i) & 1u) ? areg[i] : z;
             }
-            bf16x4 sp[NS];
-            split_bf16<NS>(v, sp);
+            x4 sp[NSA];
+            split_act<MODE>(v, sp, amax);
 #pragma unroll
-            for (int p = 0; p < NS; ++p)
-                *reinterpret_cast<bf16x4*>(&As[p][(r0 + 32 * i) * LDS_LDH + (((k4 >> 1) ^ lds_swz(r0 + 32 * i)) << 3) + ((k4 & 1) << 2)]) = sp[p];
+            for (int p = 0; p < NSA; ++p)
+                *reinterpret_cast<x4*>(&As[p][(r0 + 32 * i) * LDS_LDH + (((k4 >> 1) ^ lds_swz(r0 + 32 * i)) << 3) + ((k4 & 1) << 2)]) = sp[p];
         }
 #pragma unroll
-        for (int p = 0; p < NS; ++p)
+        for (int p = 0; p < NSB; ++p)
 #pragma unroll
             for (int j = 0; j < NBCH; ++j)
                 if (BN * 4 >= 256 || t < BN * 4)
-                    *reinterpret_cast<bf16x8*>(&Bs[p][(bw_r + 64 * j) * LDS_LDH + ((bw_c ^ lds_swz(bw_r + 64 * j)) << 3)]) = breg[p][j];
+                    *reinterpret_cast<x8*>(&Bs[p][(bw_r + 64 * j) * LDS_LDH + ((bw_c ^ lds_swz(bw_r + 64 * j)) << 3)]) = breg[p][j];
     };
 
     const int lane = t & 63, wave = t >> 6;
@@ -620,27 +677,25 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
 #pragma unroll
         for (int m = 0; m < 2; ++m) {            // two K=16 MFMA slabs per 32-wide k-step
             const int frag_off = frag_row + frag_chunk[m];
-            bf16x8 af[NS][TM], bf[NS][TN];
+            x8 af[NSA][TM], bf[NSB][TN];
 #pragma unroll
-            for (int p = 0; p < NS; ++p) {
+            for (int p = 0; p < NSA; ++p)
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
-                    af[p][a] = *reinterpret_cast<const bf16x8*>(&As[p][(wm * TM * 32 + a * 32) * LDS_LDH + frag_off]);
+                    af[p][a] = *reinterpret_cast<const x8*>(&As[p][(wm * TM * 32 + a * 32) * LDS_LDH + frag_off]);
+#pragma unroll
+            for (int p = 0; p < NSB; ++p)
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    bf[p][b] = *reinterpret_cast<const bf16x8*>(&Bs[p][(wn * TN * 32 + b * 32) * LDS_LDH + frag_off]);
-            }
+                    bf[p][b] = *reinterpret_cast<const x8*>(&Bs[p][(wn * TN * 32 + b * 32) * LDS_LDH + frag_off]);
             // product terms outermost (smallest first), accumulators innermost: consecutive MFMAs never depend on each other
-            constexpr int NT = NS == 3 ? 6 : 3;
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-            constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int q = 6 - NT; q < 6; ++q)
+            for (int q = 0; q < SM::NT; ++q)
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[PB[q]][b], af[PA[q]][a], acc[a][b], 0, 0, 0);
+                        acc[a][b] = split_mfma<MODE>(bf[SM::PB[q]][b], af[SM::PA[q]][a], acc[a][b]);
         }
         __syncthreads();
         if (more) {
@@ -648,6 +703,7 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
             __syncthreads();
         }
     }
+    report_range<MODE>(d, amax);
     conv_epilogue<TM, TN, BN>(d, acc, M, tile_m, tile_n, cls, split, py, px, wm, wn, lane);
 }
 
@@ -672,16 +728,21 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
 //     wave keeps the matrix pipe, the LDS pipe and the memory pipe busy at the same time instead of in turns.
 // The loop body is branch-free: loads past the last k-step are clamped / masked rather than skipped.
 // ================================================================================================
-template <int TM, int TN, int WAVES_M, int WAVES_N, int NS>
+template <int TM, int TN, int WAVES_M, int WAVES_N, int MODE>
 __global__ __launch_bounds__(256, 2)
 void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_m, const int tiles_n,
                             const int ksteps_per_split) {
     constexpr int BN = WAVES_N * TN * 32;
     static_assert(WAVES_M * TM * 32 == BM, "block M tile must be 128");
     static_assert(WAVES_M * WAVES_N == 4, "4 wavefronts per block");
-    constexpr int ABUF = NS * BM * LDS_LDH;      // bf16 elements of one activation buffer (all planes)
+    typedef Split<MODE> SM;
+    typedef typename SM::elem elem_t;
+    typedef vec8<elem_t> x8;
+    typedef vec4<elem_t> x4;
+    constexpr int NSA = SM::NSA, NSB = SM::NSB;
+    constexpr int ABUF = NSA * BM * LDS_LDH;     // 16-bit elements of one activation buffer (all planes)
 
-    __shared__ __attribute__((aligned(16))) __bf16 As[2 * ABUF];
+    __shared__ __attribute__((aligned(16))) elem_t As[2 * ABUF];
 
     const int t = threadIdx.x;
     int swz = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -735,12 +796,13 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
     // B fragments of this wave: 32-column blocks nb0 .. nb0+TN-1, k-slab ks, plane p
     const int nbt = d.cout_pad >> 5, kst = d.kpad >> 4;
     const size_t wplane = (size_t)d.nclass * nbt * kst * 512;
-    const __bf16* __restrict__ wfrag = reinterpret_cast<const __bf16*>(d.w_split) +
+    const elem_t* __restrict__ wfrag = reinterpret_cast<const elem_t*>(d.w_split) +
         ((size_t)(cls * nbt + tile_n * (BN / 32) + wn * TN) * kst + 2 * (size_t)kstep0) * 512 + lane * 8;
 
     f32x4 areg[4];
     unsigned aok = 0;   // bit i: staged row i is inside the image and inside the channel range
-    bf16x8 bnext[2][NS][TN];
+    x8 bnext[2][NSB][TN];
+    float amax = 0.f;
 
     // activation tile of the next k-step -> registers (sequential: every call advances the k state by one step)
     auto load_A = [&]() {
@@ -783,31 +845,31 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
     auto load_B = [&](int step, int m, int p) {
 #pragma unroll
         for (int b = 0; b < TN; ++b)
-            bnext[m][p][b] = *reinterpret_cast<const bf16x8*>(wfrag + (size_t)p * wplane + ((size_t)b * kst + 2 * step + m) * 512);
+            bnext[m][p][b] = *reinterpret_cast<const x8*>(wfrag + (size_t)p * wplane + ((size_t)b * kst + 2 * step + m) * 512);
     };
 
     // split staged row i and write it into activation buffer `buf`
     auto store_A = [&](int i, int buf) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        bf16x4 sp[NS];
-        split_bf16<NS>(((aok >> i) & 1u) ? areg[i] : z, sp);
+        x4 sp[NSA];
+        split_act<MODE>(((aok >> i) & 1u) ? areg[i] : z, sp, amax);
         const int row = r0 + 32 * i;
 #pragma unroll
-        for (int p = 0; p < NS; ++p)
-            *reinterpret_cast<bf16x4*>(&As[buf * ABUF + p * (BM * LDS_LDH) + row * LDS_LDH + (((k4 >> 1) ^ lds_swz(row)) << 3) + ((k4 & 1) << 2)]) = sp[p];
+        for (int p = 0; p < NSA; ++p)
+            *reinterpret_cast<x4*>(&As[buf * ABUF + p * (BM * LDS_LDH) + row * LDS_LDH + (((k4 >> 1) ^ lds_swz(row)) << 3) + ((k4 & 1) << 2)]) = sp[p];
     };
 
     // fragment of slab m: logical 16-byte chunk 2m + (lane>>5) of row (lane&31), swizzled like the writes
     const int frag_row = (wm * TM * 32 + (lane & 31)) * LDS_LDH;
     const int frag_sw = lds_swz(lane & 31);
     const int frag_chunk[2] = {(((lane >> 5)) ^ frag_sw) << 3, ((2 + (lane >> 5)) ^ frag_sw) << 3};
-    bf16x8 af[2][NS][TM];
+    x8 af[2][NSA][TM];
     auto read_A = [&](int m, int buf) {
 #pragma unroll
-        for (int p = 0; p < NS; ++p)
+        for (int p = 0; p < NSA; ++p)
 #pragma unroll
             for (int a = 0; a < TM; ++a)
-                af[m][p][a] = *reinterpret_cast<const bf16x8*>(&As[buf * ABUF + p * (BM * LDS_LDH) + a * 32 * LDS_LDH + frag_row + frag_chunk[m]]);
+                af[m][p][a] = *reinterpret_cast<const x8*>(&As[buf * ABUF + p * (BM * LDS_LDH) + a * 32 * LDS_LDH + frag_row + frag_chunk[m]]);
     };
 
     f32x16 acc[TM][TN];
@@ -824,7 +886,7 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int p = 0; p < NS; ++p) load_B(0, m, p);
+            for (int p = 0; p < NSB; ++p) load_B(0, m, p);
 #pragma unroll
         for (int i = 0; i < 4; ++i) store_A(i, 0);
         load_A();
@@ -832,20 +894,18 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
     __syncthreads();
 
     // work items interleaved between the MFMAs of a k-step (program order; positions are compile-time after unrolling)
-    constexpr int NT = NS == 3 ? 6 : 3;
+    constexpr int NT = SM::NT;
     constexpr int NMF = 2 * NT * TM * TN;            // MFMAs per wave and k-step
-    constexpr int NW = 4 + 1 + 1 + 2 * NS;           // 4 row stagings, slab-1 fragment reads, next A loads, 2*NS weight loads
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int NW = 4 + 1 + 1 + 2 * NSB;          // 4 row stagings, slab-1 fragment reads, next A loads, 2*NSB weight loads
 
     for (int step = 0; step < nsteps; ++step) {
         const int cur = step & 1;
         const int bstep = min(step + 1, nsteps - 1);   // weights of the next step (clamped: the last prefetch is unused)
-        bf16x8 bcur[2][NS][TN];
+        x8 bcur[2][NSB][TN];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int p = 0; p < NS; ++p)
+            for (int p = 0; p < NSB; ++p)
 #pragma unroll
                 for (int b = 0; b < TN; ++b) bcur[m][p][b] = bnext[m][p][b];
         read_A(0, cur);
@@ -856,19 +916,19 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
             else if (w == 2) read_A(1, cur);                      // fragments of the second slab
             else if (w < 5) store_A(w - 1, cur ^ 1);
             else if (w == 5) load_A();                            // tile step+2 -> registers
-            else load_B(bstep, (w - 6) / NS, (w - 6) % NS);       // weights of step+1 -> registers
+            else load_B(bstep, (w - 6) / NSB, (w - 6) % NSB);       // weights of step+1 -> registers
         };
 
         int mf = 0;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int q = 6 - NT; q < 6; ++q)
+            for (int q = 0; q < NT; ++q)
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b) {
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bcur[m][PB[q]][b], af[m][PA[q]][a], acc[a][b], 0, 0, 0);
+                        acc[a][b] = split_mfma<MODE>(bcur[m][SM::PB[q]][b], af[m][SM::PA[q]][a], acc[a][b]);
                         ++mf;
                         // item w runs after MFMA number max(1, (w+1)*NMF/(NW+1)): evenly spread, and the slab-1 fragment
                         // reads (item 2) always land in the first quarter of the stream, well before their consumers
@@ -884,6 +944,7 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
                     }
         __syncthreads();
     }
+    report_range<MODE>(d, amax);
     conv_epilogue<TM, TN, BN>(d, acc, M, tile_m, tile_n, cls, split, py, px, wm, wn, lane);
 }
 
@@ -898,7 +959,7 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
 // r01_pipebench.txt), so every removed instruction is time. The tap loop is fully unrolled (KH, KW are template
 // parameters), so which work item goes between which MFMAs is decided at compile time.
 // ================================================================================================
-template <int TM, int TN, int WAVES_M, int WAVES_N, int NS, int KH, int KW>
+template <int TM, int TN, int WAVES_M, int WAVES_N, int MODE, int KH, int KW>
 __global__ __launch_bounds__(256, 2)
 void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int tiles_n, const int chunks_per_split) {
     constexpr int BN = WAVES_N * TN * 32;
@@ -908,10 +969,15 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
     constexpr int HW = 16 + KW - 1, HH = 8 + KH - 1;   // halo tile
     constexpr int HROWS = HH * HW;                      // <= 180
     constexpr int NLD = (HROWS + 31) / 32;              // staged rows per thread (32 rows per pass of the 256 threads)
-    constexpr int PLANE = NLD * 32 * LDS_LDH;           // bf16 elements of one plane of one buffer
-    constexpr int ABUF = NS * PLANE;
+    typedef Split<MODE> SM;
+    typedef typename SM::elem elem_t;
+    typedef vec8<elem_t> x8;
+    typedef vec4<elem_t> x4;
+    constexpr int NSA = SM::NSA, NSB = SM::NSB;
+    constexpr int PLANE = NLD * 32 * LDS_LDH;           // 16-bit elements of one plane of one buffer
+    constexpr int ABUF = NSA * PLANE;
 
-    __shared__ __attribute__((aligned(16))) __bf16 As[2 * ABUF];
+    __shared__ __attribute__((aligned(16))) elem_t As[2 * ABUF];
 
     const int t = threadIdx.x;
     int swz = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -938,13 +1004,14 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
     const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
     const int nbt = d.cout_pad >> 5, kst = d.kpad >> 4;
     const size_t wplane = (size_t)d.nclass * nbt * kst * 512;
-    const __bf16* __restrict__ wfrag = reinterpret_cast<const __bf16*>(d.w_split) +
+    const elem_t* __restrict__ wfrag = reinterpret_cast<const elem_t*>(d.w_split) +
         ((size_t)(cls * nbt + tile_n * (BN / 32) + wn * TN) * kst + 2 * (size_t)chunk0 * NTAP) * 512 + lane * 8;
 
     f32x4 areg[NLD];
     unsigned aok = 0;
     int achunk = chunk0;       // next chunk to load
-    bf16x8 bnext[2][NS][TN];
+    x8 bnext[2][NSB][TN];
+    float amax = 0.f;
 
     auto load_A = [&]() {
         const int cic = achunk * BK + k4 * 4;
@@ -967,16 +1034,16 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
     auto load_B = [&](int step, int m, int p) {
 #pragma unroll
         for (int b = 0; b < TN; ++b)
-            bnext[m][p][b] = *reinterpret_cast<const bf16x8*>(wfrag + (size_t)p * wplane + ((size_t)b * kst + 2 * step + m) * 512);
+            bnext[m][p][b] = *reinterpret_cast<const x8*>(wfrag + (size_t)p * wplane + ((size_t)b * kst + 2 * step + m) * 512);
     };
     auto store_A = [&](int i, int buf) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        bf16x4 sp[NS];
-        split_bf16<NS>(((aok >> i) & 1u) ? areg[i] : z, sp);
+        x4 sp[NSA];
+        split_act<MODE>(((aok >> i) & 1u) ? areg[i] : z, sp, amax);
         const int row = r0 + 32 * i;
 #pragma unroll
-        for (int p = 0; p < NS; ++p)
-            *reinterpret_cast<bf16x4*>(&As[buf * ABUF + p * PLANE + row * LDS_LDH + (((k4 >> 1) ^ lds_swz(row)) << 3) + ((k4 & 1) << 2)]) = sp[p];
+        for (int p = 0; p < NSA; ++p)
+            *reinterpret_cast<x4*>(&As[buf * ABUF + p * PLANE + row * LDS_LDH + (((k4 >> 1) ^ lds_swz(row)) << 3) + ((k4 & 1) << 2)]) = sp[p];
     };
 
     // halo row of tile row j = wm*TM*32 + a*32 + (lane&31) for tap (0,0); tap (ky,kx) adds ky*HW + kx
@@ -986,14 +1053,14 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
         const int j = wm * TM * 32 + a * 32 + (lane & 31);
         hbase[a] = (j >> 4) * HW + (j & 15);
     }
-    bf16x8 af[2][NS][TM];
+    x8 af[2][NSA][TM];
     auto read_A = [&](int m, int buf, int toff) {
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             const int hrow = hbase[a] + toff;
             const int off = buf * ABUF + hrow * LDS_LDH + (((2 * m + (lane >> 5)) ^ lds_swz(hrow)) << 3);
 #pragma unroll
-            for (int p = 0; p < NS; ++p) af[m][p][a] = *reinterpret_cast<const bf16x8*>(&As[off + p * PLANE]);
+            for (int p = 0; p < NSA; ++p) af[m][p][a] = *reinterpret_cast<const x8*>(&As[off + p * PLANE]);
         }
     };
 
@@ -1010,16 +1077,14 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int p = 0; p < NS; ++p) load_B(0, m, p);
+        for (int p = 0; p < NSB; ++p) load_B(0, m, p);
 #pragma unroll
     for (int i = 0; i < NLD; ++i) store_A(i, 0);
     load_A();
     __syncthreads();
 
-    constexpr int NT = NS == 3 ? 6 : 3;
+    constexpr int NT = SM::NT;
     constexpr int NMF = 2 * NT * TM * TN;                       // MFMAs per wave and tap
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
     constexpr int SPT = (NLD + NTAP - 2) / (NTAP - 1);          // halo rows staged per tap (the last tap issues the loads)
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -1029,19 +1094,19 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
             const int step = chunk * NTAP + tp;
             const int bstep = min(step + 1, nsteps - 1);        // weights of the next step (clamped: the last prefetch is unused)
             const int toff = (tp / KW) * HW + (tp % KW);
-            bf16x8 bcur[2][NS][TN];
+            x8 bcur[2][NSB][TN];
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int p = 0; p < NS; ++p)
+                for (int p = 0; p < NSB; ++p)
 #pragma unroll
                     for (int b = 0; b < TN; ++b) bcur[m][p][b] = bnext[m][p][b];
             read_A(0, cur, toff);
             __builtin_amdgcn_sched_barrier(0);
 
             // work items of this tap: SPT halo-row stagings (or, on the last tap, the loads of chunk+2), the fragment reads
-            // of the second slab, 2*NS weight loads of the next step
-            const int NW = SPT + 1 + 2 * NS;
+            // of the second slab, 2*NSB weight loads of the next step
+            const int NW = SPT + 1 + 2 * NSB;
             auto work = [&](const int w) {
                 if (w == 1) read_A(1, cur, toff);
                 else if (w == 0 || (w >= 2 && w < SPT + 1)) {
@@ -1050,19 +1115,19 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
                         const int row = tp * SPT + si;
                         if (row < NLD) store_A(row, cur ^ 1);
                     } else if (si == 0) load_A();
-                } else load_B(bstep, (w - SPT - 1) / NS, (w - SPT - 1) % NS);
+                } else load_B(bstep, (w - SPT - 1) / NSB, (w - SPT - 1) % NSB);
             };
 
             int mf = 0;
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int q = 6 - NT; q < 6; ++q)
+                for (int q = 0; q < NT; ++q)
 #pragma unroll
                     for (int a = 0; a < TM; ++a)
 #pragma unroll
                         for (int b = 0; b < TN; ++b) {
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bcur[m][PB[q]][b], af[m][PA[q]][a], acc[a][b], 0, 0, 0);
+                            acc[a][b] = split_mfma<MODE>(bcur[m][SM::PB[q]][b], af[m][SM::PA[q]][a], acc[a][b]);
                             ++mf;
 #pragma unroll
                             for (int w = 0; w < NW; ++w) {
@@ -1077,6 +1142,7 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
         }
         __syncthreads();
     }
+    report_range<MODE>(d, amax);
     conv_epilogue<TM, TN, BN, true>(d, acc, tiles_m * BM, tile_m, tile_n, cls, split, py, px, wm, wn, lane);
 }
 
@@ -1358,11 +1424,12 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
         const int tiles_m2 = (int)tiles2d;
         const long nblk2 = (long)tiles_m2 * tiles_n * d.nclass * d.ksplit;
         if (nblk2 > 0x7fffffffL) return VPS_EARG(21);
-#define VPS_HALO_LAUNCH(NS, K)                                                                                                    \
-    hipLaunchKernelGGL((conv_mfma_bf16h_kernel<TM, TN, WAVES_M, WAVES_N, NS, K, K>), dim3((unsigned)nblk2), dim3(256), 0, s, d, tiles_m2, \
+#define VPS_HALO_LAUNCH(MODE, K)                                                                                                  \
+    hipLaunchKernelGGL((conv_mfma_bf16h_kernel<TM, TN, WAVES_M, WAVES_N, MODE, K, K>), dim3((unsigned)nblk2), dim3(256), 0, s, d, tiles_m2, \
                        tiles_n, per_split / ntap)
-        if (d.prec == VPS_PREC_BF16X3) { if (d.KH == 3) VPS_HALO_LAUNCH(2, 3); else VPS_HALO_LAUNCH(2, 2); }
-        else { if (d.KH == 3) VPS_HALO_LAUNCH(3, 3); else VPS_HALO_LAUNCH(3, 2); }
+        if (d.prec == VPS_PREC_BF16X3) { if (d.KH == 3) VPS_HALO_LAUNCH(VPS_PREC_BF16X3, 3); else VPS_HALO_LAUNCH(VPS_PREC_BF16X3, 2); }
+        else if (d.prec == VPS_PREC_F16X3) { if (d.KH == 3) VPS_HALO_LAUNCH(VPS_PREC_F16X3, 3); else VPS_HALO_LAUNCH(VPS_PREC_F16X3, 2); }
+        else { if (d.KH == 3) VPS_HALO_LAUNCH(VPS_PREC_BF16X6, 3); else VPS_HALO_LAUNCH(VPS_PREC_BF16X6, 2); }
 #undef VPS_HALO_LAUNCH
     } else {
 #define VPS_CONV_LAUNCH(KERNEL)                                                                              \
@@ -1371,11 +1438,14 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
         if (d.offset) VPS_CONV_LAUNCH((conv_mfma_f32_kernel<TM, TN, WAVES_M, WAVES_N, true>));
         else VPS_CONV_LAUNCH((conv_mfma_f32_kernel<TM, TN, WAVES_M, WAVES_N, false>));
     } else if (d.prec == VPS_PREC_BF16X3) {
-        if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, 2, true>));
-        else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, 2>));
+        if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X3, true>));
+        else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X3>));
+    } else if (d.prec == VPS_PREC_F16X3) {
+        if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_F16X3, true>));
+        else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_F16X3>));
     } else {
-        if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, 3, true>));
-        else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, 3>));
+        if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X6, true>));
+        else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X6>));
     }
 #undef VPS_CONV_LAUNCH
     }
@@ -1398,7 +1468,7 @@ extern "C" int vps_conv2d(const vps_conv_desc* dp, void* stream) {
     if (!dp) return VPS_EARG(1);
     const vps_conv_desc& d = *dp;
     if (!d.in || !d.out) return VPS_EARG(2);
-    if (d.prec != VPS_PREC_F32 && d.prec != VPS_PREC_BF16X3 && d.prec != VPS_PREC_BF16X6) return VPS_EARG(12);
+    if (d.prec != VPS_PREC_F32 && d.prec != VPS_PREC_BF16X3 && d.prec != VPS_PREC_BF16X6 && d.prec != VPS_PREC_F16X3) return VPS_EARG(12);
     if (d.prec == VPS_PREC_F32 ? !d.w : !d.w_split) return VPS_EARG(13);
     if ((d.in_ld & 3) || (d.in_coff & 3) || (d.cin_pad & 3) || d.cin_pad <= 0) return VPS_EARG(3);
     if ((d.kpad % BK) || d.kpad < d.KH * d.KW * d.cin_pad || (d.korder != 0 && d.korder != 1)) return VPS_EARG(4);

@@ -301,6 +301,7 @@ class PanopticFuseTrack(HipModule):
             main.wait_stream(side)         # the combine kernel reads fcn_score
         # (9)-(11) MaskRemoval + SegTerm + combine ---------------------------------------------------------------
         keep_inds, ref_boxes, masks_valid = self.mask_removal(mask_rois[:, 1:], cls_prob, mask_score, cls_idx, (H, W), ws)
+        nhwc.check_f16_range(dev)          # f16x3 only (no-op otherwise): every convolution of the frame has run by now
         rois_np = mask_rois[:, 1:].cpu().numpy()
         cls_np = cls_idx.cpu().numpy()
         pan, sem = panoptic_combine(fcn_score, rois_np, cls_np, ref_boxes, keep_inds, mask_score, self.class_mapping,

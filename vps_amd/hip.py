@@ -14,10 +14,10 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VPS_HIP_LIB: developer override to load an experimental build of the same ABI (kernel A/B timing)
 LIB_PATH = os.environ.get('VPS_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libvpship.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
-PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 2, 3
+PREC_F32, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 2, 3, 4
 
 # every symbol include/vps_hip.h declares (checked by tests/test_cabi.py without a GPU)
 SYMBOLS = [
@@ -44,7 +44,7 @@ class ConvDesc(Structure):
         ('act', c_int32), ('slope', c_float),
         ('offset', c_void_p), ('off_ld', c_int32),
         ('tile_n', c_int32), ('ksplit', c_int32), ('ws', c_void_p),
-        ('prec', c_int32), ('w_split', c_void_p), ('korder', c_int32),
+        ('prec', c_int32), ('w_split', c_void_p), ('korder', c_int32), ('status', c_void_p),
     ]
 
 

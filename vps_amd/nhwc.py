@@ -19,10 +19,27 @@ def _ceil(a, b):
     return (a + b - 1) // b * b
 
 
-# arithmetic of every PackedConv created without an explicit `prec` (hip.PREC_F32 exact / PREC_BF16X3 / PREC_BF16X6).
-# The library default is the exact fp32 mode; VPS_PREC=bf16x6 (fp32-grade, what bench.py measures) / bf16x3 / f32 selects it
+# arithmetic of every PackedConv created without an explicit `prec` (hip.PREC_F32 exact / PREC_BF16X3 / PREC_BF16X6 / PREC_F16X3).
+# The library default is the exact fp32 mode; VPS_PREC=bf16x6 / f16x3 (fp32-grade split modes) / bf16x3 / f32 selects it
 # for an unmodified caller such as tools/test_vpq.py.
-_PREC_NAMES = {'f32': hip.PREC_F32, 'bf16x3': hip.PREC_BF16X3, 'bf16x6': hip.PREC_BF16X6}
+_PREC_NAMES = {'f32': hip.PREC_F32, 'bf16x3': hip.PREC_BF16X3, 'bf16x6': hip.PREC_BF16X6, 'f16x3': hip.PREC_F16X3}
+PREC_NAMES = _PREC_NAMES
+# number of 16-bit weight planes / MFMA products per fp32 product of each split mode
+_PLANES = {hip.PREC_BF16X3: 2, hip.PREC_BF16X6: 3, hip.PREC_F16X3: 3}
+MFMA_PRODUCTS = {hip.PREC_F32: 1, hip.PREC_BF16X3: 3, hip.PREC_BF16X6: 6, hip.PREC_F16X3: 3}
+# f16x3: one device word per device; a conv launch ORs bit 0 into it when it staged an activation beyond the fp16 range
+_F16_STATUS = {}
+
+
+def f16_status(device):
+    """the range-report word of the f16x3 mode on `device` (int32 tensor [1]); PanopticFuseTrack checks and clears it every frame"""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else (torch.cuda.current_device() if device.type == 'cuda' else 0))
+    t = _F16_STATUS.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int32, device=device)
+        _F16_STATUS[key] = t
+    return t
 if os.environ.get('VPS_PREC', 'f32') not in _PREC_NAMES:
     raise ValueError('VPS_PREC must be one of %s' % sorted(_PREC_NAMES))
 DEFAULT_PREC = _PREC_NAMES[os.environ.get('VPS_PREC', 'f32')]
@@ -30,6 +47,18 @@ DEFAULT_PREC = _PREC_NAMES[os.environ.get('VPS_PREC', 'f32')]
 # bench.py sets this to a list to time every vps_conv2d launch with HIP events on the launch stream:
 # entries (algorithmic_flops, start_event, end_event, shape tag, algorithmic_bytes). None = no instrumentation (the default).
 CONV_TRACE = None
+
+
+def check_f16_range(device):
+    """f16x3 mode: raise if a convolution since the last check staged an activation beyond the fp16 range (|x| > 65504): its result
+    is not fp32-grade (fp16 overflow). Call at a point where the stream is already drained (one 4-byte D2H)."""
+    device = torch.device(device)
+    for key, t in _F16_STATUS.items():
+        if key[0] == device.type and (device.index is None or key[1] == device.index):
+            if int(t.item()) != 0:
+                t.zero_()
+                raise hip.VpsHipError('f16x3: an activation exceeded the fp16 range (|x| > 65504) in a convolution of this frame; the '
+                                      'fp16 split is not fp32-grade there. Run this checkpoint with VPS_PREC=bf16x6 (or f32).')
 
 
 class FMap:
@@ -165,7 +194,7 @@ class PackedConv:
         packed = torch.zeros(self.nclass, self.cout_pad, self.kpad)
         for c, b in enumerate(blocks):
             packed[c, :O, :K] = b
-        self._set_weights(packed, device)
+        wscale = self._set_weights(packed, device)
         # epilogue: y = acc*scale + shift
         scale = torch.ones(O)
         shift = torch.zeros(O) if bias is None else bias.detach().float().cpu().clone()
@@ -178,6 +207,10 @@ class PackedConv:
             self.has_scale = True
         else:
             self.has_scale = False
+        if wscale is not None:
+            # f16x3: the weights were pre-scaled per output channel by a power of two; undone exactly here
+            scale = scale * wscale[:O].cpu()
+            self.has_scale = True
         self.scale = scale.to(device) if self.has_scale else None
         self.shift = shift.to(device) if (bias is not None or bn is not None) else None
 
@@ -194,15 +227,30 @@ class PackedConv:
         return wp.view(O, ntap, nch, 32).permute(0, 2, 1, 3).reshape(O, nch * ntap * 32)
 
     def _set_weights(self, packed, device):
-        """packed fp32 [nclass][cout_pad][kpad] (host or device) -> the operand format of the selected arithmetic"""
+        """packed fp32 [nclass][cout_pad][kpad] (host or device) -> the operand format of the selected arithmetic.
+        Returns None, or (f16x3) the per-output-channel factor [cout_pad] the epilogue scale has to be multiplied with."""
         if self.prec == hip.PREC_F32:
             self.w, self.w_split = packed.to(device), None
-            return
+            return None
         planes, r = [], packed.to(device)
-        for _ in range(self.prec):                      # term p = bf16 RNE of the residual after p terms
-            h = r.to(torch.bfloat16)
-            planes.append(h)
-            r = r - h.float()
+        wscale = None
+        if self.prec == hip.PREC_F16X3:
+            # per output channel: w' = w * 2^s with max|w'| in [2^11, 2^12) (exact), planes g0 = fp16(w'), g1 = fp16(w' - g0),
+            # g2 = 2^-11 * g0 (exact): see VPS_PREC_F16X3 in include/vps_hip.h
+            amax = r.abs().amax(dim=(0, 2))                                   # [cout_pad]
+            e = torch.frexp(amax)[1] - 1                                      # floor(log2(amax)) for amax > 0
+            sh = torch.where(amax > 0, 11 - e, torch.zeros_like(e)).clamp(-60, 60)
+            r = torch.ldexp(r, sh.view(1, -1, 1).expand_as(r))
+            wscale = torch.ldexp(torch.ones_like(amax), -sh)
+            g0 = r.to(torch.float16)
+            g1 = (r - g0.float()).to(torch.float16)
+            g2 = torch.ldexp(g0.float(), torch.full_like(sh, -11).view(1, -1, 1).expand_as(r)).to(torch.float16)
+            planes = [g0, g1, g2]
+        else:
+            for _ in range(_PLANES[self.prec]):         # term p = bf16 RNE of the residual after p terms
+                h = r.to(torch.bfloat16)
+                planes.append(h)
+                r = r - h.float()
         ws = torch.stack(planes, 0)                     # [planes][class][cout_pad][kpad]
         if not self.deform:
             # MFMA-fragment order for the direct-to-register weight path (conv_mfma_bf16d_kernel):
@@ -210,6 +258,7 @@ class PackedConv:
             P, C, O, K = ws.shape
             ws = ws.view(P, C, O // 32, 32, K // 16, 2, 8).permute(0, 1, 2, 4, 5, 3, 6)
         self.w, self.w_split = None, ws.contiguous()
+        return wscale
 
     @classmethod
     def from_matrix(cls, mat, prec=None):
@@ -229,8 +278,10 @@ class PackedConv:
         w = torch.zeros(1, self.cout_pad, D, dtype=torch.float32, device=mat.device)
         w[0, :M] = mat
         self.prec = DEFAULT_PREC if prec is None else prec
-        self._set_weights(w, mat.device)
+        wscale = self._set_weights(w, mat.device)
         self.scale, self.shift, self.has_scale = None, None, False
+        if wscale is not None:
+            self.scale, self.has_scale = wscale[:M].contiguous(), True
         return self
 
     def out_hw(self, H, W):
@@ -286,6 +337,8 @@ class PackedConv:
             assert offset is not None and offset.coff == 0 and offset.C >= 2 * self.KH * self.KW
             d.offset = offset.t.data_ptr(); d.off_ld = offset.ld
         d.tile_n = self.tile_n
+        if self.prec == hip.PREC_F16X3:
+            d.status = f16_status(x.t.device).data_ptr()
         # split-K for launches that cannot fill 256 CUs
         M = x.N * d.Qh * d.Qw
         tiles = ((M + 127) // 128) * (self.cout_pad // self.tile_n) * d.nclass
@@ -337,7 +390,7 @@ class PackedConv:
     def bytes(self, x_N, x_H, x_W, has_res=False):
         """algorithmic HBM bytes of one call: every input / weight / residual element read once, every output written once."""
         Ho, Wo = self.out_hw(x_H, x_W)
-        wbytes = self.nclass * self.cout * self.KH * self.KW * self.cin * (4 if self.prec == hip.PREC_F32 else 2 * self.prec)
+        wbytes = self.nclass * self.cout * self.KH * self.KW * self.cin * (4 if self.prec == hip.PREC_F32 else 2 * _PLANES[self.prec])
         return 4.0 * x_N * (x_H * x_W * self.cin + Ho * Wo * self.cout * (2 if has_res else 1)) + wbytes
 
     def flops(self, x_N, x_H, x_W):
