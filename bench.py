@@ -163,6 +163,7 @@ def main():
     ap.add_argument('--variant', default='fusetrack', choices=['fusetrack', 'fuse', 'track'],
                     help='detector (SURVEY 8(f) row 4): the headline metric is fusetrack; the variants are single-GPU only')
     ap.add_argument('--conv-table', default=None, help='write the per-layer-shape conv timing table of one frame here')
+    ap.add_argument('--no-prefetch', action='store_true', help='do not enqueue the next frame behind the current one (A/B of the clip pipelining)')
     ap.add_argument('--single-stream', action='store_true', help='run every frame on one stream (for kernel traces whose durations add up)')
     args = ap.parse_args()
 
@@ -211,10 +212,10 @@ def main():
         return model(return_loss=False, rescale=True, img=[img], img_meta=[[synth.img_meta(Hh, Ww, 10000 * vid + t + 1)]], ref_img=[ref])
 
     use_runner = args.variant == 'fusetrack'
-    runner = ClipShardRunner(DetectorBackend(model, Hh, Ww), rank, world, dist, dev) if use_runner else None
+    runner = ClipShardRunner(DetectorBackend(model, Hh, Ww, prefetch=not args.no_prefetch), rank, world, dist, dev) if use_runner else None
 
     def reset():
-        model._cache = None; model._handoff = None
+        model._cache = None; model._handoff = None; model._pf = None
         model.reset_tracker()
 
     # ---- warm-up: W frames per rank through the same pipeline (also sets up the RCCL p2p communicators) -------------------------
@@ -344,6 +345,8 @@ def main():
                        'detections_per_frame': round(ndet / max(total_frames, 1), 1),
                        'parallelism': ('clip-shard x%d (contiguous shards of %d frames), 1 p2p feature hand-off per shard boundary, tracker replay '
                                        'on rank 0 + result gather inside the timed region' % (world, args.steps)) if use_runner else 'single GPU',
+                       'pipelining': 'two HIP streams per frame; the next frame of the clip (FlowNet2 + ResNet/FPN, image-only stages) is enqueued behind '
+                                     'the current frame\'s semantic head' if (use_runner and not args.no_prefetch and not args.single_stream) else 'two HIP streams per frame' if not args.single_stream else 'one stream',
                        'timed_region': 'inputs resident in HBM; excludes the H2D of the two 25 MB frames and the D2H of the two uint8 maps that '
                                        'tools/test_vpq.py:46-56 pays (~0.4 ms per frame over PCIe 5 x16 when not overlapped)'},
             'roofline': roof, 'stage_ms': stages,

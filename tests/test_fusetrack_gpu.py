@@ -206,11 +206,18 @@ def test_clip_shard_backend_and_handoff_feature(setup):
         out = m(return_loss=False, rescale=True, img=[fr[t].to(dev)], img_meta=[[synth.img_meta(H, W, 10000 + t + 1)]],
                 ref_img=[fr[t - 1 if t else 0].to(dev)])
         seq.append({k: v.cpu().numpy().copy() for k, v in out[2].items()})
-    m._cache = None; m.reset_tracker()
-    outs = ClipShardRunner(DetectorBackend(m, H, W), 0, 1, None, dev).run(lambda t: fr[t].to(dev), n)
-    for t in range(n):
-        assert np.array_equal(np.asarray(outs[t]['panoptic_det_obj_ids']), seq[t]['panoptic_det_obj_ids'])
-        assert np.array_equal(outs[t]['panoptic_outputs'].cpu().numpy(), seq[t]['panoptic_outputs'])
+    frd = [f.to(dev) for f in fr]            # the runner's frames must be stable objects: the cross-frame prefetch matches by identity
+    for prefetch in (True, False):
+        m._cache = None; m._pf = None; m.reset_tracker()
+        outs = ClipShardRunner(DetectorBackend(m, H, W, prefetch=prefetch), 0, 1, None, dev).run(lambda t: frd[t], n)
+        for t in range(n):
+            # the pipelined schedule (next frame's FlowNet2 / ResNet / FPN enqueued behind this frame's semantic head) is bitwise
+            # the sequential one
+            assert np.array_equal(np.asarray(outs[t]['panoptic_det_obj_ids']), seq[t]['panoptic_det_obj_ids']), (prefetch, t)
+            assert np.array_equal(outs[t]['panoptic_outputs'].cpu().numpy(), seq[t]['panoptic_outputs']), (prefetch, t)
+            assert np.array_equal(outs[t]['fcn_outputs'].cpu().numpy(), seq[t]['fcn_outputs']), (prefetch, t)
+            assert np.array_equal(outs[t]['panoptic_cls_prob'].cpu().numpy(), seq[t]['panoptic_cls_prob']), (prefetch, t)
+        assert (m._pf is None)
     # (b)
     m._cache = None; m.reset_tracker()
     m(return_loss=False, rescale=True, img=[fr[0].to(dev)], img_meta=[[synth.img_meta(H, W, 10001)]], ref_img=[fr[0].to(dev)])

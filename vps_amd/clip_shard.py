@@ -19,6 +19,8 @@ new design for BASELINE config 4:
     process(img, ref_img, ref_feature, iid, is_first) -> dict record (no ids yet)
     assign(record, is_first) -> np.ndarray ids     sequential tracker step (stateful)
     finalize(record, ids) -> dict                  per-frame outputs with 'panoptic_det_obj_ids'
+A backend with `supports_prefetch` also takes `next_img=` in process(): the next frame of the shard, whose image-only stages
+(FlowNet2, ResNet/FPN) it may enqueue behind the current frame's (vps_amd.detector: `prefetch`).
 """
 import numpy as np
 import torch
@@ -76,7 +78,12 @@ class ClipShardRunner:
                     rq.wait()
                 reqs = []
                 ref_feature = recv_buf
-            rec = be.process(img, ref_img, ref_feature, video_id * 10000 + t + 1, is_first)
+            if getattr(be, 'supports_prefetch', False):
+                # the next frame of this shard is known: its image-only stages are enqueued behind this frame's (detector.simple_test)
+                rec = be.process(img, ref_img, ref_feature, video_id * 10000 + t + 1, is_first,
+                                 next_img=load_frame(t + 1) if t + 1 < e else None)
+            else:
+                rec = be.process(img, ref_img, ref_feature, video_id * 10000 + t + 1, is_first)
             rec['t'] = t
             records.append(rec)
             prev = img
@@ -85,34 +92,98 @@ class ClipShardRunner:
         # 3) sequential tracker replay on rank 0
         if world == 1:
             return [be.finalize(r, be.assign(r, r['t'] == 0)) for r in records]
-        slim = [{k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in r.items() if k in self.track_keys or k == 't'}
-                for r in records]
+        # detection records -> rank 0: the per-detection tensors of a rank (boxes, labels, scores, 1024-d embeddings: <0.5 MB per
+        # frame) are packed into ONE fp32 matrix [sum K, D] and sent point-to-point; only the layout (a few ints) goes as an object
+        def pack(recs):
+            meta, rows = [], []
+            for r in recs:
+                K = int(r[self.track_keys[0]].shape[0])
+                cols, lay = [], []
+                for k in self.track_keys:
+                    v = r[k]
+                    lay.append((k, tuple(v.shape[1:]), str(v.dtype).replace('torch.', '')))
+                    cols.append(v.reshape(K, -1).to(torch.float32))
+                meta.append((r['t'], K, lay))
+                rows.append(torch.cat(cols, 1))
+            return meta, (torch.cat(rows, 0).contiguous() if rows else None)
+
+        def unpack(meta, mat):
+            out, row = [], 0
+            for t, K, lay in meta:
+                r, col = {'t': t}, 0
+                for k, shp, dt in lay:
+                    w = 1
+                    for d_ in shp:
+                        w *= d_
+                    r[k] = mat[row:row + K, col:col + w].reshape((K,) + tuple(shp)).to(getattr(torch, dt))
+                    col += w
+                row += K
+                out.append(r)
+            return out
+
+        meta, mat = pack(records)
         gathered = [None] * world if rank == 0 else None
-        dist.gather_object(slim, gathered, dst=0)
+        dist.gather_object((meta, None if mat is None else tuple(mat.shape)), gathered, dst=0)
         ids_per_rank = None
         if rank == 0:
-            allrec = sorted([r for chunk in gathered for r in chunk], key=lambda r: r['t'])
+            mats, ops = {0: mat}, []
+            for r in range(1, world):
+                if gathered[r][1] is not None:
+                    mats[r] = torch.empty(gathered[r][1], dtype=torch.float32, device=mat.device)
+                    ops.append(dist.P2POp(dist.irecv, mats[r], r))
+            for rq in (dist.batch_isend_irecv(ops) if ops else []):
+                rq.wait()
+            allrec = sorted([rec for r in range(world) if r in mats for rec in unpack(gathered[r][0], mats[r])], key=lambda r: r['t'])
             ids = {}
             for r in allrec:
-                r = {k: (v.to(self.device) if torch.is_tensor(v) and self.device is not None else v) for k, v in r.items()}
                 ids[r['t']] = np.asarray(be.assign(r, r['t'] == 0))
             ids_per_rank = [{t: ids[t] for t in range(a, b)} for a, b in parts]
+        elif mat is not None:
+            for rq in dist.batch_isend_irecv([dist.P2POp(dist.isend, mat, 0)]):
+                rq.wait()
         mine = [None]
         dist.scatter_object_list(mine, ids_per_rank, src=0)
         outs = [be.finalize(r, mine[0][r['t']]) for r in records]
-        # collect the finished per-frame outputs on rank 0 (small: uint8 maps + ids)
-        res = [None] * world if rank == 0 else None
-        dist.gather_object([{k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in o.items()} for o in outs], res, dst=0)
+        # collect the finished per-frame outputs on rank 0: the two maps of every frame (2 x 2 MB at 1024x2048) travel as ONE
+        # tensor per rank, point-to-point like the feature hand-off (RCCL over the direct xGMI link; no pickling of image-sized
+        # data), the per-instance vectors (a few hundred bytes per frame) as objects
+        map_keys = ('panoptic_outputs', 'fcn_outputs')
+        mine_maps = torch.stack([torch.stack([o[k][0] for k in map_keys]) for o in outs]) if outs else None      # [nf, 2, H, W]
+        bufs, ops = {}, []
         if rank == 0:
-            return [o for chunk in res for o in chunk]
+            for r in range(1, world):
+                nf = parts[r][1] - parts[r][0]
+                if nf > 0:
+                    bufs[r] = torch.empty((nf,) + tuple(mine_maps.shape[1:]), dtype=mine_maps.dtype, device=mine_maps.device)
+                    ops.append(dist.P2POp(dist.irecv, bufs[r], r))
+        elif mine_maps is not None:
+            ops.append(dist.P2POp(dist.isend, mine_maps.contiguous(), 0))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        small = [{k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in o.items() if k not in map_keys} for o in outs]
+        res = [None] * world if rank == 0 else None
+        dist.gather_object(small, res, dst=0)
+        for rq in reqs:
+            rq.wait()
+        if rank == 0:
+            full = list(outs)
+            for r in range(1, world):
+                for i, o in enumerate(res[r]):
+                    o = dict(o)
+                    for j, k in enumerate(map_keys):
+                        o[k] = bufs[r][i, j][None]
+                    full.append(o)
+            return full
         return outs
 
 
 class DetectorBackend:
     """adapts vps_amd.detector.PanopticFuseTrack to the ClipShardRunner protocol"""
 
-    def __init__(self, detector, H, W):
+    supports_prefetch = True
+
+    def __init__(self, detector, H, W, prefetch=True):
         self.det, self.H, self.W = detector, H, W
+        self.prefetch = prefetch
 
     def ref_feature(self, img):
         return self.det.gathered_feature(img)
@@ -121,10 +192,11 @@ class DetectorBackend:
         C = self.det.extra_neck.in_channels
         return torch.empty(1, self.H // 4, self.W // 4, C, dtype=torch.float32, device=img.device)
 
-    def process(self, img, ref_img, ref_feature, iid, is_first):
+    def process(self, img, ref_img, ref_feature, iid, is_first, next_img=None):
         from . import synth
         meta = synth.img_meta(self.H, self.W, iid)
-        out = self.det.simple_test(img, [meta], ref_img=[ref_img], ref_feature=ref_feature, defer_tracking=True)
+        pf = (next_img, img) if (self.prefetch and next_img is not None) else None      # the next frame's reference is this frame
+        out = self.det.simple_test(img, [meta], ref_img=[ref_img], ref_feature=ref_feature, defer_tracking=True, prefetch=pf)
         rec = dict(out[2])
         rec.update(self.det._track_record)
         return rec

@@ -1513,9 +1513,20 @@ extern "C" int vps_conv2d(const vps_conv_desc* dp, void* stream) {
         else hipLaunchKernelGGL((conv_small_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, s, d, M, G, logG);
         return vps_launch_status();
     }
+    // wave arrangement <TM, TN, WAVES_M, WAVES_N> of the 4 waves of a block. Weight fragments come from global memory (one 1 KB
+    // load per fragment = 64 cycles of the CU's vector-memory pipe, tools/gapbench.hip) while activation fragments come from LDS
+    // (two 1 KB reads per 32 cycles are free): tall wave tiles (all 128 rows x 32 columns per wave) minimise the former.
+#ifdef VPS_WAVES_2X2
     switch (d.tile_n) {
         case 128: return launch_conv<2, 2, 2, 2>(d, M, s);
         case 64: return launch_conv<1, 2, 4, 1>(d, M, s);
         default: return launch_conv<1, 1, 4, 1>(d, M, s);
     }
+#else
+    switch (d.tile_n) {
+        case 128: return launch_conv<4, 1, 1, 4>(d, M, s);
+        case 64: return launch_conv<2, 1, 2, 2>(d, M, s);
+        default: return launch_conv<1, 1, 4, 1>(d, M, s);
+    }
+#endif
 }

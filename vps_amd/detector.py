@@ -110,6 +110,7 @@ class PanopticFuseTrack(HipModule):
         self._flip = 0
         self._cache = None
         self._handoff = None
+        self._pf = None
         self.reset_tracker()
 
     # ------------------------------------------------------------------------------------------------------
@@ -172,11 +173,16 @@ class PanopticFuseTrack(HipModule):
 
     @torch.no_grad()
     def simple_test(self, img, img_meta, proposals=None, rescale=False, ref_img=None, inject=None, ref_feature=None,
-                    defer_tracking=False):
+                    defer_tracking=False, prefetch=None):
         """panoptic_fusetrack.py:502-606. `inject` (tests/bench only): dict overriding head inputs at the operator
         boundaries of SURVEY §8d config 2 (fcn_score, proposals, cls_score, bbox_pred, mask_score).
         ref_feature / defer_tracking (clip_shard.py): gathered pre-neck feature of the previous frame received from the
-        neighbouring GPU, and postponing the sequential id assignment to the clip-level replay."""
+        neighbouring GPU, and postponing the sequential id assignment to the clip-level replay.
+        prefetch (clip pipelines): (next_img, next_ref_img), the device tensors the NEXT call will be made with. Their
+        FlowNet2 + ResNet/FPN/gather — which depend on the images alone — are enqueued on the side stream behind this frame's
+        semantic head, so the GPU has ~20 ms of independent work while the host walks through this frame's detection branch
+        (MaskROI / tracker / MaskRemoval round trips). The next call picks the results up (matched by tensor identity);
+        outputs are bitwise those of the unpipelined schedule."""
         assert proposals is None
         if not img.is_cuda:
             raise hip.VpsHipError('PanopticFuseTrack runs on the device only (no CPU path)')
@@ -216,28 +222,28 @@ class PanopticFuseTrack(HipModule):
             x = levels
             self._mark('backbone_fpn')
         else:
-            # (1) flow ---------------------------------------------------------------------------------------------
-            if side is not None:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
+            pf, self._pf = self._pf, None
+            if pf is not None and side is not None and pf['img'] is img and pf['ref'] is ref_img and pf['version'] == (img._version, ref_img._version):
+                # (1)+(2) were enqueued on the side stream during the previous call (prefetch)
+                main.wait_event(pf['event'])
+                flow, levels, cat = pf['flow'], pf['levels'], pf['cat']
+                self._mark('flownet2')
+            else:
+                if pf is not None:
+                    self._flip ^= 1           # an unused prefetch: its 'neck.cat' buffer is the one to overwrite, not the previous frame's
+                # (1) flow ---------------------------------------------------------------------------------------------
+                if side is not None:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        flow = self.flownet2.run(img, ref_img, self._mean_t, self._std_t, ws)
+                else:
                     flow = self.flownet2.run(img, ref_img, self._mean_t, self._std_t, ws)
-            else:
-                flow = self.flownet2.run(img, ref_img, self._mean_t, self._std_t, ws)
-            self._mark('flownet2')
-            # (2) backbone + FPN of the target frame -----------------------------------------------------------------
-            self._flip ^= 1
-            tag = 'AB'[self._flip]
-            pre = self._handoff
-            if pre is not None and pre['img'] is img and pre['version'] == img._version:
-                # clip sharding: this frame's ResNet+FPN+gather already ran for the hand-off to the next GPU (gathered_feature)
-                levels, cat = pre['levels'], pre['cat']
-                self._handoff = None
-            else:
-                levels = self.neck.run(self.backbone.run(nhwc.from_nchw(img, ws, 'img_nhwc'), ws, 'bb.'), ws, 'fpn.')
-                cat = self.extra_neck.gather(levels, ws, 'neck.cat' + tag)
+                self._mark('flownet2')
+                # (2) backbone + FPN of the target frame -----------------------------------------------------------------
+                levels, cat = self._backbone_fpn_gather(img, ws)
+                if side is not None:
+                    main.wait_stream(side)
             C = self.extra_neck.in_channels
-            if side is not None:
-                main.wait_stream(side)
             # flowR2T = F.interpolate(flow, 0.25, bilinear) * 0.25 written straight into the LiteFlowNet input buffer
             nhwc.resize(flow, cat.window(C + 81, 2), 'bilinear', 0.25)
             self._mark('backbone_fpn')
@@ -258,10 +264,23 @@ class PanopticFuseTrack(HipModule):
             x, aux = self.extra_neck.run(levels, cat, ref_bsf, ws, 'neck.')
             self._mark('extra_neck')
         # (4) semantic head --------------------------------------------------------------------------------------
+        sem_done = None
         if side is not None:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 fcn_score = self.panopticFPN.run(x[0:self.panopticFPN.num_levels], ws)
+                sem_done = torch.cuda.Event()
+                sem_done.record(side)
+                if prefetch is not None and self.with_fusion:
+                    # the next frame's image-only stages, behind the semantic head on the side stream. Their buffers ('fn2.*',
+                    # 'img_nhwc', 'bb.*', 'fpn.*', the OTHER 'neck.cat' buffer) were last read by this frame's flow resize /
+                    # neck, which the main stream enqueued before the side stream's wait above; nothing after the neck reads them.
+                    nimg, nref = prefetch
+                    nflow = self.flownet2.run(nimg, nref, self._mean_t, self._std_t, ws)
+                    nlevels, ncat = self._backbone_fpn_gather(nimg, ws)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    self._pf = dict(img=nimg, ref=nref, version=(nimg._version, nref._version), event=ev, flow=nflow, levels=nlevels, cat=ncat)
         else:
             fcn_score = self.panopticFPN.run(x[0:self.panopticFPN.num_levels], ws)
         if inject is not None and 'fcn_score' in inject:
@@ -298,7 +317,7 @@ class PanopticFuseTrack(HipModule):
         mask_score = all_scores.gather(3, cls_idx.view(-1, 1, 1, 1).expand(-1, S, S, 1)).squeeze(3).contiguous()
         self._mark('mask_head')
         if side is not None:
-            main.wait_stream(side)         # the combine kernel reads fcn_score
+            main.wait_event(sem_done)      # the combine kernel reads fcn_score (prefetched work behind it is not waited for)
         # (9)-(11) MaskRemoval + SegTerm + combine ---------------------------------------------------------------
         keep_inds, ref_boxes, masks_valid = self.mask_removal(mask_rois[:, 1:], cls_prob, mask_score, cls_idx, (H, W), ws)
         nhwc.check_f16_range(dev)          # f16x3 only (no-op otherwise): every convolution of the frame has run by now
@@ -328,6 +347,18 @@ class PanopticFuseTrack(HipModule):
         return bbox_results, mask_results, pano_results
 
     # ------------------------------------------------------------------------------------------------------
+    def _backbone_fpn_gather(self, img, ws):
+        """ResNet + FPN + gather of one frame into the frame-alternating 'neck.cat' buffer -> (levels, cat)"""
+        self._flip ^= 1
+        tag = 'AB'[self._flip]
+        pre = self._handoff
+        if pre is not None and pre['img'] is img and pre['version'] == img._version:
+            # clip sharding: this frame's ResNet+FPN+gather already ran for the hand-off to the next GPU (gathered_feature)
+            self._handoff = None
+            return pre['levels'], pre['cat']
+        levels = self.neck.run(self.backbone.run(nhwc.from_nchw(img, ws, 'img_nhwc'), ws, 'bb.'), ws, 'fpn.')
+        return levels, self.extra_neck.gather(levels, ws, 'neck.cat' + tag)
+
     def gathered_feature(self, img):
         """gather(FPN(ResNet(img))) (bfp_tcea.py:96-109,117): the tensor the NEXT frame needs as ref_bsf; [1,H/4,W/4,C]"""
         dev = img.device
