@@ -34,6 +34,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA dense peak (not the 2:1-sparse headline)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured with a float4 copy)
 H, W = 1024, 2048
+DEFAULT_PREC = 'f16x3'
 WORKLOADS = {
     'fusetrack': 'FlowNet2 + ResNet50-FPN + BFP-TCEA + UPSNet panoptic head + RPN / bbox / track / mask heads',
     'fuse': 'PanopticFuse: FlowNet2 + ResNet50-FPN (both frames) + BFP-TCEA + UPSNet panoptic head + RPN / bbox / mask heads, no track head',
@@ -159,9 +160,11 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='skip the untimed extras (hbm kernel table, 30-frame clip)')
     ap.add_argument('--height', type=int, default=H)
     ap.add_argument('--width', type=int, default=W)
-    ap.add_argument('--prec', default='bf16x6', choices=['f32', 'bf16x3', 'bf16x6', 'f16x3'], help='arithmetic of the dense contractions')
+    ap.add_argument('--prec', default=DEFAULT_PREC, choices=['f32', 'bf16', 'bf16x3', 'bf16x6', 'f16x3'], help='arithmetic of the dense contractions')
     ap.add_argument('--variant', default='fusetrack', choices=['fusetrack', 'fuse', 'track'],
                     help='detector (SURVEY 8(f) row 4): the headline metric is fusetrack; the variants are single-GPU only')
+    ap.add_argument('--model-config', default=None, help='model config file (default configs/cityscapes/<variant>.py); BASELINE config 5: '
+                    'configs/viper/fusetrack_r101.py --height 1088 --width 1920 --prec bf16')
     ap.add_argument('--conv-table', default=None, help='write the per-layer-shape conv timing table of one frame here')
     ap.add_argument('--no-prefetch', action='store_true', help='do not enqueue the next frame behind the current one (A/B of the clip pipelining)')
     ap.add_argument('--single-stream', action='store_true', help='run every frame on one stream (for kernel traces whose durations add up)')
@@ -194,9 +197,10 @@ def main():
     nhwc.DEFAULT_PREC = nhwc.PREC_NAMES[args.prec]
     Hh, Ww = args.height, args.width
     assert args.variant == 'fusetrack' or world == 1
-    cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', args.variant + '.py'))
+    cfg = vps_amd.Config.fromfile(args.model_config or os.path.join(ROOT, 'configs', 'cityscapes', args.variant + '.py'))
     model = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
     synth.load_synth(model, args.seed)
+    depth = getattr(model.backbone, 'depth', 50)
     if args.single_stream:
         model.overlap_streams = False
 
@@ -277,6 +281,30 @@ def main():
                           note='one 30-frame synthetic clip over %d GPU(s): %d feature hand-off(s), tracker replay on rank 0 and result gather inside' % (world, world - 1),
                           id_checksum=int(sum(sig)))
 
+    # ---- untimed: the same pipeline in the other fp32-grade arithmetic (bf16x6: 6 bf16 MFMAs per product), for comparison ----------
+    other = None
+    if use_runner and not args.no_extras and world == 1 and args.prec == 'f16x3' and (Hh, Ww) == (H, W):
+        old = nhwc.DEFAULT_PREC
+        nhwc.DEFAULT_PREC = hip.PREC_BF16X6
+        try:
+            m2 = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+            synth.load_synth(m2, args.seed)
+            m2.ensure_packed(dev)
+        finally:
+            nhwc.DEFAULT_PREC = old
+        r2 = ClipShardRunner(DetectorBackend(m2, Hh, Ww, prefetch=not args.no_prefetch), 0, 1, None, dev)
+        r2.run(load_frame, 3, video_id=5)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        r2.run(load_frame, 10, video_id=6)
+        torch.cuda.synchronize()
+        c1 = time.perf_counter() - c0
+        other = dict(prec='bf16x6', frames=10, frames_per_s=round(10 / c1, 3), ms_per_frame=round(100 * c1, 3),
+                     note='same clip pipeline with 3 bf16 planes per operand and 6 MFMAs per fp32 product (error ~2^-23); f16x3: 2+3 fp16 planes, '
+                          '3 MFMAs (error <= 3*2^-22, operands within the fp16 range)')
+        del m2, r2
+        torch.cuda.empty_cache()
+
     # ---- instrumented extra frame (outside the timed region): per-stage and per-conv-launch HIP events, ONE stream ---------------
     roof, stages, hbm = None, None, None
     if rank == 0:
@@ -331,15 +359,16 @@ def main():
     if rank == 0:
         fps = total_frames / dt
         line = {
-            'metric': 'frames/sec %s 1024x2048' % {'fusetrack': 'FuseTrack', 'fuse': 'PanopticFuse', 'track': 'PanopticTrack'}[args.variant],
+            'metric': 'frames/sec %s%s %dx%d' % ({'fusetrack': 'FuseTrack', 'fuse': 'PanopticFuse', 'track': 'PanopticTrack'}[args.variant],
+                                                 '' if depth == 50 else ' ResNet-%d' % depth, Hh, Ww),
             'value': round(fps, 3), 'unit': 'frames/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'f32': 'f32', 'bf16x6': 'f32-grade: bf16x6 split operands on MFMA, f32 accumulate',
+            'dtype': {'f32': 'f32', 'bf16': 'bf16 operands (rounded at staging) on MFMA, f32 accumulate, f32 activations in HBM', 'bf16x6': 'f32-grade: bf16x6 split operands on MFMA, f32 accumulate',
                       'f16x3': 'f32-grade: f16x3 split operands (fp16 pair with scaled residual, 22 significand bits) on MFMA, f32 accumulate',
                       'bf16x3': 'bf16x3 split operands on MFMA, f32 accumulate'}[args.prec], 'data': 'synthetic',
             'config': {'workload': '2-frame pair %s (%s), synthetic %dx%d clip of %d frames, batch 1' % (
-                           {'fusetrack': 'FuseTrack', 'fuse': 'PanopticFuse', 'track': 'PanopticTrack'}[args.variant], WORKLOADS[args.variant],
+                           {'fusetrack': 'FuseTrack', 'fuse': 'PanopticFuse', 'track': 'PanopticTrack'}[args.variant], WORKLOADS[args.variant].replace('ResNet50', 'ResNet%d' % depth),
                            Hh, Ww, total_frames),
                        'weights': 'synthetic (vps_amd.synth seed %d)' % args.seed,
                        'detections_per_frame': round(ndet / max(total_frames, 1), 1),
@@ -354,6 +383,8 @@ def main():
         }
         if clip30 is not None:
             line['clip30'] = clip30
+        if other is not None:
+            line['other_arithmetic'] = other
         if not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.seed)
         print(json.dumps(line))

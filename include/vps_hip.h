@@ -45,6 +45,8 @@ const char* vps_build_info(void);
 enum { VPS_ACT_NONE = 0, VPS_ACT_RELU = 1, VPS_ACT_LEAKY = 2 };
 /* arithmetic of the contraction (accumulation is always fp32):
  *   VPS_PREC_F32    exact fp32 MFMA (v_mfma_f32_32x32x2_f32), needs `w`
+ *   VPS_PREC_BF16   operands rounded to bf16 (RNE) when staged, 1 bf16 MFMA per product (~2^-8 relative): the plain
+ *                   "bf16 in, fp32 accumulate" arithmetic of BASELINE config 5; activations stay fp32 in HBM; needs `w_split`
  *   VPS_PREC_BF16X3 fp32 operands split into 2 bf16 terms, 3 bf16 MFMAs per product (~2^-16 relative), needs `w_split`
  *   VPS_PREC_BF16X6 3 bf16 terms, 6 bf16 MFMAs per product (~2^-23 relative, fp32-grade), needs `w_split`
  *   VPS_PREC_F16X3  fp32 operands split into 2 fp16 terms with a scaled residual, 3 fp16 MFMAs per product, needs `w_split`:
@@ -53,7 +55,7 @@ enum { VPS_ACT_NONE = 0, VPS_ACT_RELU = 1, VPS_ACT_LEAKY = 2 };
  *                     x*w ~ h0*g0 + h0*g1 + h1*g2   (dropped: 2^-11*h1*g1 and the two residual roundings, <= 3*2^-22 relative)
  *                   full precision for 2^-14 <= |x| <= 65504 (below: absolute error <= 2^-36; above: fp16 overflow, reported
  *                   through `status`); weights within 2^-15 of their channel's largest keep 22 bits. */
-enum { VPS_PREC_F32 = 0, VPS_PREC_BF16X3 = 2, VPS_PREC_BF16X6 = 3, VPS_PREC_F16X3 = 4 };
+enum { VPS_PREC_F32 = 0, VPS_PREC_BF16 = 1, VPS_PREC_BF16X3 = 2, VPS_PREC_BF16X6 = 3, VPS_PREC_F16X3 = 4 };
 
 typedef struct vps_conv_desc {
     /* input activation, NHWC */
@@ -88,7 +90,7 @@ typedef struct vps_conv_desc {
     int32_t tile_n;     /* 32, 64 or 128 */
     int32_t ksplit;     /* >=1; >1 needs ws of ksplit*M*cout_pad floats (M = nclass*N*Qh*Qw) */
     float* ws;
-    /* split modes: 16-bit weight planes, no `w`. P planes: bf16x3 2, bf16x6 3 (plane p = bf16 RNE of the residual after p
+    /* split modes: 16-bit weight planes, no `w`. P planes: bf16 1, bf16x3 2, bf16x6 3 (plane p = bf16 RNE of the residual after p
      * terms), f16x3 3 (g0, g1, 2^-11*g0 of the per-channel pre-scaled weight; the scale's inverse is folded into `scale`).
      *   with `offset` (deformable):  [P][nclass][cout_pad][kpad]
      *   otherwise, MFMA-fragment order (weights go straight to registers, one coalesced 1 KB load per fragment):

@@ -4,6 +4,7 @@ container, with the import shims of ref_shims.py (third-party stubs + oracle-bac
 
     python tests/golden/make_golden.py [fusetrack|fuse|track]   # needs /root/reference; writes tests/golden/<variant>_clip.npz
     python tests/golden/make_golden.py fullsize                  # 2 frames at 1024x2048 -> tests/golden/fusetrack_fullsize.npz
+    python tests/golden/make_golden.py r101                      # ResNet-101 variant (BASELINE config 5), 2 frames at 128x256
 
 The reference cannot travel to the GPU box; the vectors do. tests/test_oracle_golden.py checks the oracle against them
 (CPU), tests/test_fusetrack_gpu.py checks the HIP path against the oracle and against these vectors (GPU).
@@ -27,7 +28,7 @@ H, W, NFRAMES, SEED = 128, 256, 3, 0
 FULL_H, FULL_W, FULL_NFRAMES = 1024, 2048, 2          # `fullsize`: the BASELINE frame size (configs[1]), FuseTrack only
 
 
-def main(variant='fusetrack', H=H, W=W, NFRAMES=NFRAMES, out_name=None, full=False):
+def main(variant='fusetrack', H=H, W=W, NFRAMES=NFRAMES, out_name=None, full=False, depth=None):
     """full=True: the 1024x2048 golden — same quantities, the dense stage tensors strided so the file stays a few MB"""
     import ref_shims
     mods = ref_shims.install()
@@ -36,6 +37,8 @@ def main(variant='fusetrack', H=H, W=W, NFRAMES=NFRAMES, out_name=None, full=Fal
     import vps_amd
 
     cfg = Config.fromfile('/root/reference/configs/cityscapes/%s.py' % variant)
+    if depth is not None:
+        cfg.model['backbone']['depth'] = depth          # BASELINE config 5: the ResNet-101 variant (resnet.py:361)
     has_flow, has_track = variant != 'track', variant != 'fuse'
     # --- shapes of every parameter, from OUR containers; the reference model must expose exactly the same keys ---
     ours = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
@@ -141,5 +144,7 @@ if __name__ == '__main__':
     v = sys.argv[1] if len(sys.argv) > 1 else 'fusetrack'
     if v == 'fullsize':
         main('fusetrack', FULL_H, FULL_W, FULL_NFRAMES, 'fusetrack_fullsize.npz', full=True)
+    elif v == 'r101':
+        main('fusetrack', H, W, 2, 'fusetrack_r101_clip.npz', depth=101)
     else:
         main(v)

@@ -419,6 +419,12 @@ __device__ __forceinline__ int lds_swz(int row) { return (row >> 2) & 3; }
 // The split arithmetics (vps_conv_desc.prec). NSA activation planes (staged in LDS), NSB weight planes (packed on the host),
 // NT products per k-slab: term q multiplies activation plane PA[q] with weight plane PB[q], smallest magnitude first.
 template <int MODE> struct Split;
+template <> struct Split<VPS_PREC_BF16> {
+    typedef __bf16 elem;
+    static constexpr int NSA = 1, NSB = 1, NT = 1;
+    static constexpr int PA[6] = {0, 0, 0, 0, 0, 0};
+    static constexpr int PB[6] = {0, 0, 0, 0, 0, 0};
+};
 template <> struct Split<VPS_PREC_BF16X3> {
     typedef __bf16 elem;
     static constexpr int NSA = 2, NSB = 2, NT = 3;
@@ -1427,7 +1433,8 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
 #define VPS_HALO_LAUNCH(MODE, K)                                                                                                  \
     hipLaunchKernelGGL((conv_mfma_bf16h_kernel<TM, TN, WAVES_M, WAVES_N, MODE, K, K>), dim3((unsigned)nblk2), dim3(256), 0, s, d, tiles_m2, \
                        tiles_n, per_split / ntap)
-        if (d.prec == VPS_PREC_BF16X3) { if (d.KH == 3) VPS_HALO_LAUNCH(VPS_PREC_BF16X3, 3); else VPS_HALO_LAUNCH(VPS_PREC_BF16X3, 2); }
+        if (d.prec == VPS_PREC_BF16) { if (d.KH == 3) VPS_HALO_LAUNCH(VPS_PREC_BF16, 3); else VPS_HALO_LAUNCH(VPS_PREC_BF16, 2); }
+        else if (d.prec == VPS_PREC_BF16X3) { if (d.KH == 3) VPS_HALO_LAUNCH(VPS_PREC_BF16X3, 3); else VPS_HALO_LAUNCH(VPS_PREC_BF16X3, 2); }
         else if (d.prec == VPS_PREC_F16X3) { if (d.KH == 3) VPS_HALO_LAUNCH(VPS_PREC_F16X3, 3); else VPS_HALO_LAUNCH(VPS_PREC_F16X3, 2); }
         else { if (d.KH == 3) VPS_HALO_LAUNCH(VPS_PREC_BF16X6, 3); else VPS_HALO_LAUNCH(VPS_PREC_BF16X6, 2); }
 #undef VPS_HALO_LAUNCH
@@ -1437,6 +1444,9 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
     if (d.prec == VPS_PREC_F32) {
         if (d.offset) VPS_CONV_LAUNCH((conv_mfma_f32_kernel<TM, TN, WAVES_M, WAVES_N, true>));
         else VPS_CONV_LAUNCH((conv_mfma_f32_kernel<TM, TN, WAVES_M, WAVES_N, false>));
+    } else if (d.prec == VPS_PREC_BF16) {
+        if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16, true>));
+        else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16>));
     } else if (d.prec == VPS_PREC_BF16X3) {
         if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X3, true>));
         else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X3>));
@@ -1468,7 +1478,7 @@ extern "C" int vps_conv2d(const vps_conv_desc* dp, void* stream) {
     if (!dp) return VPS_EARG(1);
     const vps_conv_desc& d = *dp;
     if (!d.in || !d.out) return VPS_EARG(2);
-    if (d.prec != VPS_PREC_F32 && d.prec != VPS_PREC_BF16X3 && d.prec != VPS_PREC_BF16X6 && d.prec != VPS_PREC_F16X3) return VPS_EARG(12);
+    if (d.prec < VPS_PREC_F32 || d.prec > VPS_PREC_F16X3) return VPS_EARG(12);
     if (d.prec == VPS_PREC_F32 ? !d.w : !d.w_split) return VPS_EARG(13);
     if ((d.in_ld & 3) || (d.in_coff & 3) || (d.cin_pad & 3) || d.cin_pad <= 0) return VPS_EARG(3);
     if ((d.kpad % BK) || d.kpad < d.KH * d.KW * d.cin_pad || (d.korder != 0 && d.korder != 1)) return VPS_EARG(4);
@@ -1514,19 +1524,14 @@ extern "C" int vps_conv2d(const vps_conv_desc* dp, void* stream) {
         return vps_launch_status();
     }
     // wave arrangement <TM, TN, WAVES_M, WAVES_N> of the 4 waves of a block. Weight fragments come from global memory (one 1 KB
-    // load per fragment = 64 cycles of the CU's vector-memory pipe, tools/gapbench.hip) while activation fragments come from LDS
-    // (two 1 KB reads per 32 cycles are free): tall wave tiles (all 128 rows x 32 columns per wave) minimise the former.
-#ifdef VPS_WAVES_2X2
+    // load per fragment = 64 cycles of the CU's vector-memory pipe, tools/gapbench.hip), activation fragments from LDS (two
+    // conflict-free 1 KB reads per 32 cycles are free). Measured per layer (profiles/r02_wave_arrangement_ab.txt): for 64-column
+    // tiles 2x2 waves of 64 rows x 32 columns beat 4x1 waves of 32 x 64 (half the weight loads: +8..18 %); for 128-column tiles
+    // the 64 x 64 wave tile stays: 1x4 waves of 128 x 32 halve the weight loads again but double the fragment reads of the halo
+    // tile, whose 18-row pitch costs a 2-way bank conflict (-7..13 %).
     switch (d.tile_n) {
         case 128: return launch_conv<2, 2, 2, 2>(d, M, s);
-        case 64: return launch_conv<1, 2, 4, 1>(d, M, s);
-        default: return launch_conv<1, 1, 4, 1>(d, M, s);
-    }
-#else
-    switch (d.tile_n) {
-        case 128: return launch_conv<4, 1, 1, 4>(d, M, s);
         case 64: return launch_conv<2, 1, 2, 2>(d, M, s);
         default: return launch_conv<1, 1, 4, 1>(d, M, s);
     }
-#endif
 }

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get('VPS_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libvpsh
 ABI_VERSION = 9
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
-PREC_F32, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 2, 3, 4
+PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
 
 # every symbol include/vps_hip.h declares (checked by tests/test_cabi.py without a GPU)
 SYMBOLS = [

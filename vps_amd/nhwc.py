@@ -20,13 +20,13 @@ def _ceil(a, b):
 
 
 # arithmetic of every PackedConv created without an explicit `prec` (hip.PREC_F32 exact / PREC_BF16X3 / PREC_BF16X6 / PREC_F16X3).
-# The library default is the exact fp32 mode; VPS_PREC=bf16x6 / f16x3 (fp32-grade split modes) / bf16x3 / f32 selects it
+# The library default is the exact fp32 mode; VPS_PREC=bf16x6 / f16x3 (fp32-grade split modes) / bf16x3 / bf16 / f32 selects it
 # for an unmodified caller such as tools/test_vpq.py.
-_PREC_NAMES = {'f32': hip.PREC_F32, 'bf16x3': hip.PREC_BF16X3, 'bf16x6': hip.PREC_BF16X6, 'f16x3': hip.PREC_F16X3}
+_PREC_NAMES = {'f32': hip.PREC_F32, 'bf16': hip.PREC_BF16, 'bf16x3': hip.PREC_BF16X3, 'bf16x6': hip.PREC_BF16X6, 'f16x3': hip.PREC_F16X3}
 PREC_NAMES = _PREC_NAMES
 # number of 16-bit weight planes / MFMA products per fp32 product of each split mode
-_PLANES = {hip.PREC_BF16X3: 2, hip.PREC_BF16X6: 3, hip.PREC_F16X3: 3}
-MFMA_PRODUCTS = {hip.PREC_F32: 1, hip.PREC_BF16X3: 3, hip.PREC_BF16X6: 6, hip.PREC_F16X3: 3}
+_PLANES = {hip.PREC_BF16: 1, hip.PREC_BF16X3: 2, hip.PREC_BF16X6: 3, hip.PREC_F16X3: 3}
+MFMA_PRODUCTS = {hip.PREC_F32: 1, hip.PREC_BF16: 1, hip.PREC_BF16X3: 3, hip.PREC_BF16X6: 6, hip.PREC_F16X3: 3}
 # f16x3: one device word per device; a conv launch ORs bit 0 into it when it staged an activation beyond the fp16 range
 _F16_STATUS = {}
 

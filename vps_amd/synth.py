@@ -8,6 +8,7 @@ CPU oracle and the golden-vector script, so all three see bit-identical weights.
 Input recipes follow SURVEY §8d: low-pass filtered random frames, the second frame a translated + noisy copy.
 """
 import math
+import re
 import zlib
 
 import numpy as np
@@ -37,6 +38,9 @@ def synth_tensor(key, shape, seed=0):
             w = torch.rand(shape, generator=g) * 1.0 + 0.5
             if '.bn3.' in key:
                 w = w * 0.35          # keep the residual branches from blowing up over 16 blocks
+                m = re.search(r'layer3\.(\d+)\.bn3', key)
+                if m and int(m.group(1)) >= 6:
+                    w = w * 0.4       # ResNet-101: 17 more blocks in layer3 (ResNet-50 has no such keys: its tensors are unchanged)
             return w
         return torch.randn(shape, generator=g) * 0.1
     if leaf == 'bias':
