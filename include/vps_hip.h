@@ -312,6 +312,14 @@ int vps_pair_count(const uint8_t* gt_rgb, const uint8_t* pred_rgb, int64_t npix,
  * impad_to_multiple) for a decoded uint8 [H][W][3] image already on the device.
  *   mean, std  HOST pointers to 3 floats (channel order of the OUTPUT, i.e. RGB when to_rgb)
  *   out        fp32 [3][Hp][Wp], (c - mean) / std in fp32, bottom/right padding = pad_val. Bit-exact with NumPy. */
+/* Resize of the same pipeline (transforms.py:107-122 -> mmcv.imrescale -> cv2.resize, INTER_LINEAR) on the decoded uint8 image:
+ * OpenCV's 8-bit fixed-point bilinear (11-bit coefficients), or the area average when the size is halved exactly.
+ *   xtab / ytab  DEVICE int32 [W][3] / [H][3]: source index, weight of it, weight of its successor (weights sum to 2048);
+ *                unused (may be NULL) for the exact 2x shrink
+ *   src / dst    uint8 [H0][W0][C] -> [H][W][C], C <= 4 */
+int vps_resize_u8(const uint8_t* src, int H0, int W0, uint8_t* dst, int H, int W, int C, const int32_t* xtab,
+                  const int32_t* ytab, void* stream);
+
 int vps_image_prep(const uint8_t* img, int H, int W, int Hp, int Wp, const float* mean, const float* std, int to_rgb,
                    float pad_val, float* out, void* stream);
 

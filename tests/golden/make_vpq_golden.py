@@ -14,7 +14,7 @@ def id2rgb(i):
     return [i % 256, (i // 256) % 256, i // 65536]
 
 
-def make_clip(rng, H, W, nfr, ninst, crowd=False, void=True):
+def make_clip(rng, H, W, nfr, ninst, crowd=False, void=True, unlisted=False):
     """gt / pred frames of a clip: stuff background in blocks, instances that move a little, predictions that are shifted /
     missing / of the wrong class, optional crowd region and void pixels. Returns the per-frame tuples the reference takes."""
     categories = {c: {'id': c, 'isthing': 1 if c >= 11 else 0} for c in range(19)}
@@ -47,6 +47,10 @@ def make_clip(rng, H, W, nfr, ninst, crowd=False, void=True):
         gt_info = [{'id': int(k), 'category_id': int(v), 'iscrowd': 0, 'area': int((gt == k).sum())} for k, v in gt_seg.items() if (gt == k).any()]
         if crowd and gt_info:
             gt_info[-1]['iscrowd'] = 1
+        if unlisted and f % 2 == 1 and ninst:
+            # inconsistent ground truth: instance 0 stays painted in this frame's PNG but its JSON entry is missing here (listed
+            # by the other frames of the window): the reference still counts its pixels in the window's confusion map
+            gt_info = [el for el in gt_info if el['id'] != gt_inst[0][0]]
         pr_info = [{'id': int(k), 'category_id': int(v), 'iscrowd': 0, 'area': int((pr == k).sum())} for k, v in pr_seg.items() if (pr == k).any()]
         to_rgb = lambda m: np.stack([m % 256, (m // 256) % 256, m // 65536], -1).astype(np.uint8)
         frames.append(({'segments_info': gt_info}, {'segments_info': pr_info}, to_rgb(gt), to_rgb(pr), {}))
@@ -58,7 +62,8 @@ def main():
     ref = importlib.import_module('tools.eval_vpq')
     rng = np.random.default_rng(0)
     out = {}
-    specs = [dict(H=48, W=80, nfr=5, ninst=9, crowd=False), dict(H=64, W=96, nfr=6, ninst=14, crowd=True), dict(H=40, W=64, nfr=4, ninst=0, crowd=False)]
+    specs = [dict(H=48, W=80, nfr=5, ninst=9, crowd=False), dict(H=64, W=96, nfr=6, ninst=14, crowd=True), dict(H=40, W=64, nfr=4, ninst=0, crowd=False),
+             dict(H=48, W=80, nfr=5, ninst=6, crowd=False, unlisted=True)]
     for ci, sp in enumerate(specs):
         frames, categories = make_clip(rng, **sp)
         out['clip%d_json' % ci] = np.frombuffer(json.dumps([[f[0], f[1]] for f in frames]).encode(), dtype=np.uint8)

@@ -33,7 +33,7 @@ def test_oracle_matches_reference_function():
     n = 0
     for ci, nf, frames, counts, iou in _clips():
         _check(oev.vpq_compute_single_core(frames, CATS, nframes=nf), counts, iou, (ci, nf)); n += 1
-    assert n == 9 and int(np.load(GOLD)['clip1_nf2_counts'][:, 1].sum()) > 0        # the golden clips do contain matches
+    assert n == 12 and int(np.load(GOLD)['clip1_nf2_counts'][:, 1].sum()) > 0        # the golden clips do contain matches
 
 
 def test_host_matching_logic_with_numpy_counts(monkeypatch):
@@ -41,7 +41,7 @@ def test_host_matching_logic_with_numpy_counts(monkeypatch):
     is replaced by its NumPy definition and the result must still equal the reference function's statistics"""
     from vps_amd import evaluate as ev
 
-    def count(self, gt_json, pred_json, gt_pan, pred_pan, categories):
+    def count(self, gt_json, pred_json, gt_pan, pred_pan, categories, extra_gt_ids=None):
         ids = lambda q: (lambda u: u[:, :, 0] + u[:, :, 1] * 256 + u[:, :, 2] * 65536)(np.asarray(q).astype(np.int64))
         g, p = ids(gt_pan), ids(pred_pan)
         gt_segms, pred_segms = ev._merged(gt_json), ev._merged(pred_json)
@@ -54,7 +54,7 @@ def test_host_matching_logic_with_numpy_counts(monkeypatch):
                 continue
             pred_segms[label]['area'] = int(c); pred_set.remove(label)
         assert not pred_set
-        listed_g = set([0] + [el['id'] for el in gt_json['segments_info']])
+        listed_g = set([0] + [el['id'] for el in gt_json['segments_info']] + list(extra_gt_ids or ()))
         lab, c2 = np.unique(g * (1 << 24) + p, return_counts=True)
         pairs = {(int(l >> 24), int(l & ((1 << 24) - 1))): int(c) for l, c in zip(lab, c2) if int(l >> 24) in listed_g}
         return gt_segms, pred_segms, pairs

@@ -46,5 +46,33 @@ def test_results_dict_and_pair_feeder(dev):
     assert a.data_ptr() == a_ref.data_ptr()                     # the first frame is its own reference
     assert b_ref.data_ptr() == a.data_ptr()                     # frame t's ref_img is frame t-1's tensor, prepared once
     assert np.array_equal(b[0].cpu().numpy(), opl.prepare(f1, **NORM))
-    with pytest.raises(NotImplementedError):
-        pl.DeviceImagePrep(**NORM, img_scale=(2048, 1024), device=dev).prep(f0)     # a non-identity rescale is not on this path
+    # a non-identity rescale: Resize (cv2 fixed-point bilinear) -> Normalize -> Pad on the device
+    out, img_shape, pad_shape, sf = pl.DeviceImagePrep(**NORM, img_scale=(2048, 1024), device=dev).prep(f0)
+    f, (nw, nh) = opl.rescale_size(64, 128, (2048, 1024))
+    assert sf == f == 16.0 and img_shape == (nh, nw, 3) == (1024, 2048, 3)
+    assert np.array_equal(out.cpu().numpy(), opl.prepare(opl.cv2_resize_linear_u8(f0, (nw, nh)), **NORM))
+
+
+def test_oracle_resize_properties():
+    """cv2.resize(INTER_LINEAR, uint8) restatement: identity, constant images, the exact-2x area rule, 11-bit weights"""
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(12, 20, 3), dtype=np.uint8)
+    assert np.array_equal(opl.cv2_resize_linear_u8(img, (20, 12)), img)
+    assert np.array_equal(opl.cv2_resize_linear_u8(np.full((9, 7, 3), 200, np.uint8), (31, 17)), np.full((17, 31, 3), 200, np.uint8))
+    half = opl.cv2_resize_linear_u8(img, (10, 6))
+    i64 = img.astype(np.int64)
+    assert np.array_equal(half, ((i64[0::2, 0::2] + i64[0::2, 1::2] + i64[1::2, 0::2] + i64[1::2, 1::2] + 2) >> 2).astype(np.uint8))
+    o, a0, a1 = opl.cv_linear_tables(31, 7)
+    assert (a0 + a1 == 2048).all() and o.min() == 0 and o.max() == 6 and a1[0] == 0 and a1[-1] == 0
+    up = opl.cv2_resize_linear_u8(img, (40, 24))            # x2 upscale: every output within the range of its 4 sources
+    assert up.shape == (24, 40, 3) and up.min() >= img.min() and up.max() <= img.max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H0,W0,H,W', [(540, 960, 1024, 1820), (1080, 1920, 1024, 1820), (2048, 4096, 1024, 2048), (37, 53, 64, 91), (64, 96, 17, 29)])
+def test_device_resize_matches_cv2_restatement(dev, H0, W0, H, W):
+    from vps_amd import pipeline as pl
+    img = np.random.default_rng(H0 + W).integers(0, 256, size=(H0, W0, 3), dtype=np.uint8)
+    prep = pl.DeviceImagePrep(**NORM, device=dev)
+    out = prep.resize(torch.from_numpy(img).to(dev), W, H)
+    assert np.array_equal(out.cpu().numpy(), opl.cv2_resize_linear_u8(img, (W, H)))

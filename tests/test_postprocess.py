@@ -141,3 +141,39 @@ def test_device_converter_matches_oracle(dev, H, W):
     for f in range(3):
         assert np.array_equal(pans_d[f], pans_r[f]), f
         assert ann_d[f] == ann_r[f], f
+
+
+def test_png_name_follows_the_reference():
+    from vps_amd import postprocess as pp
+    assert pp.png_name('out/pan_pred', 'frankfurt_000000_001736_leftImg8bit.png') == 'out/pan_pred/frankfurt_000000_001736.png'
+    assert pp.png_name('o', '0005_0025_frankfurt_000000_001736_newImg8bit.jpg') == 'o/0005_0025_frankfurt_000000_001736.png'
+
+
+@pytest.mark.gpu
+def test_inference_panoptic_video_writes_the_reference_files(dev, tmp_path):
+    """the output side of tools/test_vpq.py:194-198 (cityscapes_vps.py:27-94): labelled-frame sampling, per-video conversion,
+    pan_2ch / pan_pred PNGs and pred.json — against the oracle's converter applied to the same sampled frames"""
+    import json
+    from PIL import Image
+    from vps_amd import postprocess as pp
+    H, W, nvid, nfr = 64, 96, 2, 30
+    rng = np.random.default_rng(5)
+    frames = []
+    for v in range(nvid):
+        frames += _pan2ch_clip(rng, H, W, nfr)
+    names = ['%04d_%04d_city_%06d_newImg8bit.png' % (v, f, f) for v in range(nvid) for f in range(nfr)]
+    sampled = frames[4::5]; snames = names[4::5]                   # (labeled_fid // lambda_) :: lambda_  ->  12 labelled frames
+    assert len(sampled) == 12
+    pans, pj = pp.inference_panoptic_video([torch.from_numpy(f).to(dev) for f in frames], str(tmp_path), None, snames, n_video=nvid,
+                                           color_generator=_Colors(), device=dev)
+    gen = _Colors()
+    ann_r, pans_r = [], []
+    for v0 in range(0, 12, 6):                                     # one converter state (instance -> colour) per video
+        a, p = opp.converter_2ch_track_core(sampled[v0:v0 + 6], gen)
+        ann_r += a; pans_r += p
+    assert pj == {'annotations': ann_r}
+    assert json.load(open(tmp_path / 'pred.json')) == json.loads(json.dumps({'annotations': ann_r}))
+    for i in range(12):
+        assert np.array_equal(pans[i], pans_r[i])
+        assert np.array_equal(np.asarray(Image.open(pp.png_name(str(tmp_path / 'pan_pred'), snames[i]))), pans_r[i])
+        assert np.array_equal(np.asarray(Image.open(pp.png_name(str(tmp_path / 'pan_2ch'), snames[i]))), sampled[i])

@@ -6,8 +6,10 @@
     python $R/tools/pmc_mfma.py $R/gpurun_out/pmc_mfma > $R/gpurun_out/pmc_mfma.json
 
 SQ_VALU_MFMA_BUSY_CYCLES counts busy cycles of the matrix pipes summed over the chip's SIMDs (MI355X_MICROARCH.md: 32 per
-v_mfma_f32_32x32x16_{bf16,f16}); GRBM_GUI_ACTIVE counts the cycles the dispatch kept the GPU busy. busy fraction =
-MFMA_BUSY / (GUI_ACTIVE * 256 CUs * 4 SIMDs). Collected in its own pass (no other trace domain)."""
+v_mfma_f32_32x32x16_{bf16,f16}; calibrated: the 256->256 3x3 @256x512 layer reports exactly 32 x its 14 155 776 MFMAs);
+GRBM_GUI_ACTIVE is reported summed over the 8 XCDs (6.6 M counts for a 0.44 ms dispatch = 8 x 1.87 GHz), so the active cycles
+of the dispatch are GUI_ACTIVE / 8. busy fraction = MFMA_BUSY / (GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs). Collected in its own
+pass (no other trace domain)."""
 import csv
 import glob
 import json
@@ -15,6 +17,7 @@ import os
 import sys
 
 NSIMD = 256 * 4
+NXCD = 8
 
 
 def main():
@@ -28,10 +31,10 @@ def main():
         for (_, name), c in rows.items():
             if 'SQ_VALU_MFMA_BUSY_CYCLES' not in c or 'GRBM_GUI_ACTIVE' not in c:
                 continue
-            short = name.split('(')[0].replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '')
+            short = name.replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '').split('(')[0]
             a = per.setdefault(short, [0, 0.0, 0.0])
-            a[0] += 1; a[1] += c['SQ_VALU_MFMA_BUSY_CYCLES']; a[2] += c['GRBM_GUI_ACTIVE']
-    out = {'kernels': {}, 'note': 'busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * %d SIMDs); conv family only' % NSIMD}
+            a[0] += 1; a[1] += c['SQ_VALU_MFMA_BUSY_CYCLES']; a[2] += c['GRBM_GUI_ACTIVE'] / NXCD
+    out = {'kernels': {}, 'note': 'busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / %d XCDs * %d SIMDs); conv family only' % (NXCD, NSIMD)}
     tb = ta = 0.0
     for k, (n, busy, act) in sorted(per.items(), key=lambda kv: -kv[1][2]):
         if 'conv_mfma' not in k:

@@ -252,6 +252,50 @@ extern "C" int vps_image_prep(const uint8_t* img, int H, int W, int Hp, int Wp, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Resize of the test pipeline (transforms.py:107-122 -> mmcv.imrescale -> cv2.resize INTER_LINEAR on the decoded uint8 image):
+// OpenCV's 8-bit bilinear, fixed point (resize.cpp: 11-bit coefficients; horizontal pass into int, vertical pass
+// ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2), or the area average of an exact 2x shrink. Index / weight tables come
+// from the host (they are per row / per column).
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256)
+void resize_u8_kernel(const uint8_t* __restrict__ src, int H0, int W0, uint8_t* __restrict__ dst, int H, int W, int C,
+                      const int32_t* __restrict__ xtab, const int32_t* __restrict__ ytab, int area2x) {
+    const long total = (long)H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(idx / W), x = (int)(idx - (long)y * W);
+        if (area2x) {
+            const uint8_t* p = src + ((size_t)(2 * y) * W0 + 2 * x) * C;
+            for (int c = 0; c < C; ++c)
+                dst[idx * C + c] = (uint8_t)((p[c] + p[C + c] + p[(size_t)W0 * C + c] + p[(size_t)W0 * C + C + c] + 2) >> 2);
+            continue;
+        }
+        const int x0 = xtab[3 * x], a0 = xtab[3 * x + 1], a1 = xtab[3 * x + 2];
+        const int y0 = ytab[3 * y], b0 = ytab[3 * y + 1], b1 = ytab[3 * y + 2];
+        const int x1 = min(x0 + 1, W0 - 1), y1 = min(y0 + 1, H0 - 1);
+        const uint8_t* r0 = src + (size_t)y0 * W0 * C;
+        const uint8_t* r1 = src + (size_t)y1 * W0 * C;
+        for (int c = 0; c < C; ++c) {
+            const int s0 = r0[x0 * C + c] * a0 + r0[x1 * C + c] * a1;
+            const int s1 = r1[x0 * C + c] * a0 + r1[x1 * C + c] * a1;
+            const int v = (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2;
+            dst[idx * C + c] = (uint8_t)min(max(v, 0), 255);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int vps_resize_u8(const uint8_t* src, int H0, int W0, uint8_t* dst, int H, int W, int C, const int32_t* xtab,
+                             const int32_t* ytab, void* stream) {
+    if (!src || !dst || H0 <= 0 || W0 <= 0 || H <= 0 || W <= 0 || C <= 0 || C > 4) return VPS_EARG(1);
+    const int area2x = (W0 == 2 * W && H0 == 2 * H) ? 1 : 0;
+    if (!area2x && (!xtab || !ytab)) return VPS_EARG(2);
+    hipLaunchKernelGGL(resize_u8_kernel, dim3(stream_grid((long)H * W, 256)), dim3(256), 0, (hipStream_t)stream, src, H0, W0, dst, H, W, C,
+                       xtab, ytab, area2x);
+    return vps_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Second half of the output path: tools/dataset/cityscapes_vps.py:97-159 (converter_2ch_track_core). Per frame the reference
 // builds one boolean mask per segment (np.unique over 1000*seg + obj) to paint it, take its bounding box and count it.
 //   vps_segment_stats  per (seg, obj) pair: pixel count and bounding box, one pass (table [65536][5] int32)

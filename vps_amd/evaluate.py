@@ -78,7 +78,7 @@ class FrameCounts:
     def __init__(self, device='cuda'):
         self.device = torch.device(device)
 
-    def count(self, gt_json, pred_json, gt_pan, pred_pan, categories):
+    def count(self, gt_json, pred_json, gt_pan, pred_pan, categories, extra_gt_ids=None):
         lib = hip.load()
         dev = self.device
 
@@ -89,7 +89,10 @@ class FrameCounts:
             return t
         g, p = up(gt_pan), up(pred_pan)
         assert g.shape == p.shape
-        gt_ids = np.unique(np.array([VOID] + [el['id'] for el in gt_json['segments_info']], dtype=np.int64))
+        # ground-truth ids counted in this frame: its own JSON's plus `extra_gt_ids` (the ids any frame of the clip lists): the
+        # reference takes np.unique over the WINDOW's pixel pairs (eval_vpq.py:150-157), so an id painted in this frame's PNG but
+        # listed only by another frame of the window still takes part in the matching
+        gt_ids = np.unique(np.array([VOID] + [el['id'] for el in gt_json['segments_info']] + list(extra_gt_ids or ()), dtype=np.int64))
         pred_ids = np.unique(np.array([VOID] + [el['id'] for el in pred_json['segments_info']], dtype=np.int64))
         gi = torch.from_numpy(gt_ids.astype(np.int32)).to(dev); pi = torch.from_numpy(pred_ids.astype(np.int32)).to(dev)   # ids < 2^24
         counts = torch.empty((len(gt_ids) + 1) * (len(pred_ids) + 1), dtype=torch.int32, device=dev)
@@ -126,16 +129,17 @@ class FrameCounts:
 
 def vpq_compute_single_core(gt_pred_set, categories, nframes=2, device='cuda', _cache=None):
     """eval_vpq.py:74-209, same arguments and result. `_cache` (optional dict) keeps the per-frame device results across
-    calls with different `nframes` on the same clip."""
+    calls with different `nframes`; entries are keyed by the clip object as well, so one dict may serve several videos."""
     fc = FrameCounts(device)
     cache = {} if _cache is None else _cache
     stat = PQStat()
+    clip_gt_ids = sorted({el['id'] for item in gt_pred_set for el in item[0]['segments_info']})
     for idx in range(0, len(gt_pred_set) - nframes + 1):
         gts, preds, gt_pred_map = [], [], {}
         for off, (gt_json, pred_json, gt_pan, pred_pan, _) in enumerate(gt_pred_set[idx:idx + nframes]):
-            key = idx + off
+            key = (id(gt_pred_set), idx + off)
             if key not in cache:
-                cache[key] = fc.count(gt_json, pred_json, gt_pan, pred_pan, categories)
+                cache[key] = fc.count(gt_json, pred_json, gt_pan, pred_pan, categories, clip_gt_ids)
             g, p, pairs = cache[key]
             gts.append(copy.deepcopy(g)); preds.append(copy.deepcopy(p))        # the reference rebuilds them per window
             for k, v in pairs.items():

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VPS_HIP_LIB: developer override to load an experimental build of the same ABI (kernel A/B timing)
 LIB_PATH = os.environ.get('VPS_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libvpship.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
@@ -26,7 +26,7 @@ SYMBOLS = [
     'vps_bfp_scatter', 'vps_axpb', 'vps_flow_prep', 'vps_flow_stage', 'vps_groupnorm_relu', 'vps_tcea_temporal',
     'vps_tcea_modulate', 'vps_roi_align', 'vps_nms_batched', 'vps_delta2bbox', 'vps_bbox_overlaps',
     'vps_row_softmax', 'vps_mask_count', 'vps_mask_commit', 'vps_mask_removal', 'vps_mask_level', 'vps_panoptic_combine',
-    'vps_unify_hist', 'vps_unify_tables', 'vps_unify_write', 'vps_image_prep', 'vps_segment_stats', 'vps_segment_paint', 'vps_pair_count',
+    'vps_unify_hist', 'vps_unify_tables', 'vps_unify_write', 'vps_image_prep', 'vps_resize_u8', 'vps_segment_stats', 'vps_segment_paint', 'vps_pair_count',
 ]
 
 
@@ -132,6 +132,7 @@ def load():
     lib.vps_unify_write.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]
     lib.vps_image_prep.argtypes = [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_int,
                                    ctypes.c_float, c_void_p, c_void_p]
+    lib.vps_resize_u8.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     lib.vps_segment_stats.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.vps_segment_paint.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]
     lib.vps_pair_count.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]

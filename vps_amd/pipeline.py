@@ -8,8 +8,9 @@ the device, because frame t's `ref_img` IS frame t-1's `img` (`tools/dataset/cit
 video is its own reference) — the reference decodes and normalises every image twice.
 
 Resize: at the dataset's native 1024x2048 the keep-ratio rescale to (2048, 1024) has scale factor 1.0 and copies the image;
-any other size needs cv2's fixed-point bilinear resize, which is not reproduced here -> NotImplementedError (row 1 remainder).
-No CPU path: the HIP library must load."""
+any other size goes through `vps_resize_u8`, OpenCV's 8-bit fixed-point bilinear (what mmcv.imrescale -> cv2.resize computes on
+the decoded image; restated from the published resize.cpp, no cv2 here to pin it). Image decoding itself (cv2.imread) stays
+on the host. No CPU path: the HIP library must load."""
 import ctypes
 
 import numpy as np
@@ -39,16 +40,46 @@ class DeviceImagePrep:
         max_long, max_short = max(self.img_scale), min(self.img_scale)
         return min(max_long / max(h, w), max_short / min(h, w))
 
+    @staticmethod
+    def _linear_table(dst, src):
+        """resize.cpp, INTER_LINEAR: per destination index (source index, 2048*(1-f), 2048*f) with f in float like OpenCV"""
+        d = np.arange(dst, dtype=np.float64)
+        f = ((d + 0.5) * (float(src) / float(dst)) - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        lo = s < 0
+        f[lo] = 0; s[lo] = 0
+        hi = s >= src - 1
+        f[hi] = 0; s[hi] = src - 1
+        tab = np.stack([s, np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64), np.rint(f * np.float32(2048)).astype(np.int64)], 1)
+        return torch.from_numpy(np.ascontiguousarray(tab.astype(np.int32)))
+
+    def resize(self, t, new_w, new_h):
+        """device uint8 [H,W,3] -> [new_h,new_w,3], cv2.resize(.., INTER_LINEAR) arithmetic"""
+        H, W = int(t.shape[0]), int(t.shape[1])
+        key = (H, W, new_h, new_w)
+        tabs = self.__dict__.setdefault('_tabs', {})
+        if key not in tabs:
+            tabs[key] = (self._linear_table(new_w, W).to(self.device), self._linear_table(new_h, H).to(self.device))
+        xt, yt = tabs[key]
+        out = torch.empty(new_h, new_w, 3, dtype=torch.uint8, device=self.device)
+        hip.check(hip.load().vps_resize_u8(hip.ptr(t), H, W, hip.ptr(out), new_h, new_w, 3, hip.ptr(xt), hip.ptr(yt), hip.stream_ptr()),
+                  'vps_resize_u8')
+        return out
+
     def prep(self, img):
         """uint8 [H,W,3] (numpy as cv2.imread returns it, or a device tensor) -> device fp32 [3,Hp,Wp]"""
         t = torch.from_numpy(np.ascontiguousarray(img)) if isinstance(img, np.ndarray) else img
         assert t.dtype == torch.uint8 and t.dim() == 3 and t.shape[2] == 3, 'decoded uint8 HWC image expected'
         H, W = int(t.shape[0]), int(t.shape[1])
         sf = self.scale_factor(H, W)
-        if int(W * sf + 0.5) != W or int(H * sf + 0.5) != H:
-            raise NotImplementedError('Resize to %s changes the size of a %dx%d image; only the identity rescale of the native '
-                                      'resolution is on the device path' % (self.img_scale, H, W))
         t = t.to(self.device).contiguous()
+        nw, nh = int(W * float(sf) + 0.5), int(H * float(sf) + 0.5)              # mmcv 0.2.14 _scale_size
+        if (nw, nh) != (W, H):
+            src = t
+            t = self.resize(t, nw, nh)
+            self._keep_src = src
+            H, W = nh, nw
         d = self.size_divisor
         Hp, Wp = (H + d - 1) // d * d, (W + d - 1) // d * d
         out = torch.empty(3, Hp, Wp, dtype=torch.float32, device=self.device)

@@ -7,6 +7,8 @@ channels (pan_seg, pan_ins, pan_obj) — but the maps stay on the GPU until the 
 the reference's per-instance decisions on one wavefront, one table-lookup pass (`vps_unify_*`, `csrc/post_ops.hip`).
 The only host work is the object-id de-duplication (`:170-181`, <= 100 integers, and stateful across frames).
 No CPU path: maps must be (or are uploaded to) device tensors and the HIP library must load."""
+import json
+import os
 from collections import Counter
 
 import numpy as np
@@ -151,3 +153,77 @@ class TrackConverter:
             pan_all.append(out.cpu().numpy())
             annotations.append({"segments_info": [v for k, v in segm_info.items()]})
         return annotations, pan_all
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Output side of tools/test_vpq.py:194-198 — `inference_panoptic_video` (cityscapes_vps.py:27-94): sample the labelled frames,
+# convert the 2-channel maps (TrackConverter above), write pan_2ch / pan_pred PNGs and pred.json.
+# ------------------------------------------------------------------------------------------------------------------
+class AsyncPngWriter:
+    """PNG encoding off the critical path: a small thread pool (zlib releases the GIL) fed with host arrays; `close()` joins.
+    The reference encodes inside multiprocessing pools after ALL frames are done (base_dataset.py:434-447); here frame t is
+    encoded while frame t+1 runs on the GPU. Same file bytes' CONTENT (PIL `Image.fromarray(image).save(name)`)."""
+
+    def __init__(self, workers=4):
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(max_workers=workers)
+        self.futures = []
+
+    @staticmethod
+    def _save(image, name):
+        from PIL import Image
+        os.makedirs(os.path.dirname(name) or '.', exist_ok=True)
+        Image.fromarray(image).save(name)
+        return name
+
+    def submit(self, image, name):
+        self.futures.append(self.pool.submit(self._save, np.ascontiguousarray(image), name))
+
+    def close(self):
+        names = [f.result() for f in self.futures]       # re-raises a worker's exception
+        self.pool.shutdown()
+        self.futures = []
+        return names
+
+
+def png_name(save_folder, name):
+    """cityscapes_vps.py:73 (save_image): output file name of an input image name"""
+    return os.path.join(save_folder, name.replace('_leftImg8bit', '').replace('_newImg8bit', '').replace('jpg', 'png').replace('jpeg', 'png'))
+
+
+def inference_panoptic_video(pred_pans_2ch, output_dir, categories, names, n_video=0, color_generator=None, device='cuda',
+                             labeled_fid=20, lambda_=5, nframes_per_video=6, writer=None):
+    """`CityscapesVps.inference_panoptic_video` (cityscapes_vps.py:27-94) with the conversion on the device and asynchronous PNG
+    writing: same arguments and return value `(pred_pans, pred_json)`, same files (`pan_2ch/`, `pan_pred/`, `pred.json`).
+    `pred_pans_2ch`: per-frame uint8 [H,W,3] maps (host arrays or device tensors, e.g. straight from PanopticUnifier);
+    `names`: the image file names of the SAMPLED frames (the reference passes them already sampled, test_vpq.py:186-197).
+    color_generator: panopticapi's IdGenerator(categories) by default (imported lazily, like the reference); colours are handed
+    out per video in the reference's order — one converter state per video, as `np.array_split(.., nprocs)` over whole videos
+    gives when nprocs == number of videos."""
+    pred_pans_2ch = pred_pans_2ch[(labeled_fid // lambda_)::lambda_]            # only frames with GT annotations (:36)
+    if color_generator is None:
+        from panopticapi.utils import IdGenerator
+        color_generator = IdGenerator({el['id']: el for el in categories})
+    own = writer is None
+    writer = AsyncPngWriter() if own else writer
+    conv = TrackConverter(device)
+    annotations, pan_all = [], []
+    for v0 in range(0, len(pred_pans_2ch), nframes_per_video):
+        chunk = pred_pans_2ch[v0:v0 + nframes_per_video]
+        ann, pans = conv.convert(chunk, color_generator)
+        for j, (a, pan) in enumerate(zip(ann, pans)):
+            i = v0 + j
+            annotations.append(a)
+            pan_all.append(pan)
+            if names is not None:
+                two = chunk[j]
+                two = two.cpu().numpy() if torch.is_tensor(two) else np.asarray(two)
+                writer.submit(two, png_name(os.path.join(output_dir, 'pan_2ch'), names[i]))
+                writer.submit(pan, png_name(os.path.join(output_dir, 'pan_pred'), names[i]))
+    pred_json = {'annotations': annotations}
+    os.makedirs(output_dir, exist_ok=True)
+    with open(os.path.join(output_dir, 'pred.json'), 'w') as f:
+        json.dump(pred_json, f)
+    if own:
+        writer.close()
+    return pan_all, pred_json
