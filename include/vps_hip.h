@@ -174,6 +174,11 @@ int vps_axpb(const float* in, int in_ld, int in_coff, float* out, int out_ld, in
 int vps_flow_prep(const float* img, const float* ref, const float* mean3, const float* std3,
                   float* out, int out_ld, int H, int W, double* partial, int nblk, float* rgb_mean_out,
                   void* stream);
+/* the same with the pair zero-padded (in 0..255 RGB space, bottom / right) to [Hp][Wp] before the mean is taken and x6 is
+ * written — ref: panoptic_fusetrack.py:125-128 (800x1600 -> 832x1664, 200x400 -> 256x448; FlowNet2 needs multiples of 64). */
+int vps_flow_prep_pad(const float* img, const float* ref, const float* mean3, const float* std3,
+                      float* out, int out_ld, int H, int W, int Hp, int Wp, double* partial, int nblk, float* rgb_mean_out,
+                      void* stream);
 /* FlowNet2 inter-stage tensor build (ref flownet2.py:142-151,154-163,166-174,179-187): given a 1/4-res
  * 2-channel flow (NHWC, ld/coff) compute flow_full = up4(div_mode ? flow/mul : flow*mul) (up_mode 0
  * bilinear / 1 nearest), warped = resample2d(x[3:6], flow_full), diff = x[0:3]-warped, and write any of:

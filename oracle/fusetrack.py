@@ -483,8 +483,14 @@ class FuseTrackOracle:
                 t[:, c] = t[:, c] * self.cfg['std'][c] + self.cfg['mean'][c]
             return t
         rgbs = torch.stack([denorm(img), denorm(ref_img)], dim=2)
+        H, W = rgbs.size(-2), rgbs.size(-1)
+        if H == 800 and W == 1600:                       # :125-128 "Pad zeros"
+            rgbs = F.pad(rgbs, (0, 64, 0, 32))
+        elif H == 200 and W == 400:
+            rgbs = F.pad(rgbs, (0, 48, 0, 56))
         assert rgbs.size(-2) % 64 == 0 and rgbs.size(-1) % 64 == 0
         flow = flownet2(self.sd, 'flownet2.', rgbs)
+        flow = flow[:, :, :H, :W]                        # :135-138 "Trim zeros" (index_select of arange(H), arange(W))
         self.last_flow_full = flow
         return F.interpolate(flow, scale_factor=scale_factor, mode='bilinear', align_corners=False) * scale_factor
 

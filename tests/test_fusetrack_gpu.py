@@ -193,6 +193,47 @@ def test_operator_api_matches_reference_signatures(setup):
     assert _relmax(flow.cpu(), rf) < 2e-3
 
 
+def test_cached_reference_features_are_only_used_for_the_previous_frame(setup):
+    """with consecutive iids but a ref_img that is NOT the previous call's img (a custom pair), the cached features
+    must not be used — the result equals the reference's per-frame recomputation"""
+    m, fr, dev = setup['model'], setup['frames'], setup['dev']
+    H, W = setup['H'], setup['W']
+    if setup['prec'] != 'f16x3':
+        pytest.skip('one arithmetic mode is enough for the cache logic')
+    outs = {}
+    for reuse in (True, False):
+        m.reuse_ref_features = reuse; m.verify_ref_frame = True
+        m._cache = None; m.reset_tracker()
+        m(return_loss=False, rescale=True, img=[fr[0].to(dev)], img_meta=[[synth.img_meta(H, W, 10001)]], ref_img=[fr[0].to(dev)])
+        # frame 2 with frame 2 (not frame 1's img = frame 0) as its reference
+        out = m(return_loss=False, rescale=True, img=[fr[1].to(dev)], img_meta=[[synth.img_meta(H, W, 10002)]], ref_img=[fr[2].to(dev)])
+        outs[reuse] = (out[2]['panoptic_outputs'].cpu().numpy().copy(), m._aux['neck_out'][0].to_nchw().cpu())
+    m.reuse_ref_features = True
+    m._cache = None; m.reset_tracker()
+    assert np.array_equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+
+
+def test_compute_flow_pads_and_trims_like_the_reference(setup):
+    """panoptic_fusetrack.py:125-138: 200x400 (and 800x1600) inputs are zero-padded to a multiple of 64 for FlowNet2 and the flow
+    is trimmed back; any other size must already be a multiple of 64"""
+    from oracle.fusetrack import FuseTrackOracle
+    m, dev = setup['model'], setup['dev']
+    if setup['prec'] != 'f16x3':
+        pytest.skip('one arithmetic mode is enough for the padding logic')
+    fr = synth.synth_clip(200, 400, 2, 3)
+    o = FuseTrackOracle(setup['sd'])
+    with torch.no_grad():
+        ref = o.compute_flow(fr[1], fr[0], 0.25)
+        full = o.last_flow_full
+    flow, _ = m.compute_flow(fr[1].to(dev), fr[0].to(dev), scale_factor=0.25)
+    assert tuple(flow.shape) == (1, 2, 50, 100) == tuple(ref.shape) and tuple(full.shape) == (1, 2, 200, 400)
+    assert _relmax(flow.cpu(), ref) < 2e-3
+    flow1, _ = m.compute_flow(fr[1].to(dev), fr[0].to(dev))
+    assert _relmax(flow1.cpu(), full) < 2e-3
+    with pytest.raises(AssertionError):
+        m.compute_flow(fr[1][..., :200, :336].to(dev), fr[0][..., :200, :336].to(dev))      # 200x336: not a special case, not /64
+
+
 def test_clip_shard_backend_and_handoff_feature(setup):
     """(a) ClipShardRunner + DetectorBackend (deferred tracking + sequential replay) == plain sequential calls;
     (b) frame 1 fed with the hand-off feature gathered_feature(frame 0) (what a neighbouring GPU would send) == the

@@ -184,6 +184,7 @@ class DetectorBackend:
     def __init__(self, detector, H, W, prefetch=True):
         self.det, self.H, self.W = detector, H, W
         self.prefetch = prefetch
+        detector.verify_ref_frame = False      # the runner hands frame t-1 to frame t as its reference by construction
 
     def ref_feature(self, img):
         return self.det.gathered_feature(img)

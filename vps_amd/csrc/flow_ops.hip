@@ -335,6 +335,9 @@ void nhwc_to_nchw_kernel(const float* __restrict__ in, int in_ld, int in_coff, f
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float denorm(float v, float s, float m) { return __fadd_rn(__fmul_rn(v, s), m); }
 
+// FlowNet2 sees the frame pair zero-padded (in 0..255 RGB space) to [Hp, Wp] for the two sizes the reference special-cases
+// (panoptic_fusetrack.py:125-128: 800x1600 -> 832x1664, 200x400 -> 256x448); rgb_mean is taken over the PADDED tensor
+// (flownet2.py:135): the pad pixels add 0 to the sums and count in the divisor.
 __global__ __launch_bounds__(256)
 void flow_prep_sum_kernel(const float* __restrict__ img, const float* __restrict__ ref,
                           const float* __restrict__ mean3, const float* __restrict__ std3,
@@ -372,13 +375,18 @@ __global__ void flow_prep_mean_kernel(const double* __restrict__ partial, int nb
 __global__ __launch_bounds__(256)
 void flow_prep_write_kernel(const float* __restrict__ img, const float* __restrict__ ref,
                             const float* __restrict__ mean3, const float* __restrict__ std3,
-                            const float* __restrict__ rgb_mean, float* __restrict__ out, int out_ld, long HW) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x) {
-        float* o = out + (size_t)i * out_ld;
+                            const float* __restrict__ rgb_mean, float* __restrict__ out, int out_ld, int H, int W, int Hp, int Wp) {
+    const long HW = (long)H * W, HWp = (long)Hp * Wp;
+    for (long ip = (long)blockIdx.x * blockDim.x + threadIdx.x; ip < HWp; ip += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(ip / Wp), x = (int)(ip - (long)y * Wp);
+        const bool in = y < H && x < W;
+        const long i = in ? (long)y * W + x : 0;
+        float* o = out + (size_t)ip * out_ld;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            o[c] = (denorm(img[c * HW + i], std3[c], mean3[c]) - rgb_mean[c]) / 255.0f;
-            o[3 + c] = (denorm(ref[c * HW + i], std3[c], mean3[c]) - rgb_mean[c]) / 255.0f;
+            const float a = denorm(img[c * HW + i], std3[c], mean3[c]), b = denorm(ref[c * HW + i], std3[c], mean3[c]);
+            o[c] = ((in ? a : 0.f) - rgb_mean[c]) / 255.0f;
+            o[3 + c] = ((in ? b : 0.f) - rgb_mean[c]) / 255.0f;
         }
         for (int c = 6; c < out_ld; ++c) o[c] = 0.f;
     }
@@ -521,18 +529,24 @@ extern "C" int vps_nhwc_to_nchw(const float* in, int in_ld, int in_coff, float* 
     return vps_launch_status();
 }
 
+extern "C" int vps_flow_prep_pad(const float* img, const float* ref, const float* mean3, const float* std3,
+                                 float* out, int out_ld, int H, int W, int Hp, int Wp, double* partial, int nblk, float* rgb_mean_out,
+                                 void* stream) {
+    if (!img || !ref || !mean3 || !std3 || !out || !partial || !rgb_mean_out) return VPS_EARG(1);
+    if (out_ld < 6 || nblk <= 0 || nblk > 2048 || H <= 0 || W <= 0 || Hp < H || Wp < W) return VPS_EARG(2);
+    hipStream_t s = (hipStream_t)stream;
+    const long HW = (long)H * W, HWp = (long)Hp * Wp;
+    hipLaunchKernelGGL(flow_prep_sum_kernel, dim3(nblk), dim3(256), 0, s, img, ref, mean3, std3, HW, partial);
+    hipLaunchKernelGGL(flow_prep_mean_kernel, dim3(1), dim3(192), 0, s, partial, nblk, HWp, rgb_mean_out);
+    hipLaunchKernelGGL(flow_prep_write_kernel, dim3(stream_grid(HWp, 256)), dim3(256), 0, s, img, ref, mean3, std3,
+                       rgb_mean_out, out, out_ld, H, W, Hp, Wp);
+    return vps_launch_status();
+}
+
 extern "C" int vps_flow_prep(const float* img, const float* ref, const float* mean3, const float* std3,
                              float* out, int out_ld, int H, int W, double* partial, int nblk, float* rgb_mean_out,
                              void* stream) {
-    if (!img || !ref || !mean3 || !std3 || !out || !partial || !rgb_mean_out) return VPS_EARG(1);
-    if (out_ld < 6 || nblk <= 0 || nblk > 2048 || H <= 0 || W <= 0) return VPS_EARG(2);
-    hipStream_t s = (hipStream_t)stream;
-    const long HW = (long)H * W;
-    hipLaunchKernelGGL(flow_prep_sum_kernel, dim3(nblk), dim3(256), 0, s, img, ref, mean3, std3, HW, partial);
-    hipLaunchKernelGGL(flow_prep_mean_kernel, dim3(1), dim3(192), 0, s, partial, nblk, HW, rgb_mean_out);
-    hipLaunchKernelGGL(flow_prep_write_kernel, dim3(stream_grid(HW, 256)), dim3(256), 0, s, img, ref, mean3, std3,
-                       rgb_mean_out, out, out_ld, HW);
-    return vps_launch_status();
+    return vps_flow_prep_pad(img, ref, mean3, std3, out, out_ld, H, W, H, W, partial, nblk, rgb_mean_out, stream);
 }
 
 extern "C" int vps_flow_stage(const float* x6, int x_ld, const float* flow_lo, int flo_ld, int flo_coff,

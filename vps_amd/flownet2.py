@@ -255,7 +255,9 @@ class FlowNet2(HipModule):
         Returns the full-resolution flow FMap [1,H,W,2(+2)] (compute_flow before the x0.25 resize)."""
         self.ensure_packed(img.device)
         assert abs(self.rgb_max - 255.0) < 1e-6
-        _, _, H, W = img.shape
+        _, _, H0, W0 = img.shape
+        # panoptic_fusetrack.py:125-128: the two sizes the reference pads with zeros (bottom / right) before FlowNet2 ...
+        H, W = {(800, 1600): (832, 1664), (200, 400): (256, 448)}.get((H0, W0), (H0, W0))
         assert H % 64 == 0 and W % 64 == 0, 'Flownet input must be divisible by 64.'
         lib = hip.load()
         sp = hip.stream_ptr
@@ -263,8 +265,8 @@ class FlowNet2(HipModule):
         partial = ws.get(tag + 'partial', (3 * self._nblk,), dtype=torch.float64)
         rgb_mean = ws.get(tag + 'rgb_mean', (4,))
         img = img.contiguous(); ref = ref.contiguous()
-        hip.check(lib.vps_flow_prep(hip.ptr(img), hip.ptr(ref), hip.ptr(mean), hip.ptr(std), x6.ptr(), x6.ld, H, W,
-                                    hip.ptr(partial), self._nblk, hip.ptr(rgb_mean), sp()), 'vps_flow_prep')
+        hip.check(lib.vps_flow_prep_pad(hip.ptr(img), hip.ptr(ref), hip.ptr(mean), hip.ptr(std), x6.ptr(), x6.ld, H0, W0, H, W,
+                                        hip.ptr(partial), self._nblk, hip.ptr(rgb_mean), sp()), 'vps_flow_prep_pad')
         D = self.div_flow
 
         def stage(flow_lo, out, up_mode, mul, div_mode, flow_off, flow_out_div, warp_off, diffnorm_off, flownorm_off, img_off):
@@ -289,6 +291,11 @@ class FlowNet2(HipModule):
         stage(s2_flow2, concat3, 1, D, 0, 5, 0.0, -1, 10, 8, 0)        # :166-174 nearest x4 of flow*20
         stage(sd_flow2, concat3, 1, D, 1, 3, 0.0, -1, 9, 7, -1)        # :179-187 nearest x4 of flow/20 (sic)
         flow = self.flownetfusion.run(concat3, ws, tag + 'F.')
+        if (H, W) != (H0, W0):
+            # ... and trims afterwards (:135-138, index_select of the first H0 rows / W0 columns)
+            trimmed = ws.fmap(tag + 'flow_trim', 1, H0, W0, flow.C, ld=flow.ld)
+            trimmed.t.copy_(flow.t[:, :H0, :W0, :])
+            flow = trimmed
         self._last = dict(x6=x6, c_flow2=c_flow2, concat1=concat1, s1_flow2=s1_flow2, concat2=concat2,
                           s2_flow2=s2_flow2, sd_flow2=sd_flow2, concat3=concat3)
         return flow
