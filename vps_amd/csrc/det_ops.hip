@@ -80,48 +80,46 @@ void roi_align_kernel(RoiLevels L, float finest_scale, const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// ops/nms/src/nms_kernel.cu:13-67 / utils/upsnet/nms/nms_kernel.cu:40-84: 64x64 IoU bitmask tiles
-// (one wavefront per tile — the 64-bit tile width IS the wave width), +1 pixel convention, strict '>'.
+// Suppression bitmask of NMS. Same result as ops/nms/src/nms_kernel.cu:13-67 / utils/upsnet/nms/nms_kernel.cu:40-84 (word
+// [row i][column block c] has bit j set iff IoU(box i, box 64c+j) > thr, +1 pixel convention, strict '>', j > i on the
+// diagonal block), built the wave64 way: one wavefront per tile of the UPPER triangle only (the greedy pass never reads a
+// word left of the diagonal), lane = column box held in registers; the 64 row boxes are broadcast lane by lane and the 64-bit
+// word of a row IS the wave's ballot of "column lane is suppressed by this row". The IoU keeps the reference's operation order
+// (interS / (Sa + Sb - interS), fp32) so decisions at the threshold are the same.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float dev_iou(const float* a, const float* b) {
-    const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
-    const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
-    const float width = fmaxf(right - left + 1.f, 0.f), height = fmaxf(bottom - top + 1.f, 0.f);
-    const float interS = width * height;
-    const float Sa = (a[2] - a[0] + 1.f) * (a[3] - a[1] + 1.f);
-    const float Sb = (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f);
-    return interS / (Sa + Sb - interS);
-}
-
 __global__ __launch_bounds__(64)
 void nms_mask_kernel(const float* __restrict__ boxes_all, int nmax, const int* __restrict__ counts, float thr,
                      unsigned long long* __restrict__ mask_all, int col_blocks_max) {
     const int batch = blockIdx.z;
     const int n = counts[batch];
     const int col_blocks = (n + 63) / 64;
-    const int row_start = blockIdx.y, col_start = blockIdx.x;
-    if (row_start >= col_blocks || col_start >= col_blocks) return;
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    if (cb < rb || cb >= col_blocks) return;
     const float* boxes = boxes_all + (size_t)batch * nmax * 5;
     unsigned long long* mask = mask_all + (size_t)batch * nmax * col_blocks_max;
-    const int row_size = min(n - row_start * 64, 64);
-    const int col_size = min(n - col_start * 64, 64);
-    __shared__ float bb[64 * 5];
-    const int t = threadIdx.x;
-    if (t < col_size) {
-#pragma unroll
-        for (int k = 0; k < 5; ++k) bb[t * 5 + k] = boxes[(size_t)(64 * col_start + t) * 5 + k];
+    const int lane = threadIdx.x;
+    const int row_size = min(n - rb * 64, 64);
+    const int ci = cb * 64 + lane, ri = rb * 64 + lane;
+    const bool cvalid = ci < n;
+    // column box of this lane and (for the broadcasts) row box of this lane; clamped loads, masked by cvalid / row_size
+    const float* cp = boxes + (size_t)min(ci, n - 1) * 5;
+    const float c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+    const float Sb = (c2 - c0 + 1.f) * (c3 - c1 + 1.f);
+    const float* rp = boxes + (size_t)min(ri, n - 1) * 5;
+    const float r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+    unsigned long long mine = 0ULL;
+    for (int i = 0; i < row_size; ++i) {
+        const float a0 = __shfl(r0, i, 64), a1 = __shfl(r1, i, 64), a2 = __shfl(r2, i, 64), a3 = __shfl(r3, i, 64);
+        const float left = fmaxf(a0, c0), right = fminf(a2, c2);
+        const float top = fmaxf(a1, c1), bottom = fminf(a3, c3);
+        const float width = fmaxf(right - left + 1.f, 0.f), height = fmaxf(bottom - top + 1.f, 0.f);
+        const float interS = width * height;
+        const float Sa = (a2 - a0 + 1.f) * (a3 - a1 + 1.f);
+        const bool sup = cvalid && (rb != cb || lane > i) && (interS / (Sa + Sb - interS) > thr);
+        const unsigned long long word = __ballot(sup);
+        if (lane == i) mine = word;
     }
-    __syncthreads();
-    if (t < row_size) {
-        const int cur = 64 * row_start + t;
-        const float* cb = boxes + (size_t)cur * 5;
-        const float c4[4] = {cb[0], cb[1], cb[2], cb[3]};
-        unsigned long long bits = 0;
-        const int start = (row_start == col_start) ? t + 1 : 0;
-        for (int i = start; i < col_size; ++i)
-            if (dev_iou(c4, bb + i * 5) > thr) bits |= 1ULL << i;
-        mask[(size_t)cur * col_blocks_max + col_start] = bits;
-    }
+    if (lane < row_size) mask[(size_t)ri * col_blocks_max + cb] = mine;
 }
 
 // greedy reduce of the bitmask (the host loop of nms_kernel.cu:99-123) on the device: one wavefront per
