@@ -61,6 +61,9 @@ CONV_CASES = [
     (82, 16, 3, 1, 1, 24, 48, 'leaky', False, False),   # fusion conv (cin pad 84 -> 3 chunks, tile_n 32)
     (256, 256, 3, 1, 1, 8, 16, 'relu', True, False),    # tile_n 128, a single patch
     (194, 130, 3, 1, 1, 16, 16, 'none', False, False),  # ragged channel chunk, cout not a multiple of 32
+    # enough 256-row tiles to fill the chip, 128-column tile: the 8-wave halo kernel (weights through LDS) in f16x3 / bf16x3
+    (64, 128, 3, 1, 1, 256, 512, 'relu', True, True),   # 8x32 patches, residual + BN epilogue
+    (82, 256, 3, 1, 1, 250, 500, 'leaky', False, False),  # overhanging patches (250 % 8, 500 % 32), ragged channel chunk, 2 column tiles
 ]
 
 
@@ -121,7 +124,9 @@ def test_conv_writes_into_concat_window_and_reads_padded_window(dev):
 @pytest.mark.parametrize('cin,cout,k,pad,H,W', [(1024, 512, 4, 1, 4, 8), (386, 64, 4, 1, 16, 24), (2, 2, 4, 1, 8, 12),
                                                 (256, 256, 2, 0, 14, 14), (162, 16, 4, 1, 20, 28),
                                                 # whole 8x16 patches per parity class: halo-staged kernel
-                                                (386, 64, 4, 1, 16, 32), (162, 16, 4, 1, 8, 48), (128, 160, 4, 1, 24, 16)])
+                                                (386, 64, 4, 1, 16, 32), (162, 16, 4, 1, 8, 48), (128, 160, 4, 1, 24, 16),
+                                                # 4 parity classes x 128 tiles of 8x32: the 8-wave halo kernel on a transposed conv
+                                                (96, 128, 4, 1, 128, 256)])
 def test_conv_transpose_matches_torch_cpu(dev, cin, cout, k, pad, H, W, prec, tol):
     x = _rand(2 if k == 2 else 1, cin, H, W, seed=1)
     w = _rand(cin, cout, k, k, seed=2, scale=(1.0 / (cin * k)) ** 0.5)

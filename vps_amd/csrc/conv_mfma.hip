@@ -57,7 +57,8 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
 // scale and shift move as float4 (16 B per lane: a quarter of the store instructions of the row-per-register layout; the
 // epilogue of the short-K layers - 1x1 bottleneck convolutions - was store-issue bound).
 // TILE2D: the block's 128 rows are an 8x16 patch of output positions (halo kernel), tile_m = (n*Qh/8 + ty)*Qw/16 + tx
-template <int TM, int TN, int BN, bool TILE2D = false>
+// PWL = log2 of the patch width of a TILE2D block (8 x 16 patches of the 4-wave halo kernel, 8 x 32 of the 8-wave one)
+template <int TM, int TN, int BN, bool TILE2D = false, int PWL = 4>
 __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&acc)[TM][TN], const int M, const int tile_m,
                                               const int tile_n, const int cls, const int split, const int py, const int px,
                                               const int wm, const int wn, const int lane) {
@@ -72,9 +73,9 @@ __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&a
     {
         int t2_n = 0, t2_y0 = 0, t2_x0 = 0;
         if constexpr (TILE2D) {
-            const int tiles_x = (d.Qw + 15) >> 4, tiles_y = (d.Qh + 7) >> 3;
+            const int tiles_x = (d.Qw + (1 << PWL) - 1) >> PWL, tiles_y = (d.Qh + 7) >> 3;
             const int tx = tile_m % tiles_x, tq = tile_m / tiles_x;
-            t2_x0 = tx * 16; t2_y0 = (tq % tiles_y) * 8; t2_n = tq / tiles_y;
+            t2_x0 = tx << PWL; t2_y0 = (tq % tiles_y) * 8; t2_n = tq / tiles_y;
         }
         const bool simple_pix = !TILE2D && (d.nclass == 1 && d.os_y == 1 && d.os_x == 1 && d.res_shift == 0);
 #pragma unroll
@@ -83,7 +84,7 @@ __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&a
             int qx, qy, n;
             if constexpr (TILE2D) {
                 // patches overhang the right / bottom edge when Qw % 16 or Qh % 8: those rows are computed and dropped
-                qx = t2_x0 + (jl & 15); qy = t2_y0 + (jl >> 4); n = t2_n;
+                qx = t2_x0 + (jl & ((1 << PWL) - 1)); qy = t2_y0 + (jl >> PWL); n = t2_n;
                 inside[a] = qx < d.Qw && qy < d.Qh;
                 qx = min(qx, d.Qw - 1); qy = min(qy, d.Qh - 1);
                 mlin[a] = (n * d.Qh + qy) * d.Qw + qx;
@@ -1153,6 +1154,213 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
 }
 
 // ================================================================================================
+// Halo-staged, 8 wavefronts, weights shared through LDS ("h8"): the 128-column stride-1 3x3 / 2x2 layers in the 3-product
+// modes (f16x3, bf16x3) and plain bf16, when the layer fills the chip with 256-row tiles.
+// tools/gapbench.hip: a 1 KB global load occupies the CU's vector-memory pipe for 64 cycles, a 1 KB LDS read for 4-16. In the
+// 4-wave kernel above every wave loads the 12 fragments (12 KB) of its 64 columns per tap from global memory: 2 blocks x 4 waves
+// x 12 KB = 1536 vector-memory cycles per tap and CU - exactly the 2 x 24 x 32 MFMA cycles a SIMD spends on the tap in the
+// 3-product modes (measured: matrix pipe 0.45 busy). Here ONE block of 8 waves (256 rows = an 8 x 32 patch, 128 columns) owns
+// the CU: the 24 weight fragments of a tap are loaded once (3 x 16 bytes per thread) into a double-buffered LDS region and read
+// by all 8 waves (lane-contiguous, conflict-free); a quarter of the global weight traffic. The 32-wide patch rows also make
+// the activation-fragment reads conflict-free (32 consecutive halo rows per sub-tile instead of 2 x 16 rows 18 apart).
+// Price: one barrier per tap (the weight buffers alternate per tap) instead of one per chunk.
+// ================================================================================================
+template <int MODE, int KH, int KW>
+__global__ __launch_bounds__(512, 2)
+void conv_mfma_h8_kernel(const vps_conv_desc d, const int tiles_m, const int tiles_n, const int chunks_per_split) {
+    constexpr int TM = 2, TN = 2, WAVES_N = 2, BN = 128;
+    constexpr int NTAP = KH * KW;
+    constexpr int HW = 32 + KW - 1, HH = 8 + KH - 1;   // halo tile of an 8 x 32 patch
+    constexpr int HROWS = HH * HW;                      // <= 340
+    constexpr int NLD = (HROWS + 63) / 64;              // staged rows per thread (64 rows per pass of the 512 threads)
+    typedef Split<MODE> SM;
+    typedef typename SM::elem elem_t;
+    typedef vec8<elem_t> x8;
+    typedef vec4<elem_t> x4;
+    constexpr int NSA = SM::NSA, NSB = SM::NSB;
+    constexpr int PLANE = NLD * 64 * LDS_LDH;           // 16-bit elements of one plane of one activation buffer
+    constexpr int ABUF = NSA * PLANE;
+    constexpr int NFRAG = NSB * 2 * (BN / 32);          // 1 KB weight fragments of one tap of the block tile
+    constexpr int BBUF = NFRAG * 512;
+    static_assert((NFRAG * 64) % 512 == 0, "whole 16-byte chunks per thread");
+    constexpr int NBL = NFRAG * 64 / 512;               // 16-byte weight chunks per thread and tap
+    static_assert(2 * (ABUF + BBUF) * 2 <= 160 * 1024, "LDS budget of the CU");
+
+    __shared__ __attribute__((aligned(16))) elem_t As[2 * ABUF];
+    __shared__ __attribute__((aligned(16))) elem_t Bs[2 * BBUF];
+
+    const int t = threadIdx.x;
+    int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_n = swz % tiles_n; swz /= tiles_n;
+    const int tile_m = swz % tiles_m; swz /= tiles_m;
+    const int cls = swz % d.nclass;
+    const int split = swz / d.nclass;          // split-K over whole 32-channel chunks
+
+    const int py = cls / d.os_x, px = cls - py * d.os_x;
+    const int H = d.H, W = d.W, cin_pad = d.cin_pad;
+    const int tiles_x = (d.Qw + 31) >> 5, tiles_y = (d.Qh + 7) >> 3;
+    const int tx = tile_m % tiles_x, tq = tile_m / tiles_x;
+    const int ty = tq % tiles_y, n = tq / tiles_y;
+    const int iy_org = ty * 8 - d.pad_y[py], ix_org = tx * 32 - d.pad_x[px];   // input position of halo row 0, column 0
+
+    const int k4 = t & 7;      // 4-channel group staged by this thread (8 lanes = one 128-byte line)
+    const int r0 = t >> 3;     // halo rows r0 + 64 i
+    const int chunk0 = split * chunks_per_split;
+    const int nchunks = min(chunks_per_split, d.kpad / (BK * NTAP) - chunk0);
+    const int nsteps = nchunks * NTAP;
+
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;     // wm 0..3: output rows 2 wm, 2 wm + 1 of the patch
+    const int nbt = d.cout_pad >> 5, kst = d.kpad >> 4;
+    const size_t wplane = (size_t)d.nclass * nbt * kst * 512;
+    const elem_t* __restrict__ wblk = reinterpret_cast<const elem_t*>(d.w_split) +
+        ((size_t)(cls * nbt + tile_n * (BN / 32)) * kst + 2 * (size_t)chunk0 * NTAP) * 512;
+
+    f32x4 areg[NLD];
+    unsigned aok = 0;
+    int achunk = chunk0;       // next chunk to load
+    x8 breg[NBL];
+    float amax = 0.f;
+
+    auto load_A = [&]() {
+        const int cic = achunk * BK + k4 * 4;
+        const bool kv = cic < cin_pad;
+        ++achunk;
+        aok = 0;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            // branch-free: rows outside the halo / image / channel range read element 0 and are zeroed when staged
+            const int hp = r0 + 64 * i;
+            const int hy = hp / HW, hx = hp - hy * HW;
+            const int iy = iy_org + hy, ix = ix_org + hx;
+            const bool ok = kv && hp < HROWS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const int pix = ok ? (n * H + iy) * W + ix : 0;
+            areg[i] = *reinterpret_cast<const f32x4*>(d.in + ((size_t)pix * d.in_ld + d.in_coff + (ok ? cic : 0)));
+            aok |= (ok ? 1u : 0u) << i;
+        }
+    };
+    auto store_A = [&](int i, int buf) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        x4 sp[NSA];
+        split_act<MODE>(((aok >> i) & 1u) ? areg[i] : z, sp, amax);
+        const int row = r0 + 64 * i;
+#pragma unroll
+        for (int p = 0; p < NSA; ++p)
+            *reinterpret_cast<x4*>(&As[buf * ABUF + p * PLANE + row * LDS_LDH + (((k4 >> 1) ^ lds_swz(row)) << 3) + ((k4 & 1) << 2)]) = sp[p];
+    };
+    // this thread's 16-byte chunks c = t + 512 j of fragment f = c / 64 = (plane * 2 + slab) * (BN/32) + column block
+    auto load_B = [&](int step) {
+#pragma unroll
+        for (int j = 0; j < NBL; ++j) {
+            const int c = t + 512 * j;
+            const int f = c >> 6, bcol = f % (BN / 32), pm = f / (BN / 32);
+            breg[j] = *reinterpret_cast<const x8*>(wblk + (size_t)(pm >> 1) * wplane + ((size_t)bcol * kst + 2 * step + (pm & 1)) * 512 + (c & 63) * 8);
+        }
+    };
+    auto store_B = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NBL; ++j) *reinterpret_cast<x8*>(&Bs[buf * BBUF + (t + 512 * j) * 8]) = breg[j];
+    };
+
+    // halo row of tile row j = wm*64 + a*32 + (lane&31) = patch row 2 wm + a, column lane&31, for tap (0,0); tap (ky,kx) adds ky*HW + kx
+    int hbase[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) hbase[a] = (wm * TM + a) * HW + (lane & 31);
+    x8 af[2][NSA][TM];
+    auto read_A = [&](int m, int buf, int toff) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int hrow = hbase[a] + toff;
+            const int off = buf * ABUF + hrow * LDS_LDH + (((2 * m + (lane >> 5)) ^ lds_swz(hrow)) << 3);
+#pragma unroll
+            for (int p = 0; p < NSA; ++p) af[m][p][a] = *reinterpret_cast<const x8*>(&As[off + p * PLANE]);
+        }
+    };
+    x8 bcur[2][NSB][TN];
+    auto read_B = [&](int m, int buf) {
+#pragma unroll
+        for (int p = 0; p < NSB; ++p)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+                bcur[m][p][b] = *reinterpret_cast<const x8*>(&Bs[buf * BBUF + (((p * 2 + m) * (BN / 32)) + wn * TN + b) * 512 + lane * 8]);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // prologue: chunk 0 staged in activation buffer 0, chunk 1 in flight in registers, weights of tap 0 staged in weight buffer 0
+    load_A();
+    load_B(0);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) store_A(i, 0);
+    store_B(0);
+    load_A();
+    __syncthreads();
+
+    constexpr int NT = SM::NT;
+    constexpr int NMF = 2 * NT * TM * TN;                       // MFMAs per wave and tap
+    constexpr int SPT = (NLD + NTAP - 2) / (NTAP - 1);          // halo rows staged per tap (the last tap issues the loads)
+    constexpr int NW = SPT + 3;                                 // weight loads | slab-1 fragment reads | SPT stagings | weight stores
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int cur = chunk & 1;
+#pragma unroll
+        for (int tp = 0; tp < NTAP; ++tp) {
+            const int step = chunk * NTAP + tp;
+            const int bb = step & 1;                            // weight buffer of this tap
+            const int bstep = min(step + 1, nsteps - 1);        // weights of the next tap (clamped: the last prefetch is unused)
+            const int toff = (tp / KW) * HW + (tp % KW);
+            read_A(0, cur, toff);
+            read_B(0, bb);
+            __builtin_amdgcn_sched_barrier(0);
+
+            auto work = [&](const int w) {
+                if (w == 0) load_B(bstep);                               // next tap's weights -> registers (issued first)
+                else if (w == 1) { read_A(1, cur, toff); read_B(1, bb); }   // fragments of the second slab
+                else if (w < SPT + 2) {
+                    const int si = w - 2;                                // 0 .. SPT-1
+                    if (tp < NTAP - 1) {
+                        const int row = tp * SPT + si;
+                        if (row < NLD) store_A(row, cur ^ 1);
+                    } else if (si == 0) load_A();
+                } else store_B(bb ^ 1);                                  // next tap's weights -> LDS (their loads are most of a tap old)
+            };
+
+            int mf = 0;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < NT; ++q)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) {
+                            acc[a][b] = split_mfma<MODE>(bcur[m][SM::PB[q]][b], af[m][SM::PA[q]][a], acc[a][b]);
+                            ++mf;
+#pragma unroll
+                            for (int w = 0; w < NW; ++w) {
+                                const int pos = ((w + 1) * NMF) / (NW + 1);
+                                if (mf == (pos < 1 ? 1 : pos)) {
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    work(w);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            }
+                        }
+            __syncthreads();                                    // weight buffers alternate per tap (and, after the last tap, the chunk's)
+        }
+    }
+    report_range<MODE>(d, amax);
+    conv_epilogue<TM, TN, BN, true, 5>(d, acc, tiles_m * 256, tile_m, tile_n, cls, split, py, px, wm, wn, lane);
+}
+
+// ================================================================================================
 // Narrow-output convolution (cout <= 4: the FlowNet predict_flow / upsampled_flow layers, 2 channels). A 32-column MFMA
 // tile would waste 94 % of the matrix pipe and still stage the whole activation tile through LDS; these layers are
 // pure activation streaming, so they run on the vector ALU in exact fp32: G lanes (G = pow2 >= cin_pad/4, <= 64) share
@@ -1426,7 +1634,21 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
     const int ntap = d.KH * d.KW;
     const bool halo = d.prec != VPS_PREC_F32 && !d.offset && d.stride == 1 && d.korder == 1 && d.KH == d.KW && (d.KH == 3 || d.KH == 2) &&
                       tiles2d * 128 * 2 <= (long)M * 3 && (d.ksplit == 1 || (ksteps % d.ksplit == 0 && per_split % ntap == 0));
-    if (halo) {
+    // 8-wave variant (256-row tiles, weights through LDS): 128-column layers in the modes whose two activation planes leave room
+    // for the weight buffers, when the 8 x 32 patches waste little and there are enough tiles to give every CU one
+    const long tiles2d8 = (long)d.N * ((d.Qh + 7) / 8) * ((d.Qw + 31) / 32);
+    const bool h8 = halo && BN == 128 && (d.prec == VPS_PREC_F16X3 || d.prec == VPS_PREC_BF16X3 || d.prec == VPS_PREC_BF16) &&
+                    tiles2d8 * 256 * 2 <= (long)M * 3 && tiles2d8 * tiles_n * d.nclass * d.ksplit >= 256;
+    if (h8) {
+        const int tiles_m8 = (int)tiles2d8;
+        const long nblk8 = (long)tiles_m8 * tiles_n * d.nclass * d.ksplit;
+#define VPS_H8_LAUNCH(MODE, K)                                                                                                   \
+    hipLaunchKernelGGL((conv_mfma_h8_kernel<MODE, K, K>), dim3((unsigned)nblk8), dim3(512), 0, s, d, tiles_m8, tiles_n, per_split / ntap)
+        if (d.prec == VPS_PREC_BF16) { if (d.KH == 3) VPS_H8_LAUNCH(VPS_PREC_BF16, 3); else VPS_H8_LAUNCH(VPS_PREC_BF16, 2); }
+        else if (d.prec == VPS_PREC_BF16X3) { if (d.KH == 3) VPS_H8_LAUNCH(VPS_PREC_BF16X3, 3); else VPS_H8_LAUNCH(VPS_PREC_BF16X3, 2); }
+        else { if (d.KH == 3) VPS_H8_LAUNCH(VPS_PREC_F16X3, 3); else VPS_H8_LAUNCH(VPS_PREC_F16X3, 2); }
+#undef VPS_H8_LAUNCH
+    } else if (halo) {
         const int tiles_m2 = (int)tiles2d;
         const long nblk2 = (long)tiles_m2 * tiles_n * d.nclass * d.ksplit;
         if (nblk2 > 0x7fffffffL) return VPS_EARG(21);
