@@ -502,6 +502,12 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
 
     __shared__ __attribute__((aligned(16))) elem_t As[NSA][BM * LDS_LDH];
     __shared__ __attribute__((aligned(16))) elem_t Bs[NSB][BN * LDS_LDH];
+    // DEFORM: the bilinear sampling of (tile row, tap) - 4 corner weights, 4 clamped corner coordinates - depends on neither the
+    // channel chunk nor the column tile: computed ONCE per block into this table (24 bytes per entry) instead of once per k-step
+    // (~45 VALU instructions per staged row and step: more than the 24-48 MFMAs of a step leave room for).
+    constexpr int DTAP = 9;
+    __shared__ __attribute__((aligned(16))) float cw[DEFORM ? BM * DTAP * 4 : 4];
+    __shared__ __attribute__((aligned(8))) unsigned short cc[DEFORM ? BM * DTAP * 4 : 4];
 
     const int t = threadIdx.x;
     int swz = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -585,30 +591,17 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
                 aok = (aok & ~(1u << i)) | ((ok ? 1u : 0u) << i);
             }
         } else {
-            const int tap = ky * KW + kx;
+            const int tap = min(ky * KW + kx, DTAP - 1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                // branch-free: corner weights are zeroed where the reference zeroes the corner value (or skips the whole
-                // sample), corner addresses are clamped into the image, and all four float4 loads are always issued
-                const bool act = kval && ri[i].moff >= 0;
-                const float* op = d.offset + (size_t)(act ? ri[i].moff : 0) * d.off_ld + 2 * min(tap, KH * KW - 1);
-                const float h_im = (float)(ri[i].iy0 + ky) + op[0];
-                const float w_im = (float)(ri[i].ix0 + kx) + op[1];
-                const bool inside = act && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-                const float hf = floorf(h_im), wf = floorf(w_im);
-                const int h_low = inside ? (int)hf : 0, w_low = inside ? (int)wf : 0;
-                const int h_high = h_low + 1, w_high = w_low + 1;
-                const float lh = h_im - hf, lw = w_im - wf;
-                const float hh = 1.f - lh, hw = 1.f - lw;
-                const bool hl = inside && h_low >= 0, hhv = inside && h_high <= H - 1;
-                const bool wl = w_low >= 0, whv = w_high <= W - 1;
-                dcw[i][0] = (hl && wl) ? hh * hw : 0.f;
-                dcw[i][1] = (hl && whv) ? hh * lw : 0.f;
-                dcw[i][2] = (hhv && wl) ? lh * hw : 0.f;
-                dcw[i][3] = (hhv && whv) ? lh * lw : 0.f;
-                const int hlc = min(max(h_low, 0), H - 1), hhc = min(max(h_high, 0), H - 1);
-                const int wlc = min(max(w_low, 0), W - 1), whc = min(max(w_high, 0), W - 1);
-                const float* base = d.in + (size_t)ri[i].pixbase * d.in_ld + d.in_coff + ci;
+                // table entry of (row, tap): all four float4 corner loads are always issued (clamped coordinates), the weights are
+                // zero where the reference zeroes the corner value or skips the sample, and beyond the last real k-step
+                const int e = ((r0 + 32 * i) * DTAP + tap) * 4;
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(&cw[e]);
+                const vec4<unsigned short> c4 = *reinterpret_cast<const vec4<unsigned short>*>(&cc[e]);
+                dcw[i][0] = kval ? w4[0] : 0.f; dcw[i][1] = kval ? w4[1] : 0.f; dcw[i][2] = kval ? w4[2] : 0.f; dcw[i][3] = kval ? w4[3] : 0.f;
+                const int hlc = c4[0], hhc = c4[1], wlc = c4[2], whc = c4[3];
+                const float* base = d.in + (size_t)ri[i].pixbase * d.in_ld + d.in_coff + (kval ? ci : 0);
                 dcv[i][0] = *reinterpret_cast<const f32x4*>(base + (size_t)(hlc * W + wlc) * d.in_ld);
                 dcv[i][1] = *reinterpret_cast<const f32x4*>(base + (size_t)(hlc * W + whc) * d.in_ld);
                 dcv[i][2] = *reinterpret_cast<const f32x4*>(base + (size_t)(hhc * W + wlc) * d.in_ld);
@@ -672,6 +665,36 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    if constexpr (DEFORM) {
+        // deform_conv_cuda_kernel.cu:83-113,205-237: sample position = tap position + (dh, dw) of this output pixel; valid iff
+        // -1 < h < H and -1 < w < W; a corner outside the image contributes 0
+        for (int e = t; e < BM * DTAP; e += 256) {
+            const int row = e / DTAP, tap = e - row * DTAP;
+            const int m = tile_m * BM + row;
+            const bool act = m < M && tap < ntap;
+            const int mm = act ? m : 0;
+            const int qx = mm % d.Qw, tq = mm / d.Qw, qy = tq % d.Qh;
+            const int tky = tap / KW, tkx = tap - tky * KW;
+            const float* op = d.offset + (size_t)mm * d.off_ld + 2 * min(tap, ntap - 1);
+            const float h_im = (float)(qy * d.stride - pad_y + tky) + op[0];
+            const float w_im = (float)(qx * d.stride - pad_x + tkx) + op[1];
+            const bool inside = act && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int h_low = inside ? (int)hf : 0, w_low = inside ? (int)wf : 0;
+            const int h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = h_im - hf, lw = w_im - wf;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const bool hl = inside && h_low >= 0, hhv = inside && h_high <= H - 1;
+            const bool wl = w_low >= 0, whv = w_high <= W - 1;
+            const f32x4 w4 = {(hl && wl) ? hh * hw : 0.f, (hl && whv) ? hh * lw : 0.f, (hhv && wl) ? lh * hw : 0.f, (hhv && whv) ? lh * lw : 0.f};
+            *reinterpret_cast<f32x4*>(&cw[e * 4]) = w4;
+            vec4<unsigned short> c4;
+            c4[0] = (unsigned short)min(max(h_low, 0), H - 1); c4[1] = (unsigned short)min(max(h_high, 0), H - 1);
+            c4[2] = (unsigned short)min(max(w_low, 0), W - 1); c4[3] = (unsigned short)min(max(w_high, 0), W - 1);
+            *reinterpret_cast<vec4<unsigned short>*>(&cc[e * 4]) = c4;
+        }
+        __syncthreads();
+    }
     if (nsteps > 0) {
         load_tiles(0);
         store_tiles();
@@ -1709,7 +1732,7 @@ extern "C" int vps_conv2d(const vps_conv_desc* dp, void* stream) {
     if (d.cout_pad % d.tile_n || d.cout > d.cout_pad || d.cout <= 0) return VPS_EARG(6);
     if (d.nclass != d.os_y * d.os_x || d.nclass < 1 || d.os_y > 2 || d.os_x > 2) return VPS_EARG(7);
     if (d.ksplit < 1 || (d.ksplit > 1 && !d.ws)) return VPS_EARG(8);
-    if (d.offset && (d.nclass != 1 || d.off_ld < 2 * d.KH * d.KW)) return VPS_EARG(9);
+    if (d.offset && (d.nclass != 1 || d.off_ld < 2 * d.KH * d.KW || d.KH * d.KW > 9 || d.H > 65535 || d.W > 65535)) return VPS_EARG(9);
     if (((uintptr_t)d.in & 15) || ((uintptr_t)d.w & 15) || ((uintptr_t)d.w_split & 15)) return VPS_EARG(10);
     const long Ml = (long)d.N * d.Qh * d.Qw;
     if (Ml <= 0 || Ml > 0x7fffffffL) return VPS_EARG(11);
