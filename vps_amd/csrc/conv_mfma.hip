@@ -23,6 +23,7 @@
 //     launch < 256 blocks on a 256-CU chip; partials go to a caller workspace and a reduce kernel applies
 //     the epilogue.
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -829,13 +830,15 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
     const elem_t* __restrict__ wfrag = reinterpret_cast<const elem_t*>(d.w_split) +
         ((size_t)(cls * nbt + tile_n * (BN / 32) + wn * TN) * kst + 2 * (size_t)kstep0) * 512 + lane * 8;
 
-    f32x4 areg[4];
-    unsigned aok = 0;   // bit i: staged row i is inside the image and inside the channel range
+    // activation tiles in flight in registers: tile T waits in slot T & 1 from the step T-3 that requested it until step T-1
+    // stages it (two full k-steps: a 3-product k-step is 24 MFMAs = 0.4 us, shorter than a trip to HBM)
+    f32x4 areg[2][4];
+    unsigned aok[2] = {0u, 0u};   // bit i: staged row i is inside the image and inside the channel range
     x8 bnext[2][NSB][TN];
     float amax = 0.f;
 
-    // activation tile of the next k-step -> registers (sequential: every call advances the k state by one step)
-    auto load_A = [&]() {
+    // next activation tile -> registers of `slot` (sequential: every call advances the k state by one step)
+    auto load_A = [&](const int slot) {
         int kyc, kxc, cic;
         bool kv;
         if (korder == 1) {
@@ -866,8 +869,8 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
             const int iy = ri[i].iy0 + kyc, ix = ri[i].ix0 + kxc;
             const bool ok = kv && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
             const int pix = ri[i].pixbase + (ok ? iy * W + ix : 0);
-            areg[i] = *reinterpret_cast<const f32x4*>(d.in + ((size_t)pix * d.in_ld + d.in_coff + (ok ? cic : 0)));
-            aok = (aok & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+            areg[slot][i] = *reinterpret_cast<const f32x4*>(d.in + ((size_t)pix * d.in_ld + d.in_coff + (ok ? cic : 0)));
+            aok[slot] = (aok[slot] & ~(1u << i)) | ((ok ? 1u : 0u) << i);
         }
     };
 
@@ -878,11 +881,11 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
             bnext[m][p][b] = *reinterpret_cast<const x8*>(wfrag + (size_t)p * wplane + ((size_t)b * kst + 2 * step + m) * 512);
     };
 
-    // split staged row i and write it into activation buffer `buf`
-    auto store_A = [&](int i, int buf) {
+    // split staged row i of `slot` and write it into activation buffer `buf`
+    auto store_A = [&](int i, int buf, const int slot) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         x4 sp[NSA];
-        split_act<MODE>(((aok >> i) & 1u) ? areg[i] : z, sp, amax);
+        split_act<MODE>(((aok[slot] >> i) & 1u) ? areg[slot][i] : z, sp, amax);
         const int row = r0 + 32 * i;
 #pragma unroll
         for (int p = 0; p < NSA; ++p)
@@ -910,16 +913,17 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // prologue: tile 0 staged in buffer 0, tile 1 in flight in registers, weights of step 0 in flight
+    // prologue: tile 0 staged in buffer 0, tiles 1 and 2 in flight in registers (slots 1, 0), weights of step 0 in flight
     if (nsteps > 0) {
-        load_A();
+        load_A(0);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int p = 0; p < NSB; ++p) load_B(0, m, p);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) store_A(i, 0);
-        load_A();
+        for (int i = 0; i < 4; ++i) store_A(i, 0, 0);
+        load_A(1);
+        load_A(0);
     }
     __syncthreads();
 
@@ -928,8 +932,10 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
     constexpr int NMF = 2 * NT * TM * TN;            // MFMAs per wave and k-step
     constexpr int NW = 4 + 1 + 1 + 2 * NSB;          // 4 row stagings, slab-1 fragment reads, next A loads, 2*NSB weight loads
 
-    for (int step = 0; step < nsteps; ++step) {
-        const int cur = step & 1;
+    // one k-step on activation buffer CUR (= parity of the step, compile-time: the loop below is unrolled by two so that the
+    // register slots are static)
+    auto kstep = [&](const int step, auto cur_tag) {
+        constexpr int cur = decltype(cur_tag)::value;
         const int bstep = min(step + 1, nsteps - 1);   // weights of the next step (clamped: the last prefetch is unused)
         x8 bcur[2][NSB][TN];
 #pragma unroll
@@ -942,10 +948,10 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
         __builtin_amdgcn_sched_barrier(0);
 
         auto work = [&](const int w) {
-            if (w < 2) store_A(w, cur ^ 1);                       // stage tile step+1 (its loads are one step old)
+            if (w < 2) store_A(w, cur ^ 1, cur ^ 1);                       // stage tile step+1 (its loads are one step old)
             else if (w == 2) read_A(1, cur);                      // fragments of the second slab
-            else if (w < 5) store_A(w - 1, cur ^ 1);
-            else if (w == 5) load_A();                            // tile step+2 -> registers
+            else if (w < 5) store_A(w - 1, cur ^ 1, cur ^ 1);
+            else if (w == 5) load_A(cur ^ 1);                     // tile step+3 -> the slot the stagings above just emptied
             else load_B(bstep, (w - 6) / NSB, (w - 6) % NSB);       // weights of step+1 -> registers
         };
 
@@ -973,6 +979,10 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
                         }
                     }
         __syncthreads();
+    };
+    for (int step = 0; step < nsteps; step += 2) {
+        kstep(step, std::integral_constant<int, 0>{});
+        if (step + 1 < nsteps) kstep(step + 1, std::integral_constant<int, 1>{});
     }
     report_range<MODE>(d, amax);
     conv_epilogue<TM, TN, BN>(d, acc, M, tile_m, tile_n, cls, split, py, px, wm, wn, lane);
