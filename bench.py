@@ -327,6 +327,9 @@ def main():
                 f.write('%-58s %5s %9s %9s %8s\n' % ('layer shape', 'calls', 'ms', 'GFLOP', 'TFLOP/s'))
                 for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                     f.write('%-58s %5d %9.3f %9.2f %8.2f\n' % (k, a[0], a[1], a[2] / 1e9, a[2] / a[1] / 1e9))
+            # launch order of the instrumented frame (tools/pmc_per_layer.py joins it with the per-dispatch PMC rows)
+            with open(args.conv_table + '.ordered.json', 'w') as f:
+                json.dump([dict(layer=c[3], flops=c[0], ms=c[1].elapsed_time(c[2]), algorithmic_bytes=c[4]) for c in nhwc.CONV_TRACE], f)
         nhwc.CONV_TRACE = None
         model.profile = None
         ach = fl / (ms * 1e-3) / 1e12

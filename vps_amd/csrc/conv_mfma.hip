@@ -48,6 +48,25 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+// work-item order inside an XCD's contiguous chunk: column tile fastest; the parity classes of a transposed conv come next when the
+// input outweighs the weights (the classes of one pixel tile read the same input patch: adjacent in the dispatch order, they share it
+// through the XCD's L2 instead of streaming the input once per class), else the pixel tiles come next (class-major: an XCD then
+// needs the weights of ~one class instead of all of them)
+__device__ __forceinline__ void decode_tile(const vps_conv_desc& d, int swz, const int tiles_n, const int tiles_m, int& tile_n, int& tile_m, int& cls,
+                                            int& split) {
+    tile_n = swz % tiles_n; swz /= tiles_n;
+    const bool cls_inner = d.nclass > 1 && (size_t)d.kpad * d.cout_pad * 8 < (size_t)d.N * d.H * d.W * d.cin_pad;
+    if (cls_inner) {
+        cls = swz % d.nclass; swz /= d.nclass;
+        tile_m = swz % tiles_m;
+        split = swz / tiles_m;
+    } else {
+        tile_m = swz % tiles_m; swz /= tiles_m;
+        cls = swz % d.nclass;
+        split = swz / d.nclass;
+    }
+}
+
 // ---- shared epilogue.
 // The kernels feed the WEIGHT fragment as the MFMA's A operand and the ACTIVATION fragment as its B operand (the two
 // fragment layouts of the 32x32 shapes are mirror images, so this is an argument swap), i.e. every accumulator holds the
@@ -208,10 +227,8 @@ void conv_mfma_f32_kernel(const vps_conv_desc d, const int M, const int tiles_m,
 
     const int t = threadIdx.x;
     int swz = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int tile_n = swz % tiles_n; swz /= tiles_n;
-    const int tile_m = swz % tiles_m; swz /= tiles_m;
-    const int cls = swz % d.nclass;
-    const int split = swz / d.nclass;
+    int tile_n, tile_m, cls, split;
+    decode_tile(d, swz, tiles_n, tiles_m, tile_n, tile_m, cls, split);
 
     const int py = cls / d.os_x, px = cls - py * d.os_x;
     const int pad_y = d.pad_y[py], pad_x = d.pad_x[px];
@@ -512,10 +529,8 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
 
     const int t = threadIdx.x;
     int swz = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int tile_n = swz % tiles_n; swz /= tiles_n;
-    const int tile_m = swz % tiles_m; swz /= tiles_m;
-    const int cls = swz % d.nclass;
-    const int split = swz / d.nclass;
+    int tile_n, tile_m, cls, split;
+    decode_tile(d, swz, tiles_n, tiles_m, tile_n, tile_m, cls, split);
 
     const int py = cls / d.os_x, px = cls - py * d.os_x;
     const int pad_y = d.pad_y[py], pad_x = d.pad_x[px];
@@ -777,10 +792,8 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
 
     const int t = threadIdx.x;
     int swz = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int tile_n = swz % tiles_n; swz /= tiles_n;
-    const int tile_m = swz % tiles_m; swz /= tiles_m;
-    const int cls = swz % d.nclass;
-    const int split = swz / d.nclass;
+    int tile_n, tile_m, cls, split;
+    decode_tile(d, swz, tiles_n, tiles_m, tile_n, tile_m, cls, split);
 
     const int py = cls / d.os_x, px = cls - py * d.os_x;
     const int pad_y = d.pad_y[py], pad_x = d.pad_x[px];
@@ -1021,10 +1034,8 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
 
     const int t = threadIdx.x;
     int swz = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int tile_n = swz % tiles_n; swz /= tiles_n;
-    const int tile_m = swz % tiles_m; swz /= tiles_m;
-    const int cls = swz % d.nclass;
-    const int split = swz / d.nclass;          // split-K over whole 32-channel chunks
+    int tile_n, tile_m, cls, split;             // split: split-K over whole 32-channel chunks
+    decode_tile(d, swz, tiles_n, tiles_m, tile_n, tile_m, cls, split);
 
     const int py = cls / d.os_x, px = cls - py * d.os_x;
     const int H = d.H, W = d.W, cin_pad = d.cin_pad;
@@ -1224,10 +1235,8 @@ void conv_mfma_h8_kernel(const vps_conv_desc d, const int tiles_m, const int til
 
     const int t = threadIdx.x;
     int swz = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int tile_n = swz % tiles_n; swz /= tiles_n;
-    const int tile_m = swz % tiles_m; swz /= tiles_m;
-    const int cls = swz % d.nclass;
-    const int split = swz / d.nclass;          // split-K over whole 32-channel chunks
+    int tile_n, tile_m, cls, split;             // split: split-K over whole 32-channel chunks
+    decode_tile(d, swz, tiles_n, tiles_m, tile_n, tile_m, cls, split);
 
     const int py = cls / d.os_x, px = cls - py * d.os_x;
     const int H = d.H, W = d.W, cin_pad = d.cin_pad;
