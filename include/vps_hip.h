@@ -103,6 +103,15 @@ typedef struct vps_conv_desc {
     /* VPS_PREC_F16X3: device word that gets bit 0 OR-ed in when an activation beyond the fp16 range (|x| > 65504) was staged
      * (the result of that launch is then not fp32-grade); NULL = not reported. Never written in the other modes. */
     int32_t* status;
+    /* GroupNorm sums of the OUTPUT taken by the epilogue (the deformable conv + GroupNorm towers, upsnetFPN.py:39-52): when non-NULL,
+     * the sum and the sum of squares of the stored values of every group of gn_cpg consecutive output channels (4, or a multiple
+     * of 8) are ADDED to gn_stats[r][2 g], gn_stats[r][2 g + 1] (doubles; the caller zeroes all gn_rep copies; a block adds to
+     * copy r = block index % gn_rep, gn_rep a power of two, so that the atomics of ~1000 blocks spread over gn_rep * 4 cache lines)
+     * - the statistics pass of vps_groupnorm_relu without re-reading the tensor; finish with vps_groupnorm_apply, which adds the
+     * copies up. Deformable launches (offset != NULL) of the split-operand modes only, ksplit == 1, no residual,
+     * cout/out_ld/out_coff multiples of 4; VPS_EARG otherwise. */
+    double* gn_stats;
+    int32_t gn_cpg, gn_rep;
 } vps_conv_desc;
 
 int vps_conv2d(const vps_conv_desc* d, void* stream);
@@ -195,6 +204,11 @@ int vps_flow_stage(const float* x6, int x_ld, const float* flow_lo, int flo_ld, 
 int vps_groupnorm_relu(const float* in, int in_ld, float* out, int out_ld, int out_coff, int64_t npix, int C, int G,
                        const float* gamma, const float* beta, float eps, int relu,
                        double* stats, void* stream);
+/* The apply pass alone: `stats` already holds nrep copies [nrep][2*G] of partial sums (vps_conv_desc.gn_stats / gn_rep of the
+ * conv that produced `in`); 2*G <= 512. */
+int vps_groupnorm_apply(const float* in, int in_ld, float* out, int out_ld, int out_coff, int64_t npix, int C, int G,
+                        const float* gamma, const float* beta, float eps, int relu,
+                        const double* stats, int nrep, void* stream);
 
 /* TCEA temporal attention, N=2 frames, center 0. ref: utils/tcea_modules.py:50-65.
  * emb [npix][>=2C] holds tAtt_1(frame0) in channels [0,C) and tAtt_1(frame1) in [C,2C); emb_ref = tAtt_2(frame0);

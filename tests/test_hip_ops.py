@@ -189,6 +189,40 @@ def test_deform_conv_matches_oracle(dev, cin, cout, H, W, prec, tol):
     _cmp(out.to_nchw(), ref, rtol=tol, atol=tol * max(1.0, float(ref.abs().max()) / 4), what='deform conv')
 
 
+@pytest.mark.parametrize('prec', [hip.PREC_F16X3, hip.PREC_BF16X6], ids=['f16x3', 'bf16x6'])
+@pytest.mark.parametrize('cin,cout,H,W', [(256, 256, 128, 160), (256, 128, 157, 211)])
+def test_deform_conv_epilogue_takes_the_groupnorm_sums(dev, cin, cout, H, W, prec):
+    """vps_conv_desc.gn_stats: the deformable conv's epilogue adds sum / sum of squares of each GroupNorm group of its output
+    (groups of 8 resp. 4 channels) -> equal to the sums of the stored tensor, and GroupNorm+ReLU finished by vps_groupnorm_apply
+    equals the two-pass vps_groupnorm_relu and torch (upsnetFPN.py:39-52). Split-K launches leave the slot alone."""
+    x = _rand(1, cin, H, W, seed=1)
+    off = _rand(1, 18, H, W, seed=2, scale=1.5)
+    w = _rand(cout, cin, 3, 3, seed=3, scale=(2.0 / (cin * 9)) ** 0.5)
+    g = torch.rand(cout) + 0.5; b = _rand(cout, seed=4, scale=0.2)
+    ws = nhwc.Workspace(dev)
+    pc = nhwc.PackedConv(w, None, None, 1, 1, device=dev, deform=True, prec=prec)
+    xs, offs = nhwc.from_nchw(x.to(dev)), nhwc.from_nchw(off.to(dev))
+    slot = ws.get('gn', (nhwc.GN_REP, 64), dtype=torch.float64); slot.zero_()
+    raw = pc(xs, ws=ws, name='raw', offset=offs, gn=(slot, 32))
+    assert pc.gn_fused
+    o = raw.to_nchw().double().view(32, cout // 32, -1)
+    sums = torch.stack([o.sum(dim=(1, 2)), (o * o).sum(dim=(1, 2))], dim=1).reshape(-1).cpu()
+    got = slot.sum(dim=0).cpu()
+    # lanes add their <= 8 values in fp32 before everything goes to double: errors relative to sum|v| resp. sum v^2
+    scale = torch.stack([o.abs().sum(dim=(1, 2)), (o * o).sum(dim=(1, 2))], dim=1).reshape(-1).cpu()
+    assert float(((got - sums).abs() / scale).max()) < 1e-6, (got[:6], sums[:6])
+    gd, bd = g.to(dev), b.to(dev)
+    fused = nhwc.groupnorm_relu(raw, ws.fmap('f', 1, H, W, cout), 32, gd, bd, 1e-5, slot, stats_ready=True).to_nchw()
+    two = nhwc.groupnorm_relu(raw, ws.fmap('t', 1, H, W, cout), 32, gd, bd, 1e-5, ws.get('st2', (64,), dtype=torch.float64)).to_nchw()
+    _cmp(fused, two, rtol=1e-6, atol=1e-6, what='fused vs two-pass groupnorm')
+    _cmp(fused, F.relu(F.group_norm(raw.to_nchw().cpu(), 32, g, b, 1e-5)), rtol=1e-5, atol=1e-5, what='fused groupnorm vs torch')
+    # a launch that is split over K keeps the two-pass route
+    small = nhwc.from_nchw(x[:, :, :8, :16].contiguous().to(dev))
+    slot.zero_()
+    pc(small, ws=ws, name='raws', offset=nhwc.from_nchw(off[:, :, :8, :16].contiguous().to(dev)), gn=(slot, 32))
+    assert not pc.gn_fused and float(slot.abs().max()) == 0.0
+
+
 def test_f16x3_reports_operands_beyond_the_fp16_range(dev):
     """VPS_PREC_F16X3: activations above 65504 overflow fp16 -> the launch ORs bit 0 into vps_conv_desc.status and
     nhwc.check_f16_range raises; in range, wide dynamic range (1e-4 .. 3e4) and per-channel weight scales stay fp32-grade"""

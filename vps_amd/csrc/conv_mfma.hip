@@ -78,7 +78,8 @@ __device__ __forceinline__ void decode_tile(const vps_conv_desc& d, int swz, con
 // epilogue of the short-K layers - 1x1 bottleneck convolutions - was store-issue bound).
 // TILE2D: the block's 128 rows are an 8x16 patch of output positions (halo kernel), tile_m = (n*Qh/8 + ty)*Qw/16 + tx
 // PWL = log2 of the patch width of a TILE2D block (8 x 16 patches of the 4-wave halo kernel, 8 x 32 of the 8-wave one)
-template <int TM, int TN, int BN, bool TILE2D = false, int PWL = 4>
+// GN: the sums the GroupNorm behind this conv needs (vps_conv_desc.gn_stats) are taken from the values as they are stored
+template <int TM, int TN, int BN, bool TILE2D = false, int PWL = 4, bool GN = false>
 __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&acc)[TM][TN], const int M, const int tile_m,
                                               const int tile_n, const int cls, const int split, const int py, const int px,
                                               const int wm, const int wn, const int lane) {
@@ -174,6 +175,7 @@ __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&a
                 f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
                 if (d.scale) sc = *reinterpret_cast<const f32x4*>(d.scale + cc);
                 if (d.shift) sh = *reinterpret_cast<const f32x4*>(d.shift + cc);
+                float gs = 0.f, gq = 0.f;
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {
                     if (!inside[a] || !cok) continue;
@@ -183,8 +185,28 @@ __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&a
                         float t = acc[a][b][4 * g + e] * sc[e] + sh[e];
                         if (d.res) t += rv[a][b][g][e];
                         v[e] = vps_act(t, d.act, d.slope);
+                        if constexpr (GN) { gs += v[e]; gq += v[e] * v[e]; }
                     }
                     *reinterpret_cast<f32x4*>(d.out + opix[a] * d.out_ld + d.out_coff + co) = v;
+                }
+                if constexpr (GN) {
+                    // this lane's <= TM * 4 values belong to ONE group (4 | gn_cpg): channels co .. co+3 of group co / gn_cpg. The 32 lanes
+                    // of a half wave hold the same channels of 32 positions; with gn_cpg == 8 the other half holds the group's other
+                    // four channels. Lane sums in fp32 (8 values), everything above in double, one atomic pair per wave (and half).
+                    if (d.gn_stats) {
+                        double ds = (double)gs, dq = (double)gq;
+#pragma unroll
+                        for (int off = 1; off < 32; off <<= 1) { ds += __shfl_xor(ds, off, 64); dq += __shfl_xor(dq, off, 64); }
+                        if (d.gn_cpg >= 8) { ds += __shfl_xor(ds, 32, 64); dq += __shfl_xor(dq, 32, 64); }
+                        const bool writer = d.gn_cpg >= 8 ? lane == 0 : (lane & 31) == 0;
+                        if (writer && cok) {
+                            // gn_rep copies of the 2 G sums, chosen by block: a thousand blocks on 4 cache lines would queue up
+                            double* __restrict__ st = d.gn_stats + (size_t)(blockIdx.x & (d.gn_rep - 1)) * 2 * (d.cout / d.gn_cpg);
+                            const int grp = co / d.gn_cpg;
+                            atomicAdd(&st[2 * grp], ds);
+                            atomicAdd(&st[2 * grp + 1], dq);
+                        }
+                    }
                 }
             }
         return;
@@ -750,7 +772,7 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
         }
     }
     report_range<MODE>(d, amax);
-    conv_epilogue<TM, TN, BN>(d, acc, M, tile_m, tile_n, cls, split, py, px, wm, wn, lane);
+    conv_epilogue<TM, TN, BN, false, 4, DEFORM>(d, acc, M, tile_m, tile_n, cls, split, py, px, wm, wn, lane);
 }
 
 // ================================================================================================
@@ -1753,6 +1775,10 @@ extern "C" int vps_conv2d(const vps_conv_desc* dp, void* stream) {
     if (d.ksplit < 1 || (d.ksplit > 1 && !d.ws)) return VPS_EARG(8);
     if (d.offset && (d.nclass != 1 || d.off_ld < 2 * d.KH * d.KW || d.KH * d.KW > 9 || d.H > 65535 || d.W > 65535)) return VPS_EARG(9);
     if (((uintptr_t)d.in & 15) || ((uintptr_t)d.w & 15) || ((uintptr_t)d.w_split & 15)) return VPS_EARG(10);
+    // GroupNorm sums in the epilogue: the deformable kernel of the split-operand modes only, unsplit, float4 stores, groups of 4 | 8 | 16 ...
+    if (d.gn_stats && (!d.offset || d.prec == VPS_PREC_F32 || d.ksplit != 1 || d.gn_rep < 1 || (d.gn_rep & (d.gn_rep - 1)) || d.cout % d.gn_cpg || (d.gn_cpg != 4 && (d.gn_cpg < 8 || (d.gn_cpg & 7))) ||
+                       ((d.cout | d.out_ld | d.out_coff) & 3) || ((uintptr_t)d.out & 15) || d.res || ((uintptr_t)d.gn_stats & 7)))
+        return VPS_EARG(15);
     const long Ml = (long)d.N * d.Qh * d.Qw;
     if (Ml <= 0 || Ml > 0x7fffffffL) return VPS_EARG(11);
     const int M = (int)Ml;

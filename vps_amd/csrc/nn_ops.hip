@@ -204,7 +204,15 @@ void groupnorm_stats_kernel(const float* __restrict__ in, int in_ld, long npix, 
 __global__ __launch_bounds__(256)
 void groupnorm_apply_kernel(const float* __restrict__ in, int in_ld, float* __restrict__ out, int out_ld, int out_coff, long npix,
                             int C, int G, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                            int relu, const double* __restrict__ stats) {
+                            int relu, const double* __restrict__ stats_g, int nrep) {
+    // the sums may come as nrep partial copies (conv epilogue): add them up once per block
+    __shared__ double stats[512];
+    for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) {
+        double a = 0.0;
+        for (int r = 0; r < nrep; ++r) a += stats_g[(size_t)r * 2 * G + i];
+        stats[i] = a;
+    }
+    __syncthreads();
     const long total = npix * C;
     const int cpg = C / G;
     const double cnt = (double)npix * cpg;
@@ -260,7 +268,15 @@ void groupnorm_stats4_kernel(const float* __restrict__ in, int in_ld, long npix,
 __global__ __launch_bounds__(256)
 void groupnorm_apply4_kernel(const float* __restrict__ in, int in_ld, float* __restrict__ out, int out_ld, int out_coff, long npix,
                              int C, int G, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                             int relu, const double* __restrict__ stats) {
+                             int relu, const double* __restrict__ stats_g, int nrep) {
+    // the sums may come as nrep partial copies (conv epilogue): add them up once per block
+    __shared__ double stats[512];
+    for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) {
+        double a = 0.0;
+        for (int r = 0; r < nrep; ++r) a += stats_g[(size_t)r * 2 * G + i];
+        stats[i] = a;
+    }
+    __syncthreads();
     const int c4n = C >> 2;
     const long total = npix * c4n;
     const int cpg = C / G;
@@ -405,14 +421,28 @@ extern "C" int vps_groupnorm_relu(const float* in, int in_ld, float* out, int ou
         long g4 = (npix + ppb4 - 1) / ppb4; if (g4 > 1024) g4 = 1024;
         hipLaunchKernelGGL(groupnorm_stats4_kernel, dim3((unsigned)g4), dim3(256), 0, s, in, in_ld, (long)npix, C, G, stats);
         hipLaunchKernelGGL(groupnorm_apply4_kernel, dim3(stream_grid((long)npix * (C >> 2), 256)), dim3(256), 0, s, in, in_ld, out,
-                           out_ld, out_coff, (long)npix, C, G, gamma, beta, eps, relu, stats);
+                           out_ld, out_coff, (long)npix, C, G, gamma, beta, eps, relu, stats, 1);
         return vps_launch_status();
     }
     const int ppb = 256 / C;
     long g = (npix + ppb - 1) / ppb; if (g > 1024) g = 1024;
     hipLaunchKernelGGL(groupnorm_stats_kernel, dim3((unsigned)g), dim3(256), 0, s, in, in_ld, (long)npix, C, G, stats);
     hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(stream_grid((long)npix * C, 256)), dim3(256), 0, s, in, in_ld, out, out_ld,
-                       out_coff, (long)npix, C, G, gamma, beta, eps, relu, stats);
+                       out_coff, (long)npix, C, G, gamma, beta, eps, relu, stats, 1);
+    return vps_launch_status();
+}
+
+extern "C" int vps_groupnorm_apply(const float* in, int in_ld, float* out, int out_ld, int out_coff, int64_t npix, int C, int G,
+                                   const float* gamma, const float* beta, float eps, int relu, const double* stats, int nrep, void* stream) {
+    if (!in || !out || !gamma || !beta || !stats || npix <= 0) return VPS_EARG(1);
+    if (C <= 0 || C > 256 || 256 % C || G <= 0 || C % G || G > 256 || nrep < 1) return VPS_EARG(2);
+    hipStream_t s = (hipStream_t)stream;
+    if (!((C | in_ld | out_ld | out_coff) & 3))
+        hipLaunchKernelGGL(groupnorm_apply4_kernel, dim3(stream_grid((long)npix * (C >> 2), 256)), dim3(256), 0, s, in, in_ld, out,
+                           out_ld, out_coff, (long)npix, C, G, gamma, beta, eps, relu, stats, nrep);
+    else
+        hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(stream_grid((long)npix * C, 256)), dim3(256), 0, s, in, in_ld, out, out_ld,
+                           out_coff, (long)npix, C, G, gamma, beta, eps, relu, stats, nrep);
     return vps_launch_status();
 }
 

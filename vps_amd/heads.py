@@ -65,18 +65,22 @@ class UPSNetFPN(HipModule):
         l0 = levels[0]
         oc = self.out_channels
         cat = ws.fmap(tag + 'cat', l0.N, l0.H, l0.W, oc * len(levels))
-        stats = ws.get(tag + 'gnstats', (64,), dtype=torch.float64)
+        # GroupNorm sums: one zeroed slot per (level, tower layer); the deformable conv's epilogue adds into it (unsplit launches:
+        # the two high-resolution levels), else vps_groupnorm_relu makes its own statistics pass
+        stats = ws.get(tag + 'gnstats', (len(levels) * len(self._tower), nhwc.GN_REP, 64), dtype=torch.float64)
+        stats.zero_()
         for li, x in enumerate(levels):
             for ti, t in enumerate(self._tower):
                 n = '%sl%dt%d' % (tag, li, ti)
                 off = t['off'](x, ws=ws, name=n + 'off')
-                raw = t['dcn'](x, ws=ws, name=n + 'dcn', offset=off)
+                slot = stats[li * len(self._tower) + ti]
+                raw = t['dcn'](x, ws=ws, name=n + 'dcn', offset=off, gn=(slot, t['G']))
                 last = ti == len(self._tower) - 1
                 if last and li == 0:
                     dst = cat.window(0, oc)
                 else:
                     dst = ws.fmap(n + 'gn', raw.N, raw.H, raw.W, raw.C)
-                x = nhwc.groupnorm_relu(raw, dst, t['G'], t['gamma'], t['beta'], t['eps'], stats)
+                x = nhwc.groupnorm_relu(raw, dst, t['G'], t['gamma'], t['beta'], t['eps'], slot, stats_ready=t['dcn'].gn_fused)
             if li > 0:
                 nhwc.resize(x, cat.window(li * oc, oc), 'bilinear')
         return self._pred(cat, ws=ws, name=tag + 'fcn_score')

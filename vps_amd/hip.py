@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VPS_HIP_LIB: developer override to load an experimental build of the same ABI (kernel A/B timing)
 LIB_PATH = os.environ.get('VPS_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libvpship.so')
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
@@ -23,7 +23,7 @@ PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
 SYMBOLS = [
     'vps_abi_version', 'vps_build_info', 'vps_conv2d', 'vps_resample2d', 'vps_channelnorm', 'vps_correlation',
     'vps_flow_warp', 'vps_nchw_to_nhwc', 'vps_nhwc_to_nchw', 'vps_resize', 'vps_pool3x3s2', 'vps_bfp_gather',
-    'vps_bfp_scatter', 'vps_axpb', 'vps_flow_prep', 'vps_flow_prep_pad', 'vps_flow_stage', 'vps_groupnorm_relu', 'vps_tcea_temporal',
+    'vps_bfp_scatter', 'vps_axpb', 'vps_flow_prep', 'vps_flow_prep_pad', 'vps_flow_stage', 'vps_groupnorm_relu', 'vps_groupnorm_apply', 'vps_tcea_temporal',
     'vps_tcea_modulate', 'vps_roi_align', 'vps_nms_batched', 'vps_delta2bbox', 'vps_bbox_overlaps',
     'vps_row_softmax', 'vps_mask_count', 'vps_mask_commit', 'vps_mask_removal', 'vps_mask_level', 'vps_panoptic_combine',
     'vps_unify_hist', 'vps_unify_tables', 'vps_unify_write', 'vps_image_prep', 'vps_resize_u8', 'vps_segment_stats', 'vps_segment_paint', 'vps_pair_count',
@@ -45,6 +45,7 @@ class ConvDesc(Structure):
         ('offset', c_void_p), ('off_ld', c_int32),
         ('tile_n', c_int32), ('ksplit', c_int32), ('ws', c_void_p),
         ('prec', c_int32), ('w_split', c_void_p), ('korder', c_int32), ('status', c_void_p),
+        ('gn_stats', c_void_p), ('gn_cpg', c_int32), ('gn_rep', c_int32),
     ]
 
 
@@ -109,6 +110,8 @@ def load():
                                    c_void_p, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_void_p]
     lib.vps_groupnorm_relu.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_void_p,
                                        c_float, c_int, c_void_p, c_void_p]
+    lib.vps_groupnorm_apply.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_void_p,
+                                       c_float, c_int, c_void_p, c_int, c_void_p]
     lib.vps_tcea_temporal.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                                       c_int64, c_int, c_void_p]
     lib.vps_tcea_modulate.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]

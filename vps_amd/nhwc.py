@@ -47,6 +47,7 @@ DEFAULT_PREC = _PREC_NAMES[os.environ.get('VPS_PREC', 'f32')]
 # bench.py sets this to a list to time every vps_conv2d launch with HIP events on the launch stream:
 # entries (algorithmic_flops, start_event, end_event, shape tag, algorithmic_bytes). None = no instrumentation (the default).
 CONV_TRACE = None
+GN_REP = 32   # copies of the GroupNorm sums a conv epilogue spreads its atomics over (vps_conv_desc.gn_rep)
 
 
 def check_f16_range(device):
@@ -295,8 +296,11 @@ class PackedConv:
         p = self.pad_y[0]
         return (H + 2 * p - self.KH) // self.stride + 1, (W + 2 * p - self.KW) // self.stride + 1
 
-    def __call__(self, x, out=None, ws=None, name=None, res=None, res_shift=0, offset=None, act=None):
-        """x: FMap. out: FMap window to write (allocated from `ws` under `name` if None)."""
+    def __call__(self, x, out=None, ws=None, name=None, res=None, res_shift=0, offset=None, act=None, gn=None):
+        """x: FMap. out: FMap window to write (allocated from `ws` under `name` if None).
+        gn = (stats, G): float64 tensor [GN_REP, 2*G] of zeros that receives the GroupNorm sums of the output from the epilogue
+        (vps_conv_desc.gn_stats; deformable layers of the split-operand modes). `self.gn_fused` tells whether the launch took
+        them (it does not when the layer is split over K) - the caller then runs the statistics pass itself."""
         assert x.C == self.cin or (x.C >= self.cin and x.C <= self.cin_pad), (x.C, self.cin)
         assert x.coff % 4 == 0 and x.ld % 4 == 0 and x.coff + self.cin_pad <= x.ld, (x.coff, x.ld, self.cin_pad)
         Ho, Wo = self.out_hw(x.H, x.W)
@@ -308,10 +312,12 @@ class PackedConv:
         # ctypes field stores (the low-resolution layers run for 10-20 us, less than it takes to describe them).
         ckey = (x.t.data_ptr(), x.N, x.H, x.W, x.ld, x.coff, out.t.data_ptr(), out.ld, out.coff,
                 None if res is None else (res.t.data_ptr(), res.ld, res.coff, res_shift),
-                None if offset is None else (offset.t.data_ptr(), offset.ld), act, getattr(hip.stream_ptr(), 'value', None) or 0)
+                None if offset is None else (offset.t.data_ptr(), offset.ld), act, getattr(hip.stream_ptr(), 'value', None) or 0,
+                None if gn is None else (gn[0].data_ptr(), gn[1]))
         cache = self.__dict__.setdefault('_dcache', {})
         hit = cache.get(ckey)
         if hit is not None and CONV_TRACE is None:
+            self.gn_fused = bool(hit[0].gn_stats)
             hip.conv2d(hit[0])
             return out
         d = hip.ConvDesc()
@@ -362,6 +368,13 @@ class PackedConv:
                 per = (ksteps + ksplit - 1) // ksplit
                 ksplit = (ksteps + per - 1) // per
         d.ksplit = ksplit
+        self.gn_fused = False
+        if gn is not None and self.deform and self.prec != hip.PREC_F32 and ksplit == 1 and res is None and not ((self.cout | out.ld | out.coff) & 3):
+            cpg = self.cout // gn[1]
+            if self.cout % gn[1] == 0 and (cpg == 4 or cpg % 8 == 0):
+                assert gn[0].dtype == torch.float64 and gn[0].numel() == GN_REP * 2 * gn[1] and gn[0].is_contiguous()
+                d.gn_stats, d.gn_cpg, d.gn_rep = gn[0].data_ptr(), cpg, GN_REP
+                self.gn_fused = True
         if ksplit > 1:
             need = ksplit * d.nclass * M * self.cout_pad
             if ws is not None:
@@ -477,10 +490,14 @@ def bfp_scatter(bsf, level, out):
     return out
 
 
-def groupnorm_relu(x, out, G, gamma, beta, eps, stats, relu=True):
+def groupnorm_relu(x, out, G, gamma, beta, eps, stats, relu=True, stats_ready=False):
+    """stats: 2*G doubles of scratch; stats_ready: it already holds the [GN_REP, 2*G] partial sums the producing conv's epilogue took"""
     assert x.coff == 0 and x.N == 1
-    hip.check(hip.load().vps_groupnorm_relu(x.ptr(), x.ld, out.ptr(), out.ld, out.coff, x.npix, x.C, G, hip.ptr(gamma), hip.ptr(beta),
-                                            float(eps), 1 if relu else 0, hip.ptr(stats), hip.stream_ptr()), 'vps_groupnorm_relu')
+    args = (x.ptr(), x.ld, out.ptr(), out.ld, out.coff, x.npix, x.C, G, hip.ptr(gamma), hip.ptr(beta), float(eps), 1 if relu else 0, hip.ptr(stats))
+    if stats_ready:
+        hip.check(hip.load().vps_groupnorm_apply(*args, GN_REP, hip.stream_ptr()), 'vps_groupnorm_apply')
+    else:
+        hip.check(hip.load().vps_groupnorm_relu(*args, hip.stream_ptr()), 'vps_groupnorm_relu')
     return out
 
 
