@@ -199,6 +199,16 @@ int vps_flow_stage(const float* x6, int x_ld, const float* flow_lo, int flo_ld, 
                    float* out, int out_ld, int flow_off, float flow_out_div, int warp_off,
                    int diffnorm_off, int flownorm_off, int img_off, void* stream);
 
+/* The same stage writing WHOLE 12-float pixels (three 16-byte stores; x6 with x_ld == 8, out with out_ld == 12, both 16-byte
+ * aligned), same formulas as vps_flow_stage (+ vps_axpb for the image channels):
+ *   mode 0, FlowNetS input (flownet2.py:142-163): out = [x6[0..5] | warp(img2, f) | f / mul | ||img1 - warp||], f = bilinear x4 of
+ *           flow_a * mul (flow_b unused);
+ *   mode 1, FlowNetFusion input (flownet2.py:166-187): out = [img1 | f_b | f_a | |f_b| | |f_a| | ||img1 - warp(img2, f_b)|| |
+ *           ||img1 - warp(img2, f_a)|| | 0], f_a = nearest x4 of flow_a * mul (FlowNetS_2), f_b = nearest x4 of flow_b / mul (FlowNetSD). */
+int vps_flow_stage_full(const float* x6, int x_ld, const float* flow_a, int a_ld, int a_coff,
+                        const float* flow_b, int b_ld, int b_coff, int H, int W, int mode, float mul,
+                        float* out, int out_ld, void* stream);
+
 /* GroupNorm(G) + ReLU over NHWC (N=1): stats pass then apply pass. ref: upsnetFPN.py:39-52 (GroupNorm(32)).
  * in is a coff-0 buffer, the result goes to out[.., out_coff + c]. `stats` workspace: 2*G doubles (zeroed by the call). */
 int vps_groupnorm_relu(const float* in, int in_ld, float* out, int out_ld, int out_coff, int64_t npix, int C, int G,

@@ -276,6 +276,47 @@ def test_correlation_matches_oracle(dev, C, H, W, md, s2):
     _cmp(out.to_nchw(), ref, rtol=1e-5, atol=1e-5, what='correlation')
 
 
+@pytest.mark.parametrize('H,W', [(32, 48), (64, 36)])
+def test_flow_stage_full_pixel_kernels(dev, H, W):
+    """vps_flow_stage_full (whole 12-float pixels, FlowNetS input and FlowNetFusion input) == the channel-wise vps_flow_stage +
+    vps_axpb route (same formulas, contracted differently by the compiler, then amplified by the image gradient in the warp: 2e-5), and == the torch / oracle composition of flownet2.py:142-187 (upsample, Resample2d, ChannelNorm)"""
+    lib = hip.load()
+    sp = hip.stream_ptr
+    D = 20.0
+    img = _rand(1, 6, H, W, seed=1, scale=1.0)
+    fa = _rand(1, 2, H // 4, W // 4, seed=2, scale=0.2)
+    fb = _rand(1, 2, H // 4, W // 4, seed=3, scale=60.0)
+    ws = nhwc.Workspace(dev)
+    x6 = ws.fmap('x6', 1, H, W, 6, ld=8); x6.t[..., :6] = img.permute(0, 2, 3, 1).to(dev)
+    la, lb = nhwc.from_nchw(fa.to(dev)), nhwc.from_nchw(fb.to(dev))
+
+    def stage(flow_lo, out, *a):
+        hip.check(lib.vps_flow_stage(x6.ptr(), x6.ld, flow_lo.ptr(), flow_lo.ld, flow_lo.coff, H, W, a[0], a[1], a[2], out.ptr(), out.ld,
+                                     a[3], a[4], a[5], a[6], a[7], a[8], sp()), 'stage')
+
+    # FlowNetS input
+    old = ws.fmap('old', 1, H, W, 12); new = ws.fmap('new', 1, H, W, 12)
+    hip.check(lib.vps_axpb(x6.ptr(), x6.ld, 0, old.ptr(), old.ld, 0, x6.npix, 6, 1.0, 0.0, sp()), 'axpb')
+    stage(la, old, 0, D, 0, 9, D, 6, 11, -1, -1)
+    hip.check(lib.vps_flow_stage_full(x6.ptr(), 8, la.ptr(), la.ld, la.coff, la.ptr(), la.ld, la.coff, H, W, 0, D, new.ptr(), 12, sp()), 'full')
+    _cmp(new.t, old.t.cpu(), rtol=2e-5, atol=2e-5, what='whole-pixel vs channel-wise stage')     # same formulas; the compiler contracts them differently
+    up = F.interpolate(fa * D, scale_factor=4, mode='bilinear', align_corners=False)
+    warped = O.resample2d(img[:, 3:], up)
+    ref = torch.cat([img, warped, up / D, O.channelnorm(img[:, :3] - warped)], dim=1)
+    _cmp(new.to_nchw(), ref, rtol=1e-5, atol=1e-5, what='FlowNetS input')
+    # FlowNetFusion input
+    old3 = ws.fmap('old3', 1, H, W, 11); new3 = ws.fmap('new3', 1, H, W, 11)
+    stage(la, old3, 1, D, 0, 5, 0.0, -1, 10, 8, 0)
+    stage(lb, old3, 1, D, 1, 3, 0.0, -1, 9, 7, -1)
+    hip.check(lib.vps_flow_stage_full(x6.ptr(), 8, la.ptr(), la.ld, la.coff, lb.ptr(), lb.ld, lb.coff, H, W, 1, D, new3.ptr(), 12, sp()), 'full')
+    _cmp(new3.t[..., :11], old3.t[..., :11].cpu(), rtol=2e-5, atol=2e-5, what='whole-pixel vs channel-wise fusion stage')
+    assert float(new3.t[..., 11].abs().max()) == 0.0
+    f2 = F.interpolate(fa * D, scale_factor=4, mode='nearest'); fd = F.interpolate(fb / D, scale_factor=4, mode='nearest')
+    ref3 = torch.cat([img[:, :3], fd, f2, O.channelnorm(fd), O.channelnorm(f2), O.channelnorm(img[:, :3] - O.resample2d(img[:, 3:], fd)),
+                      O.channelnorm(img[:, :3] - O.resample2d(img[:, 3:], f2))], dim=1)
+    _cmp(new3.to_nchw(), ref3, rtol=1e-5, atol=1e-5, what='FlowNetFusion input')
+
+
 def test_flow_warp_matches_grid_sample(dev):
     x = _rand(1, 64, 24, 40, seed=1); flow = _rand(1, 2, 24, 40, seed=2, scale=4.0)
     ref = OF.warping_layer(x, flow)

@@ -400,6 +400,94 @@ void flow_prep_write_kernel(const float* __restrict__ img, const float* __restri
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float scale_lo(float v, float mul, int div_mode) { return div_mode ? v / mul : v * mul; }
 
+// ---- whole-pixel variants of the inter-network stage: the 12-float pixel of the next network's input is composed in registers and
+// stored as three float4 (a wave writes 3 KB contiguous). flow_stage_kernel stores 4-byte channels at a 48-byte pixel stride
+// (every store instruction touches 24 cache lines, and the 6 image channels needed a copy pass of their own).
+__device__ __forceinline__ void warp_img2(const float* __restrict__ x6, const int x_ld, const int H, const int W, const int x, const int y,
+                                          const float fx, const float fy, const float* __restrict__ xi, float (&wv)[3], float& nrm) {
+    // Resample2d of image 2 (channels 3..5) at (x + fx, y + fy) and the ChannelNorm of img1 - warped (flownet2.py:142-151)
+    const float xf = (float)x + fx, yf = (float)y + fy;
+    const float alpha = xf - floorf(xf), beta = yf - floorf(yf);
+    const int xL = max(min((int)floorf(xf), W - 1), 0);
+    const int xR = max(min((int)(floorf(xf) + 1.f), W - 1), 0);
+    const int yT = max(min((int)floorf(yf), H - 1), 0);
+    const int yB = max(min((int)(floorf(yf) + 1.f), H - 1), 0);
+    const float* tl = x6 + ((size_t)yT * W + xL) * x_ld + 3;
+    const float* tr = x6 + ((size_t)yT * W + xR) * x_ld + 3;
+    const float* bl = x6 + ((size_t)yB * W + xL) * x_ld + 3;
+    const float* br = x6 + ((size_t)yB * W + xR) * x_ld + 3;
+    nrm = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        wv[c] = resample_tap(tl[c], tr[c], bl[c], br[c], alpha, beta);
+        const float df = xi[c] - wv[c];
+        nrm += df * df;
+    }
+}
+
+// FlowNetS input (flownet2.py:142-163): [img1 img2 | warped img2 | flow / mul | ||img1 - warped||], flow = bilinear x4 of flo * mul
+__global__ __launch_bounds__(256)
+void flow_stage_s_kernel(const float* __restrict__ x6, const float* __restrict__ flo, int flo_ld, int flo_coff, int H, int W, float mul,
+                         float* __restrict__ out) {
+    const int Hl = H >> 2, Wl = W >> 2;
+    const long HW = (long)H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < HW; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W), y = (int)(idx / W);
+        float sy = 0.25f * ((float)y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+        float sx = 0.25f * ((float)x + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int yp = y0 < Hl - 1 ? 1 : 0, xp = x0 < Wl - 1 ? 1 : 0;
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float* p00 = flo + ((size_t)y0 * Wl + x0) * flo_ld + flo_coff;
+        const float* p01 = p00 + (size_t)xp * flo_ld;
+        const float* p10 = p00 + (size_t)yp * Wl * flo_ld;
+        const float* p11 = p10 + (size_t)xp * flo_ld;
+        const float fx = hy * (hx * (p00[0] * mul) + lx * (p01[0] * mul)) + ly * (hx * (p10[0] * mul) + lx * (p11[0] * mul));
+        const float fy = hy * (hx * (p00[1] * mul) + lx * (p01[1] * mul)) + ly * (hx * (p10[1] * mul) + lx * (p11[1] * mul));
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x6 + (size_t)idx * 8);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(x6 + (size_t)idx * 8 + 4);
+        const float xi[3] = {a[0], a[1], a[2]};
+        float wv[3], nrm;
+        warp_img2(x6, 8, H, W, x, y, fx, fy, xi, wv, nrm);
+        float* o = out + (size_t)idx * 12;
+        const f32x4 o1 = {b[0], b[1], wv[0], wv[1]};
+        const f32x4 o2 = {wv[2], fx / mul, fy / mul, sqrtf(nrm)};
+        *reinterpret_cast<f32x4*>(o) = a;
+        *reinterpret_cast<f32x4*>(o + 4) = o1;
+        *reinterpret_cast<f32x4*>(o + 8) = o2;
+    }
+}
+
+// FlowNetFusion input (flownet2.py:166-187): [img1 | flow_sd | flow_s2 | |flow_sd| | |flow_s2| | diff_sd | diff_s2 | 0],
+// flow_s2 = nearest x4 of flo_s2 * mul, flow_sd = nearest x4 of flo_sd / mul
+__global__ __launch_bounds__(256)
+void flow_stage_f_kernel(const float* __restrict__ x6, const float* __restrict__ flo_s2, int s2_ld, int s2_coff,
+                         const float* __restrict__ flo_sd, int sd_ld, int sd_coff, int H, int W, float mul, float* __restrict__ out) {
+    const int Wl = W >> 2;
+    const long HW = (long)H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < HW; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W), y = (int)(idx / W);
+        const size_t lo = (size_t)(y >> 2) * Wl + (x >> 2);
+        const float* p2 = flo_s2 + lo * s2_ld + s2_coff;
+        const float* pd = flo_sd + lo * sd_ld + sd_coff;
+        const float f2x = p2[0] * mul, f2y = p2[1] * mul;
+        const float fdx = pd[0] / mul, fdy = pd[1] / mul;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x6 + (size_t)idx * 8);
+        const float xi[3] = {a[0], a[1], a[2]};
+        float wv[3], n2, nd;
+        warp_img2(x6, 8, H, W, x, y, f2x, f2y, xi, wv, n2);
+        warp_img2(x6, 8, H, W, x, y, fdx, fdy, xi, wv, nd);
+        float* o = out + (size_t)idx * 12;
+        const f32x4 o0 = {a[0], a[1], a[2], fdx};
+        const f32x4 o1 = {fdy, f2x, f2y, sqrtf(fdx * fdx + fdy * fdy)};
+        const f32x4 o2 = {sqrtf(f2x * f2x + f2y * f2y), sqrtf(nd), sqrtf(n2), 0.f};
+        *reinterpret_cast<f32x4*>(o) = o0;
+        *reinterpret_cast<f32x4*>(o + 4) = o1;
+        *reinterpret_cast<f32x4*>(o + 8) = o2;
+    }
+}
+
 __global__ __launch_bounds__(256)
 void flow_stage_kernel(const float* __restrict__ x6, int x_ld, const float* __restrict__ flo, int flo_ld, int flo_coff,
                        int H, int W, int up_mode, float mul, int div_mode,
@@ -547,6 +635,24 @@ extern "C" int vps_flow_prep(const float* img, const float* ref, const float* me
                              float* out, int out_ld, int H, int W, double* partial, int nblk, float* rgb_mean_out,
                              void* stream) {
     return vps_flow_prep_pad(img, ref, mean3, std3, out, out_ld, H, W, H, W, partial, nblk, rgb_mean_out, stream);
+}
+
+extern "C" int vps_flow_stage_full(const float* x6, int x_ld, const float* flow_a, int a_ld, int a_coff,
+                                   const float* flow_b, int b_ld, int b_coff, int H, int W, int mode, float mul,
+                                   float* out, int out_ld, void* stream) {
+    if (!x6 || !flow_a || !out || H <= 0 || W <= 0 || (H & 3) || (W & 3) || mul == 0.f) return VPS_EARG(1);
+    if (x_ld != 8 || out_ld != 12 || (((uintptr_t)x6 | (uintptr_t)out) & 15)) return VPS_EARG(2);
+    if (mode == 0) {
+        hipLaunchKernelGGL(flow_stage_s_kernel, dim3(stream_grid((long)H * W, 256)), dim3(256), 0, (hipStream_t)stream,
+                           x6, flow_a, a_ld, a_coff, H, W, mul, out);
+    } else if (mode == 1) {
+        if (!flow_b) return VPS_EARG(3);
+        hipLaunchKernelGGL(flow_stage_f_kernel, dim3(stream_grid((long)H * W, 256)), dim3(256), 0, (hipStream_t)stream,
+                           x6, flow_a, a_ld, a_coff, flow_b, b_ld, b_coff, H, W, mul, out);
+    } else {
+        return VPS_EARG(4);
+    }
+    return vps_launch_status();
 }
 
 extern "C" int vps_flow_stage(const float* x6, int x_ld, const float* flow_lo, int flo_ld, int flo_coff,

@@ -269,27 +269,22 @@ class FlowNet2(HipModule):
                                         hip.ptr(partial), self._nblk, hip.ptr(rgb_mean), sp()), 'vps_flow_prep_pad')
         D = self.div_flow
 
-        def stage(flow_lo, out, up_mode, mul, div_mode, flow_off, flow_out_div, warp_off, diffnorm_off, flownorm_off, img_off):
-            hip.check(lib.vps_flow_stage(x6.ptr(), x6.ld, flow_lo.ptr(), flow_lo.ld, flow_lo.coff, H, W, up_mode, mul, div_mode,
-                                         out.ptr(), out.ld, flow_off, flow_out_div, warp_off, diffnorm_off, flownorm_off, img_off,
-                                         sp()), 'vps_flow_stage')
+        def full(mode, flow_a, flow_b, out):
+            fb = flow_a if flow_b is None else flow_b
+            hip.check(lib.vps_flow_stage_full(x6.ptr(), x6.ld, flow_a.ptr(), flow_a.ld, flow_a.coff, fb.ptr(), fb.ld, fb.coff, H, W, mode, D,
+                                              out.ptr(), out.ld, sp()), 'vps_flow_stage_full')
 
-        def copy6(dst):
-            hip.check(lib.vps_axpb(x6.ptr(), x6.ld, 0, dst.ptr(), dst.ld, 0, x6.npix, 6, 1.0, 0.0, sp()), 'axpb')
-
+        # whole 12-float pixels per thread (vps_flow_stage_full); the channel-wise vps_flow_stage + vps_axpb pair is the general form
         c_flow2 = self.flownetc.run(x6, ws, tag + 'C.')
         concat1 = ws.fmap(tag + 'concat1', 1, H, W, 12)
-        copy6(concat1)
-        stage(c_flow2, concat1, 0, D, 0, 9, D, 6, 11, -1, -1)          # flownet2.py:142-151
+        full(0, c_flow2, None, concat1)                                # flownet2.py:142-151
         s1_flow2 = self.flownets_1.run(concat1, ws, tag + 'S1.')
         concat2 = ws.fmap(tag + 'concat2', 1, H, W, 12)
-        copy6(concat2)
-        stage(s1_flow2, concat2, 0, D, 0, 9, D, 6, 11, -1, -1)         # :154-163
+        full(0, s1_flow2, None, concat2)                               # :154-163
         s2_flow2 = self.flownets_2.run(concat2, ws, tag + 'S2.')
         sd_flow2 = self.flownets_d.run(x6, ws, tag + 'SD.')
         concat3 = ws.fmap(tag + 'concat3', 1, H, W, 11)
-        stage(s2_flow2, concat3, 1, D, 0, 5, 0.0, -1, 10, 8, 0)        # :166-174 nearest x4 of flow*20
-        stage(sd_flow2, concat3, 1, D, 1, 3, 0.0, -1, 9, 7, -1)        # :179-187 nearest x4 of flow/20 (sic)
+        full(1, s2_flow2, sd_flow2, concat3)                           # :166-187 nearest x4 of flow*20 resp. flow/20 (sic)
         flow = self.flownetfusion.run(concat3, ws, tag + 'F.')
         if (H, W) != (H0, W0):
             # ... and trims afterwards (:135-138, index_select of the first H0 rows / W0 columns)

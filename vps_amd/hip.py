@@ -23,7 +23,7 @@ PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
 SYMBOLS = [
     'vps_abi_version', 'vps_build_info', 'vps_conv2d', 'vps_resample2d', 'vps_channelnorm', 'vps_correlation',
     'vps_flow_warp', 'vps_nchw_to_nhwc', 'vps_nhwc_to_nchw', 'vps_resize', 'vps_pool3x3s2', 'vps_bfp_gather',
-    'vps_bfp_scatter', 'vps_axpb', 'vps_flow_prep', 'vps_flow_prep_pad', 'vps_flow_stage', 'vps_groupnorm_relu', 'vps_groupnorm_apply', 'vps_tcea_temporal',
+    'vps_bfp_scatter', 'vps_axpb', 'vps_flow_prep', 'vps_flow_prep_pad', 'vps_flow_stage', 'vps_flow_stage_full', 'vps_groupnorm_relu', 'vps_groupnorm_apply', 'vps_tcea_temporal',
     'vps_tcea_modulate', 'vps_roi_align', 'vps_nms_batched', 'vps_delta2bbox', 'vps_bbox_overlaps',
     'vps_row_softmax', 'vps_mask_count', 'vps_mask_commit', 'vps_mask_removal', 'vps_mask_level', 'vps_panoptic_combine',
     'vps_unify_hist', 'vps_unify_tables', 'vps_unify_write', 'vps_image_prep', 'vps_resize_u8', 'vps_segment_stats', 'vps_segment_paint', 'vps_pair_count',
@@ -108,6 +108,8 @@ def load():
                                       c_int, c_void_p, c_void_p]
     lib.vps_flow_stage.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
                                    c_void_p, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_void_p]
+    lib.vps_flow_stage_full.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                        c_void_p, c_int, c_void_p]
     lib.vps_groupnorm_relu.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_void_p,
                                        c_float, c_int, c_void_p, c_void_p]
     lib.vps_groupnorm_apply.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_void_p,
