@@ -125,12 +125,32 @@ def hbm_kernels(dev):
     h8, w8 = H // 8, W // 8
     a8 = fm('a8', h8, w8, 256); b8 = fm('b8', h8, w8, 256); c441 = ws.fmap('c441', 1, h8, w8, 441)
     add('correlation_flownetc_441ch', 4.0 * h8 * w8 * (512 + 441), lambda: nhwc.correlation(a8, b8, c441, 20, 2), '2x256ch -> 441ch @%dx%d' % (h8, w8))
-    # FlowNet2 stage kernel (upsample x4 + resample2d + 2x channelnorm + concat, flownet2.py:142-187): ~8 ch read + <=7 ch written @full res
+    # FlowNet2 stage kernel (upsample x4 + resample2d + 2x channelnorm + concat, flownet2.py:142-187), whole-pixel form: the 8-float
+    # image pixel + the quarter-resolution flow read, the 12-float pixel of the next network's input written @full res
     lib = hip.load()
     x6 = fm('x6', H, W, 6, 8); flo = fm('flo', h4, w4, 2, 4, 0.2); cc = ws.fmap('cc', 1, H, W, 12)
-    add('flow_stage', 4.0 * (H * W * (6 + 6) + h4 * w4 * 2), lambda: hip.check(lib.vps_flow_stage(
-        x6.ptr(), x6.ld, flo.ptr(), flo.ld, flo.coff, H, W, 0, 20.0, 0, cc.ptr(), cc.ld, 9, 20.0, 6, 11, -1, -1, hip.stream_ptr()), 'stage'),
-        'x6 + flow/4 -> 6 of 12 concat channels @%dx%d' % (H, W))
+    add('flow_stage', 4.0 * (H * W * (8 + 12) + h4 * w4 * 2), lambda: hip.check(lib.vps_flow_stage_full(
+        x6.ptr(), x6.ld, flo.ptr(), flo.ld, flo.coff, flo.ptr(), flo.ld, flo.coff, H, W, 0, 20.0, cc.ptr(), cc.ld, hip.stream_ptr()), 'stage'),
+        'x6 + flow/4 -> 12-channel FlowNetS input @%dx%d' % (H, W))
+    # panoptic combine (panoptic_fusetrack.py:588-597): 20-channel quarter-resolution logits + 45 instances (28x28 mask logits) -> two uint8 maps
+    from vps_amd import hip as _h
+    k = 45
+    sc = fm('sc', h4, w4, 19, 20)
+    inst = (_h.PanInst * k)()
+    rgi = np.random.default_rng(1)
+    for j in range(k):
+        bw, bh = int(rgi.integers(40, 400)), int(rgi.integers(40, 300))
+        x1, y1 = int(rgi.integers(0, W - bw)), int(rgi.integers(0, H - bh))
+        inst[j].sx0, inst[j].sy0, inst[j].sx1, inst[j].sy1 = x1, y1, x1 + bw + 1, y1 + bh + 1
+        inst[j].seg_ch = 11 + j % 8
+        inst[j].bx1, inst[j].by1, inst[j].bx2, inst[j].by2 = x1, y1, x1 + bw, y1 + bh
+        inst[j].mask_idx = j
+    inst_dev = torch.frombuffer(bytearray(bytes(inst)), dtype=torch.uint8).to(dev)
+    ml = torch.randn(k, 28, 28, device=dev)
+    pan = torch.empty(H, W, dtype=torch.uint8, device=dev); sem = torch.empty(H, W, dtype=torch.uint8, device=dev)
+    add('panoptic_combine', 4.0 * h4 * w4 * 20 + 4.0 * k * 28 * 28 + 2.0 * H * W, lambda: hip.check(lib.vps_panoptic_combine(
+        sc.ptr(), sc.ld, h4, w4, 19, 11, hip.ptr(inst_dev), k, hip.ptr(ml), 28, hip.ptr(pan), hip.ptr(sem), H, W, hip.stream_ptr()), 'combine'),
+        '19 classes @%dx%d + %d instances -> 2 x uint8 @%dx%d' % (h4, w4, k, H, W))
     # RoIAlign 1000 x 7x7 x 256 over P2..P5 (output-bound)
     lv = [fm('l%d' % s, H // s, W // s, 256) for s in (4, 8, 16, 32)]
     rg = np.random.default_rng(0)
