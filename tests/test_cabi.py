@@ -36,25 +36,24 @@ def test_abi_version_and_info():
 
 
 def test_struct_layout_matches_c(tmp_path):
-    """compile a tiny C program against the header and compare sizeof/offsetof with the ctypes mirrors"""
+    """compile a tiny C program against the header and compare sizeof / offsetof of EVERY field with the ctypes mirrors"""
+    cname = {'inp': 'in'}                                    # `in` is a Python keyword: the ctypes mirror calls it `inp`
+    structs = (('vps_conv_desc', hip.ConvDesc), ('vps_tensor4', hip.Tensor4), ('vps_pan_inst', hip.PanInst))
+    lines = []
+    for cn, ct in structs:
+        lines.append('printf("%%zu\\n", sizeof(%s));' % cn)
+        lines += ['printf("%%zu\\n", offsetof(%s, %s));' % (cn, cname.get(f[0], f[0])) for f in ct._fields_]
     src = tmp_path / 'layout.c'
-    src.write_text('''
-#include <stdio.h>
-#include <stddef.h>
-#include "vps_hip.h"
-int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(vps_conv_desc), offsetof(vps_conv_desc, w), offsetof(vps_conv_desc, out),
-         offsetof(vps_conv_desc, scale), offsetof(vps_conv_desc, offset), offsetof(vps_conv_desc, ws), offsetof(vps_conv_desc, tile_n));
-  printf("%zu %zu\\n", sizeof(vps_tensor4), sizeof(vps_pan_inst));
-  return 0; }
-''')
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vps_hip.h"\nint main(void) {\n%s\nreturn 0; }\n' % '\n'.join(lines))
     exe = tmp_path / 'layout'
     subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
-    out = subprocess.check_output([str(exe)]).decode().split()
-    D = hip.ConvDesc
-    want = [ctypes.sizeof(D), D.w.offset, D.out.offset, D.scale.offset, D.offset.offset, D.ws.offset, D.tile_n.offset,
-            ctypes.sizeof(hip.Tensor4), ctypes.sizeof(hip.PanInst)]
-    assert [int(v) for v in out] == want
+    out = [int(v) for v in subprocess.check_output([str(exe)]).decode().split()]
+    want = []
+    for cn, ct in structs:
+        want.append(ctypes.sizeof(ct))
+        want += [getattr(ct, f[0]).offset for f in ct._fields_]
+    assert out == want
+    assert {'gn_stats', 'gn_cpg', 'gn_rep', 'status', 'w_split'} <= {f[0] for f in hip.ConvDesc._fields_}
 
 
 def test_cpu_tensor_is_rejected_loudly():

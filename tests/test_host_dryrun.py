@@ -90,3 +90,45 @@ def test_host_control_flow_with_stubbed_launches(monkeypatch, variant, keys):
     undeclared = sorted(n for n in lib.called if n not in hip.SYMBOLS)
     assert not undeclared, undeclared
     assert 'vps_conv2d' in lib.called and ('vps_correlation' in lib.called) == (variant != 'track')
+
+
+@pytest.mark.parametrize('prec,expect_fused', [('f16x3', True), ('f32', False)])
+def test_semantic_head_hands_groupnorm_sums_to_the_unsplit_deformable_layers(monkeypatch, prec, expect_fused):
+    """Host logic of upsnetFPN.py:39-81 on this package (kernel launches recorded, not executed): a deformable conv that is not
+    split over K carries vps_conv_desc.gn_stats / gn_cpg / gn_rep (its own zeroed slot) and is followed by vps_groupnorm_apply on
+    that slot; a split one (small levels) carries none and is followed by the two-pass vps_groupnorm_relu; the exact-fp32 mode never
+    asks for the sums (its deformable kernel has no such epilogue)."""
+    from vps_amd import nhwc
+    lib = _RecordingLib()
+    log = []
+    monkeypatch.setattr(hip, 'load', lambda: lib)
+    monkeypatch.setattr(hip, 'ptr', lambda t: None if t is None else ctypes.c_void_p(t.data_ptr()))
+    monkeypatch.setattr(hip, 'stream_ptr', lambda: None)
+    monkeypatch.setattr(hip, 'conv2d', lambda d: log.append(('conv', bool(d.offset), d.ksplit, d.gn_stats, d.gn_cpg, d.gn_rep, d.cout)))
+    monkeypatch.setattr(_RecordingLib, '_vps_groupnorm_apply', lambda self, *a: log.append(('apply', a[-3].value, a[-2])) or 0, raising=False)
+    monkeypatch.setattr(_RecordingLib, '_vps_groupnorm_relu', lambda self, *a: log.append(('relu', a[-2].value)) or 0, raising=False)
+    monkeypatch.setattr(nhwc, 'DEFAULT_PREC', nhwc.PREC_NAMES[prec])
+    monkeypatch.setattr(nhwc, 'f16_status', lambda device: torch.zeros(1, dtype=torch.int32))
+    cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', 'fusetrack.py'))
+    head = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg).panopticFPN
+    ws = nhwc.Workspace(torch.device('cpu'))
+    levels = [nhwc.FMap(torch.zeros(1, 128 >> l, 256 >> l, 256)) for l in range(4)]       # P2 128x256 (256 tiles x 2: unsplit) ... P5 16x32
+    head.run(levels, ws)
+    dcn = [(i, e) for i, e in enumerate(log) if e[0] == 'conv' and e[1]]
+    assert len(dcn) == 12
+    slots = set()
+    for i, (_, _, ksplit, gn_stats, gn_cpg, gn_rep, cout) in dcn:
+        nxt = log[i + 1]
+        if expect_fused and ksplit == 1:
+            assert gn_stats and gn_cpg == cout // 32 and gn_rep == nhwc.GN_REP
+            assert nxt[0] == 'apply' and nxt[1] == gn_stats and nxt[2] == nhwc.GN_REP
+            slots.add(gn_stats)
+        else:
+            assert not gn_stats and nxt[0] == 'relu'
+    unsplit = sum(1 for _, e in dcn if e[2] == 1)
+    assert unsplit >= 3                                              # at least the three layers of the P2 tower
+    assert len(slots) == (unsplit if expect_fused else 0)            # one slot per layer, never shared
+    if expect_fused:
+        stats = ws.bufs['sem.gnstats']
+        assert stats.dtype == torch.float64 and tuple(stats.shape) == (12, nhwc.GN_REP, 64)
+        assert all(stats.data_ptr() <= s < stats.data_ptr() + stats.numel() * 8 and (s - stats.data_ptr()) % (nhwc.GN_REP * 64 * 8) == 0 for s in slots)
