@@ -66,3 +66,16 @@ def test_bad_arguments_return_error_codes_without_a_gpu():
     d = hip.ConvDesc()
     assert lib.vps_conv2d(ctypes.byref(d), None) <= -1000      # null pointers are rejected before any launch
     assert lib.vps_conv2d(None, None) <= -1000
+
+
+def test_library_isa_is_free_of_the_packed_fp32_form_that_fails_beside_mfma_kernels():
+    """tools/check_isa.py on the built library: no v_pk_{mul,add,fma}_f32 with op_sel = 1 on its second source (wrong results
+    beside MFMA kernels on gfx950: tools/pkhazard); the Makefile builds without packed FP32 at all"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('check_isa', os.path.join(ROOT, 'tools', 'check_isa.py'))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    if not os.path.exists(mod.OBJDUMP):
+        pytest.skip('llvm-objdump not available')
+    nobj, npk, bad = mod.scan(hip.LIB_PATH)
+    assert nobj >= 1 and not bad, bad[:5]
+    assert npk == 0, 'packed FP32 was re-enabled: keep the lint above green and re-validate the stream-invariance tests'
