@@ -64,6 +64,10 @@ CONV_CASES = [
     # enough 256-row tiles to fill the chip, 128-column tile: the 8-wave halo kernel (weights through LDS) in f16x3 / bf16x3
     (64, 128, 3, 1, 1, 256, 512, 'relu', True, True),   # 8x32 patches, residual + BN epilogue
     (82, 256, 3, 1, 1, 250, 500, 'leaky', False, False),  # overhanging patches (250 % 8, 500 % 32), ragged channel chunk, 2 column tiles
+    # stride-2 layers with >= 256 tiles of 8x32 outputs (FlowNet conv2 / conv3, ResNet stage entries): the pipelined kernel; with
+    # VPS_S2_HALO=1 in the environment the experimental phase-split 8-wave halo kernel (f16x3 / bf16x3)
+    (64, 128, 5, 2, 2, 512, 512, 'leaky', False, False),
+    (128, 256, 3, 2, 1, 500, 516, 'relu', True, True),   # overhanging patches, two column tiles, residual + BN epilogue
 ]
 
 

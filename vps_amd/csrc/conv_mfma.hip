@@ -24,6 +24,7 @@
 //     the epilogue.
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1425,6 +1426,234 @@ void conv_mfma_h8_kernel(const vps_conv_desc d, const int tiles_m, const int til
 }
 
 // ================================================================================================
+// Stride-2 K x K layers (K = 3, 5) on the 8-wave halo structure ("h8s2"), phase-split staging. EXPERIMENTAL: dispatched only when
+// the environment variable VPS_S2_HALO is set (launch_conv); not part of the measured configuration of round 2.
+// A stride-2 conv is four stride-1 convs on the (row, column)-parity sub-images of the input: tap (ky, kx) = (2j + a, 2i + b) of
+// output pixel (oy, ox) reads sub-image (a, b) at (oy + j, ox + i) (origin shifted by the padding). One stage of the k loop =
+// (32-channel chunk, phase (a, b)): the 8 x 32 output patch's sub-image patch ((8 + J_a - 1) x (32 + I_b - 1) pixels, J_0 = I_0 =
+// ceil(K/2), J_1 = I_1 = floor(K/2)) is staged ONCE in LDS like the stride-1 halo tile, then the J_a x I_b taps of the phase read
+// their activation fragments from it at the row offset j * HW + i. 5x5: 9 + 6 + 6 + 4 taps on <= 340 staged rows each (54 rows
+// per tap; the pipelined kernel stages 256 rows per tap and re-fetches every input element 6.25 times); 3x3: 4 + 2 + 2 + 1.
+// Everything else - weights through LDS per tap, fragment layouts, interleaving, epilogue - is conv_mfma_h8_kernel's.
+// ================================================================================================
+struct S2Tap { int ph, j, i, idx, t, nt; };    // phase, tap (j, i) inside it, k index ky*K + kx, position t of nt taps of the phase
+constexpr int s2_taps_1d(int K, int a) { return (K - a + 1) / 2; }
+constexpr S2Tap s2_tap(int K, int ts) {
+    int base = 0;
+    for (int ph = 0; ph < 4; ++ph) {
+        const int a = ph >> 1, b = ph & 1, J = s2_taps_1d(K, a), I = s2_taps_1d(K, b);
+        if (ts < base + J * I) {
+            const int t = ts - base, j = t / I, i = t - j * I;
+            return S2Tap{ph, j, i, (2 * j + a) * K + 2 * i + b, t, J * I};
+        }
+        base += J * I;
+    }
+    return S2Tap{0, 0, 0, 0, 0, 1};
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+template <int MODE, int K>
+__global__ __launch_bounds__(512, 2)
+void conv_mfma_h8s2_kernel(const vps_conv_desc d, const int tiles_m, const int tiles_n, const int chunks_per_split) {
+    constexpr int TM = 2, TN = 2, WAVES_N = 2, BN = 128;
+    constexpr int NTAP = K * K;
+    constexpr int J0 = s2_taps_1d(K, 0);                // taps per axis of the even phase (the larger one)
+    constexpr int HW = 32 + J0 - 1, HH = 8 + J0 - 1;    // sub-image patch of an 8 x 32 output patch: 10 x 34 (K = 5), 9 x 33 (K = 3)
+    constexpr int HROWS = HH * HW;
+    constexpr int NLD = (HROWS + 63) / 64;
+    typedef Split<MODE> SM;
+    typedef typename SM::elem elem_t;
+    typedef vec8<elem_t> x8;
+    typedef vec4<elem_t> x4;
+    constexpr int NSA = SM::NSA, NSB = SM::NSB;
+    constexpr int PLANE = NLD * 64 * LDS_LDH;
+    constexpr int ABUF = NSA * PLANE;
+    constexpr int NFRAG = NSB * 2 * (BN / 32);
+    constexpr int BBUF = NFRAG * 512;
+    static_assert((NFRAG * 64) % 512 == 0, "whole 16-byte chunks per thread");
+    constexpr int NBL = NFRAG * 64 / 512;
+    static_assert(2 * (ABUF + BBUF) * 2 <= 160 * 1024, "LDS budget of the CU");
+
+    __shared__ __attribute__((aligned(16))) elem_t As[2 * ABUF];
+    __shared__ __attribute__((aligned(16))) elem_t Bs[2 * BBUF];
+
+    const int t = threadIdx.x;
+    const int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+    int tile_n, tile_m, cls, split;
+    decode_tile(d, swz, tiles_n, tiles_m, tile_n, tile_m, cls, split);
+
+    const int H = d.H, W = d.W, cin_pad = d.cin_pad;
+    const int tiles_x = (d.Qw + 31) >> 5, tiles_y = (d.Qh + 7) >> 3;
+    const int tx = tile_m % tiles_x, tq = tile_m / tiles_x;
+    const int ty = tq % tiles_y, n = tq / tiles_y;
+    const int iy_org = ty * 16 - d.pad_y[0], ix_org = tx * 64 - d.pad_x[0];   // input position of tap (0, 0) of the patch's first output
+
+    const int k4 = t & 7;
+    const int r0 = t >> 3;
+    const int chunk0 = split * chunks_per_split;
+    const int nchunks = min(chunks_per_split, d.kpad / (BK * NTAP) - chunk0);
+
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+    const int nbt = d.cout_pad >> 5, kst = d.kpad >> 4;
+    const size_t wplane = (size_t)nbt * kst * 512;
+    const elem_t* __restrict__ wblk = reinterpret_cast<const elem_t*>(d.w_split) +
+        ((size_t)(tile_n * (BN / 32)) * kst + 2 * (size_t)chunk0 * NTAP) * 512;
+
+    f32x4 areg[NLD];
+    unsigned aok = 0;
+    int achunk = chunk0, aph = 0;      // next (chunk, phase) stage to load
+    x8 breg[NBL];
+    float amax = 0.f;
+
+    // sub-image patch of the next stage -> registers (sequential: every call advances (chunk, phase))
+    auto load_A = [&]() {
+        const int a = aph >> 1, b = aph & 1;
+        const int rows = 8 + ((K - a + 1) >> 1) - 1, cols = 32 + ((K - b + 1) >> 1) - 1;
+        const int cic = achunk * BK + k4 * 4;
+        const bool kv = cic < cin_pad;
+        if (++aph == 4) { aph = 0; ++achunk; }
+        aok = 0;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int hp = r0 + 64 * i;
+            const int hy = hp / HW, hx = hp - hy * HW;
+            const int iy = iy_org + a + 2 * hy, ix = ix_org + b + 2 * hx;
+            const bool ok = kv && hy < rows && hx < cols && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const int pix = ok ? (n * H + iy) * W + ix : 0;
+            areg[i] = *reinterpret_cast<const f32x4*>(d.in + ((size_t)pix * d.in_ld + d.in_coff + (ok ? cic : 0)));
+            aok |= (ok ? 1u : 0u) << i;
+        }
+    };
+    auto store_A = [&](int i, int buf) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        x4 sp[NSA];
+        split_act<MODE>(((aok >> i) & 1u) ? areg[i] : z, sp, amax);
+        const int row = r0 + 64 * i;
+#pragma unroll
+        for (int p = 0; p < NSA; ++p)
+            *reinterpret_cast<x4*>(&As[buf * ABUF + p * PLANE + row * LDS_LDH + (((k4 >> 1) ^ lds_swz(row)) << 3) + ((k4 & 1) << 2)]) = sp[p];
+    };
+    // wstep = k-step pair index relative to this split: (chunk - chunk0) * NTAP + ky * K + kx
+    auto load_B = [&](int wstep) {
+#pragma unroll
+        for (int j = 0; j < NBL; ++j) {
+            const int c = t + 512 * j;
+            const int f = c >> 6, bcol = f % (BN / 32), pm = f / (BN / 32);
+            breg[j] = *reinterpret_cast<const x8*>(wblk + (size_t)(pm >> 1) * wplane + ((size_t)bcol * kst + 2 * wstep + (pm & 1)) * 512 + (c & 63) * 8);
+        }
+    };
+    auto store_B = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NBL; ++j) *reinterpret_cast<x8*>(&Bs[buf * BBUF + (t + 512 * j) * 8]) = breg[j];
+    };
+
+    int hbase[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) hbase[a] = (wm * TM + a) * HW + (lane & 31);
+    x8 af[2][NSA][TM];
+    auto read_A = [&](int m, int buf, int toff) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int hrow = hbase[a] + toff;
+            const int off = buf * ABUF + hrow * LDS_LDH + (((2 * m + (lane >> 5)) ^ lds_swz(hrow)) << 3);
+#pragma unroll
+            for (int p = 0; p < NSA; ++p) af[m][p][a] = *reinterpret_cast<const x8*>(&As[off + p * PLANE]);
+        }
+    };
+    x8 bcur[2][NSB][TN];
+    auto read_B = [&](int m, int buf) {
+#pragma unroll
+        for (int p = 0; p < NSB; ++p)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+                bcur[m][p][b] = *reinterpret_cast<const x8*>(&Bs[buf * BBUF + (((p * 2 + m) * (BN / 32)) + wn * TN + b) * 512 + lane * 8]);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // prologue: stage (chunk 0, phase 0) in activation buffer 0, stage (chunk 0, phase 1) in flight in registers, weights of the
+    // first tap in weight buffer 0
+    load_A();
+    load_B(s2_tap(K, 0).idx);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) store_A(i, 0);
+    store_B(0);
+    load_A();
+    __syncthreads();
+
+    constexpr int NT = SM::NT;
+    constexpr int NMF = 2 * NT * TM * TN;                       // MFMAs per wave and tap
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        static_for<NTAP>([&](auto ts_tag) {
+            constexpr int TS = decltype(ts_tag)::value;         // position of the tap in the chunk's phase-major tap sequence
+            constexpr S2Tap tp = s2_tap(K, TS);
+            constexpr S2Tap nx = s2_tap(K, (TS + 1) % NTAP);
+            constexpr int cur = tp.ph & 1;                      // four stages per chunk: the activation buffer is the phase's parity
+            constexpr bool last_of_phase = tp.t == tp.nt - 1;
+            constexpr int SPT = (NLD + tp.nt - 1) / tp.nt;      // rows of the next stage staged per tap of this phase
+            constexpr int NW = 3 + SPT + (last_of_phase ? 1 : 0);   // weight loads | slab-1 fragment reads | SPT stagings | [next loads] | weight stores
+            const int step = chunk * NTAP + TS;
+            const int bb = step & 1;                            // weight buffer of this tap
+            const int wnext = (TS + 1 < NTAP ? chunk : min(chunk + 1, nchunks - 1)) * NTAP + nx.idx;   // clamped: the last prefetch is unused
+            constexpr int toff = tp.j * HW + tp.i;
+            read_A(0, cur, toff);
+            read_B(0, bb);
+            __builtin_amdgcn_sched_barrier(0);
+
+            auto work = [&](const int w) {
+                if (w == 0) load_B(wnext);
+                else if (w == 1) { read_A(1, cur, toff); read_B(1, bb); }
+                else if (w < SPT + 2) {
+                    const int row = tp.t * SPT + (w - 2);
+                    if (row < NLD) store_A(row, cur ^ 1);
+                } else if (last_of_phase && w == SPT + 2) load_A();          // the stage after next, into the registers just staged
+                else store_B(bb ^ 1);
+            };
+
+            int mf = 0;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < NT; ++q)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) {
+                            acc[a][b] = split_mfma<MODE>(bcur[m][SM::PB[q]][b], af[m][SM::PA[q]][a], acc[a][b]);
+                            ++mf;
+#pragma unroll
+                            for (int w = 0; w < NW; ++w) {
+                                const int pos = ((w + 1) * NMF) / (NW + 1);
+                                if (mf == (pos < 1 ? 1 : pos)) {
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    work(w);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            }
+                        }
+            __syncthreads();
+        });
+    }
+    report_range<MODE>(d, amax);
+    conv_epilogue<TM, TN, BN, true, 5>(d, acc, tiles_m * 256, tile_m, tile_n, cls, split, 0, 0, wm, wn, lane);
+}
+
+// ================================================================================================
 // Narrow-output convolution (cout <= 4: the FlowNet predict_flow / upsampled_flow layers, 2 channels). A 32-column MFMA
 // tile would waste 94 % of the matrix pipe and still stage the whole activation tile through LDS; these layers are
 // pure activation streaming, so they run on the vector ALU in exact fp32: G lanes (G = pow2 >= cin_pad/4, <= 64) share
@@ -1703,7 +1932,22 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
     const long tiles2d8 = (long)d.N * ((d.Qh + 7) / 8) * ((d.Qw + 31) / 32);
     const bool h8 = halo && BN == 128 && (d.prec == VPS_PREC_F16X3 || d.prec == VPS_PREC_BF16X3 || d.prec == VPS_PREC_BF16) &&
                     tiles2d8 * 256 * 2 <= (long)M * 3 && tiles2d8 * tiles_n * d.nclass * d.ksplit >= 256;
-    if (h8) {
+    // EXPERIMENTAL (VPS_S2_HALO=1): stride-2 3x3 / 5x5 layers on the phase-split 8-wave halo kernel
+    static const bool s2_enabled = getenv("VPS_S2_HALO") != nullptr;
+    const bool h8s2 = s2_enabled && BN == 128 && (d.prec == VPS_PREC_F16X3 || d.prec == VPS_PREC_BF16X3 || d.prec == VPS_PREC_BF16) && !d.offset &&
+                      d.stride == 2 && d.nclass == 1 && d.korder == 1 && d.KH == d.KW && (d.KH == 3 || d.KH == 5) &&
+                      d.pad_y[0] == d.KH / 2 && d.pad_x[0] == d.KW / 2 && tiles2d8 * 256 * 2 <= (long)M * 3 &&
+                      tiles2d8 * tiles_n * d.ksplit >= 256 && (d.ksplit == 1 || (ksteps % d.ksplit == 0 && per_split % ntap == 0));
+    if (h8s2) {
+        const int tiles_m8 = (int)tiles2d8;
+        const long nblk8 = (long)tiles_m8 * tiles_n * d.ksplit;
+#define VPS_H8S2_LAUNCH(MODE, K)                                                                                                 \
+    hipLaunchKernelGGL((conv_mfma_h8s2_kernel<MODE, K>), dim3((unsigned)nblk8), dim3(512), 0, s, d, tiles_m8, tiles_n, per_split / ntap)
+        if (d.prec == VPS_PREC_BF16) { if (d.KH == 3) VPS_H8S2_LAUNCH(VPS_PREC_BF16, 3); else VPS_H8S2_LAUNCH(VPS_PREC_BF16, 5); }
+        else if (d.prec == VPS_PREC_BF16X3) { if (d.KH == 3) VPS_H8S2_LAUNCH(VPS_PREC_BF16X3, 3); else VPS_H8S2_LAUNCH(VPS_PREC_BF16X3, 5); }
+        else { if (d.KH == 3) VPS_H8S2_LAUNCH(VPS_PREC_F16X3, 3); else VPS_H8S2_LAUNCH(VPS_PREC_F16X3, 5); }
+#undef VPS_H8S2_LAUNCH
+    } else if (h8) {
         const int tiles_m8 = (int)tiles2d8;
         const long nblk8 = (long)tiles_m8 * tiles_n * d.nclass * d.ksplit;
 #define VPS_H8_LAUNCH(MODE, K)                                                                                                   \
