@@ -5,6 +5,7 @@ container, with the import shims of ref_shims.py (third-party stubs + oracle-bac
     python tests/golden/make_golden.py [fusetrack|fuse|track]   # needs /root/reference; writes tests/golden/<variant>_clip.npz
     python tests/golden/make_golden.py fullsize                  # 2 frames at 1024x2048 -> tests/golden/fusetrack_fullsize.npz
     python tests/golden/make_golden.py r101                      # ResNet-101 variant (BASELINE config 5), 2 frames at 128x256
+    python tests/golden/make_golden.py seed1                     # FuseTrack, weight / clip seed 1, 3 frames at 128x192
 
 The reference cannot travel to the GPU box; the vectors do. tests/test_oracle_golden.py checks the oracle against them
 (CPU), tests/test_fusetrack_gpu.py checks the HIP path against the oracle and against these vectors (GPU).
@@ -28,7 +29,7 @@ H, W, NFRAMES, SEED = 128, 256, 3, 0
 FULL_H, FULL_W, FULL_NFRAMES = 1024, 2048, 2          # `fullsize`: the BASELINE frame size (configs[1]), FuseTrack only
 
 
-def main(variant='fusetrack', H=H, W=W, NFRAMES=NFRAMES, out_name=None, full=False, depth=None):
+def main(variant='fusetrack', H=H, W=W, NFRAMES=NFRAMES, out_name=None, full=False, depth=None, seed=SEED):
     """full=True: the 1024x2048 golden — same quantities, the dense stage tensors strided so the file stays a few MB"""
     import ref_shims
     mods = ref_shims.install()
@@ -43,7 +44,7 @@ def main(variant='fusetrack', H=H, W=W, NFRAMES=NFRAMES, out_name=None, full=Fal
     # --- shapes of every parameter, from OUR containers; the reference model must expose exactly the same keys ---
     ours = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
     shapes = {k: tuple(v.shape) for k, v in ours.state_dict().items()}
-    sd = synth.synth_state_dict(shapes, SEED)
+    sd = synth.synth_state_dict(shapes, seed)
 
     # --- the reference detector; its __init__ loads FlowNet2 from cwd/work_dirs/flownet/FlowNet2_checkpoint.pth.tar ---
     tmp = tempfile.mkdtemp(prefix='vps_golden_')
@@ -94,7 +95,7 @@ def main(variant='fusetrack', H=H, W=W, NFRAMES=NFRAMES, out_name=None, full=Fal
         return r
     ref.simple_test_rpn = rpn_wrap
 
-    frames = synth.synth_clip(H, W, NFRAMES, SEED)
+    frames = synth.synth_clip(H, W, NFRAMES, seed)
     out = {}
     with torch.no_grad():
         for t in range(NFRAMES):
@@ -132,7 +133,7 @@ def main(variant='fusetrack', H=H, W=W, NFRAMES=NFRAMES, out_name=None, full=Fal
             out[p + 'mask_pred'] = cap['mask_head'][0][:8].numpy()          # first 8 detections
             print('%s frame %d: K=%d kept=%d ids=%s' % (variant, t, cap['mask_head'][0].shape[0], len(out[p + 'panoptic_cls_inds']),
                                                        out[p + 'panoptic_det_obj_ids'][:8] if has_track else None))
-    out['meta'] = np.array([H, W, NFRAMES, SEED], dtype=np.int64)
+    out['meta'] = np.array([H, W, NFRAMES, seed], dtype=np.int64)
     out['strides'] = np.array([s1, s2, c5 or 0], dtype=np.int64)
     out['state_dict_manifest'] = np.frombuffer(manifest.encode(), dtype=np.uint8)
     path = os.path.join(HERE, out_name or '%s_clip.npz' % variant)
@@ -146,5 +147,7 @@ if __name__ == '__main__':
         main('fusetrack', FULL_H, FULL_W, FULL_NFRAMES, 'fusetrack_fullsize.npz', full=True)
     elif v == 'r101':
         main('fusetrack', H, W, 2, 'fusetrack_r101_clip.npz', depth=101)
+    elif v == 'seed1':
+        main('fusetrack', 128, 192, 3, 'fusetrack_clip_seed1.npz', seed=1)      # second weight / clip seed, another aspect ratio
     else:
         main(v)
