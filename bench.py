@@ -404,6 +404,8 @@ def main():
             'roofline': roof, 'stage_ms': stages,
             'stage_ms_note': 'instrumented extra frame on ONE stream; the timed frames overlap FlowNet2 with backbone+FPN and the semantic head with the detection heads on two streams',
         }
+        if os.environ.get('VPS_S2_HALO'):
+            line['config']['experimental'] = 'VPS_S2_HALO: stride-2 3x3/5x5 layers on the phase-split 8-wave halo kernel (opt-in, not the validated configuration)'
         if clip30 is not None:
             line['clip30'] = clip30
         if other is not None:
