@@ -79,3 +79,21 @@ def test_library_isa_is_free_of_the_packed_fp32_form_that_fails_beside_mfma_kern
     nobj, npk, bad = mod.scan(hip.LIB_PATH)
     assert nobj >= 1 and not bad, bad[:5]
     assert npk == 0, 'packed FP32 was re-enabled: keep the lint above green and re-validate the stream-invariance tests'
+
+
+def test_kernel_resource_budget():
+    """code-object metadata of every kernel in the built library (tools/check_isa.py --resources): no VGPR spills anywhere, no
+    scratch memory in the MFMA conv kernels (a spilled accumulator would silently cost more than any tuning gains), LDS within the
+    160 KB of a CU, the 8-wave kernels within one block per CU's register file (<= 256 VGPRs at 2 waves per SIMD)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('check_isa', os.path.join(ROOT, 'tools', 'check_isa.py'))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    if not (os.path.exists(mod.OBJDUMP) and os.path.exists(mod.READELF)):
+        pytest.skip('llvm-objdump / llvm-readelf not available')
+    res = mod.resources(hip.LIB_PATH)
+    assert len(res) > 100 and any('conv_mfma_h8_kernel' in n for n in res), len(res)
+    for name, r in res.items():
+        assert r['vgpr_spill'] == 0, (name, r)
+        assert r['lds_bytes'] <= 160 * 1024 and r['vgpr'] <= 256 and r['agpr'] == 0, (name, r)
+        if 'conv_mfma' in name:
+            assert r['scratch_bytes'] == 0, (name, r)

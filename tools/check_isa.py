@@ -5,6 +5,7 @@ DESIGN.md 3.3). The Makefile builds without packed FP32 altogether; this check k
 re-enables packed FP32 prove that it is free of the failing form.
 
     python tools/check_isa.py [path/to/libvpship.so]      # exit code 1 + the offending lines when the form is present
+    python tools/check_isa.py --resources [lib]            # per-kernel registers / spills / scratch / LDS from the code-object notes
 """
 import glob
 import os
@@ -16,6 +17,8 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OBJDUMP = os.environ.get('LLVM_OBJDUMP', '/opt/rocm/lib/llvm/bin/llvm-objdump')
+READELF = os.environ.get('LLVM_READELF', '/opt/rocm/lib/llvm/bin/llvm-readelf')
+CXXFILT = os.environ.get('CXXFILT') or shutil.which('c++filt') or '/opt/rocm/lib/llvm/bin/llvm-cxxfilt'
 BAD = re.compile(r'v_pk_(mul|add|fma)_f32\b.*\bop_sel:\[[01],1')
 PK = re.compile(r'v_pk_[a-z]+_f32\b')
 
@@ -41,7 +44,53 @@ def scan(lib):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def resources(lib):
+    """-> {demangled kernel name: dict(vgpr, agpr, sgpr_spill, vgpr_spill, scratch_bytes, lds_bytes)} from the AMDGPU metadata notes"""
+    tmp = tempfile.mkdtemp(prefix='vps_isa_')
+    try:
+        so = os.path.join(tmp, 'lib.so')
+        shutil.copy(lib, so)
+        subprocess.run([OBJDUMP, '--offloading', so], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        out = {}
+        for o in sorted(glob.glob(so + '.*gfx950*')):
+            txt = subprocess.run([READELF, '--notes', o], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode(errors='replace')
+            cur = {}
+            for line in txt.splitlines():
+                m = re.match(r'\s*-?\s*\.(\w+):\s*(.*)$', line)
+                if not m:
+                    continue
+                k, v = m.group(1), m.group(2).strip()
+                if k == 'agpr_count' or (k == 'group_segment_fixed_size' and 'name' in cur):
+                    # a new kernel record starts (keys are emitted alphabetically: .agpr_count first, .args next ...)
+                    pass
+                if k == 'name' and not v.startswith("'") and ('kernel' in v or v.startswith('_Z')):
+                    cur['name'] = v
+                elif k in ('vgpr_count', 'agpr_count', 'sgpr_spill_count', 'vgpr_spill_count', 'private_segment_fixed_size', 'group_segment_fixed_size'):
+                    cur[k] = int(v)
+                if k == 'wavefront_size':                       # last key of a kernel record
+                    if 'name' in cur:
+                        out[cur['name']] = cur
+                    cur = {}
+        names = list(out)
+        if names and os.path.exists(CXXFILT):
+            dem = subprocess.run([CXXFILT], input='\n'.join(names).encode(), stdout=subprocess.PIPE, check=True).stdout.decode().splitlines()
+            out = {d: out[n] for d, n in zip(dem, names)}
+        return {n: dict(vgpr=r.get('vgpr_count', 0), agpr=r.get('agpr_count', 0), sgpr_spill=r.get('sgpr_spill_count', 0),
+                        vgpr_spill=r.get('vgpr_spill_count', 0), scratch_bytes=r.get('private_segment_fixed_size', 0),
+                        lds_bytes=r.get('group_segment_fixed_size', 0)) for n, r in out.items()}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == '--resources':
+        lib = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, 'vps_amd', 'csrc', 'libvpship.so')
+        res = resources(lib)
+        print('%-110s %5s %6s %6s %8s %8s' % ('kernel', 'VGPR', 'vspill', 'sspill', 'scratch', 'LDS'))
+        for n, r in sorted(res.items()):
+            short = re.sub(r'\(anonymous namespace\)::', '', n).split('(')[0]
+            print('%-110s %5d %6d %6d %8d %8d' % (short[:110], r['vgpr'], r['vgpr_spill'], r['sgpr_spill'], r['scratch_bytes'], r['lds_bytes']))
+        return 0
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'vps_amd', 'csrc', 'libvpship.so')
     nobj, npk, bad = scan(lib)
     print('%s: %d gfx950 code objects, %d packed-FP32 instructions, %d with op_sel = 1 on src1' % (lib, nobj, npk, len(bad)))
