@@ -51,7 +51,7 @@ enum { VPS_ACT_NONE = 0, VPS_ACT_RELU = 1, VPS_ACT_LEAKY = 2 };
  *   VPS_PREC_BF16X6 3 bf16 terms, 6 bf16 MFMAs per product (~2^-23 relative, fp32-grade), needs `w_split`
  *   VPS_PREC_F16X3  fp32 operands split into 2 fp16 terms with a scaled residual, 3 fp16 MFMAs per product, needs `w_split`:
  *                     x = h0 + 2^-11*h1,  h0 = fp16(x), h1 = fp16((x - h0) * 2^11)        (22 significand bits)
- *                     w = g0 + g1,        g0 = fp16(w), g1 = fp16(w - g0),  g2 = 2^-11*g0 (exact), w pre-scaled per output channel
+ *                     w = g0 + g1,        g0 = fp16(w), g1 = fp16(w - g0),  g2 = 2^-11*g0 (exact for |g0| >= 2^-3, i.e. weights less than 2^14 below their channel's maximum; fp16-rounded below), w pre-scaled per output channel
  *                     x*w ~ h0*g0 + h0*g1 + h1*g2   (dropped: 2^-11*h1*g1 and the two residual roundings, <= 3*2^-22 relative)
  *                   full precision for 2^-14 <= |x| <= 65504 (below: absolute error <= 2^-36; above: fp16 overflow, reported
  *                   through `status`); weights within 2^-15 of their channel's largest keep 22 bits. */

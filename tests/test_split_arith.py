@@ -1,0 +1,131 @@
+"""CPU check of the HOST side of the split-operand arithmetic (vps_amd/nhwc.py:PackedConv packs on whatever device it is given):
+the operand planes, the per-channel power-of-two scaling of f16x3, the k ordering (tap-major / chunk-major), the parity classes of
+the transposed convs and the MFMA-fragment permutation are undone from the packed buffer exactly as the kernels index them
+(include/vps_hip.h: w_split [plane][class][cout_pad/32][kpad/16][lane = 32*((k/8)%2) + cout%32][8]), the activation split of
+conv_mfma.hip:split_act is mirrored in torch, the product table of Split<MODE> is applied, and the result — accumulated in float64,
+i.e. the arithmetic DESIGN, not the accumulation order of the matrix pipe — is compared with the exact float64 convolution:
+
+    f16x3  : |err| <= 3 * 2^-22 * sum|x||w|     (the GPU test measures the same bound through the kernels)
+    bf16x6 : |err| <= 2^-22 * sum|x||w|
+    bf16x3 : |err| <= 2^-15 * sum|x||w|
+    bf16   : |err| <= 2^-7  * sum|x||w|
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from vps_amd import hip, nhwc
+
+PA = {hip.PREC_F16X3: [0, 1, 0], hip.PREC_BF16X6: [0, 0, 1, 1, 0, 2], hip.PREC_BF16X3: [0, 0, 1], hip.PREC_BF16: [0]}
+PB = {hip.PREC_F16X3: [1, 2, 0], hip.PREC_BF16X6: [0, 1, 0, 1, 2, 0], hip.PREC_BF16X3: [0, 1, 0], hip.PREC_BF16: [0]}
+BOUND = {hip.PREC_F16X3: 3 * 2.0 ** -22, hip.PREC_BF16X6: 2.0 ** -22, hip.PREC_BF16X3: 2.0 ** -15, hip.PREC_BF16: 2.0 ** -7}
+
+
+def unpack_planes(pc):
+    """w_split -> float64 [plane][class][cout_pad][tap][cin_pad] in natural order (undoes fragment order and k order)"""
+    ws = pc.w_split
+    if not pc.deform:
+        P, C, OB, KB, two, thirty2, eight = ws.shape
+        assert (two, thirty2, eight) == (2, 32, 8)
+        ws = ws.permute(0, 1, 2, 5, 3, 4, 6).reshape(P, C, OB * 32, KB * 16)
+    ws = ws.double()
+    P, C, O, K = ws.shape
+    ntap = pc.KH * pc.KW
+    if pc.korder == 0:
+        return ws[..., :ntap * pc.cin_pad].reshape(P, C, O, ntap, pc.cin_pad)
+    nch = (pc.cin_pad + 31) // 32
+    return ws[..., :nch * ntap * 32].reshape(P, C, O, nch, ntap, 32).permute(0, 1, 2, 4, 3, 5).reshape(P, C, O, ntap, nch * 32)
+
+
+def split_act(x, prec):
+    """mirror of conv_mfma.hip:split_act -> list of float64 planes whose weighted sum is the staged activation"""
+    if prec == hip.PREC_F16X3:
+        h0 = x.to(torch.float16)
+        h1 = ((x - h0.float()) * 2048.0).to(torch.float16)
+        return [h0.double(), h1.double()]
+    n = {hip.PREC_BF16X6: 3, hip.PREC_BF16X3: 2, hip.PREC_BF16: 1}[prec]
+    r, out = x.clone(), []
+    for _ in range(n):
+        h = r.to(torch.bfloat16)
+        out.append(h.double())
+        r = r - h.float()
+    return out
+
+
+def packed_planes_checks(pc, prec):
+    planes = unpack_planes(pc)
+    if prec == hip.PREC_F16X3:
+        g0, g1, g2 = planes
+        # g2 = 2^-11 g0: exact while it stays a normal fp16 number, i.e. for |g0| >= 2^-3 (weights less than 2^14 below their
+        # channel's maximum); below, the fp16 rounding of the product (what the host stores) - an error <= 2^-25 per element
+        assert torch.equal(g2, (g0 * 2.0 ** -11).to(torch.float16).double())
+        big = g0.abs() >= 0.125
+        assert torch.equal(g2[big], (g0 * 2.0 ** -11)[big])
+        top = g0.abs().amax(dim=(0, 2, 3))[:pc.cout]
+        assert bool(((top >= 2.0 ** 11) & (top <= 2.0 ** 12)).all())                  # every output channel fills the fp16 significand range
+        sc = pc.scale if pc.scale is not None else torch.ones(pc.cout)
+        assert bool((torch.frexp(sc.float())[0].abs() == 0.5).all()) or pc.has_scale  # pure powers of two unless a BN scale is folded in
+    return planes
+
+
+@pytest.mark.parametrize('prec', [hip.PREC_F16X3, hip.PREC_BF16X6, hip.PREC_BF16X3, hip.PREC_BF16], ids=['f16x3', 'bf16x6', 'bf16x3', 'bf16'])
+@pytest.mark.parametrize('cin,cout,k,stride,pad', [(64, 96, 3, 1, 1), (12, 40, 3, 1, 1), (82, 130, 5, 2, 2), (256, 64, 1, 1, 0)],
+                         ids=['chunk_major', 'tap_major_small_cin', 'ragged_chunk_5x5_s2', 'pointwise'])
+def test_packed_conv_operands_reproduce_the_convolution(prec, cin, cout, k, stride, pad):
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(1, cin, 9, 11, generator=g) * torch.logspace(-2, 2, cin).view(1, cin, 1, 1)      # 4 decades of activation range
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5 * torch.logspace(-3, 1, cout).view(cout, 1, 1, 1)
+    pc = nhwc.PackedConv(w, None, None, stride, pad, device=torch.device('cpu'), prec=prec)
+    assert pc.prec == prec and pc.nclass == 1
+    planes = packed_planes_checks(pc, prec)
+    xa = split_act(x, prec)
+    if prec == hip.PREC_F16X3:
+        xa = [xa[0], xa[1]]                                                       # x = h0 + 2^-11 h1; g2 carries the 2^-11
+    y = torch.zeros(1, cout, *F.conv2d(x, w, stride=stride, padding=pad).shape[2:], dtype=torch.float64)
+    for pa, pb in zip(PA[prec], PB[prec]):
+        wp = planes[pb][0, :cout, :, :cin].reshape(cout, k, k, cin).permute(0, 3, 1, 2)      # [cout][cin][ky][kx]
+        y += F.conv2d(xa[pa], wp, stride=stride, padding=pad)
+    if pc.scale is not None:
+        y = y * pc.scale.double().view(1, -1, 1, 1)
+    ref = F.conv2d(x.double(), w.double(), stride=stride, padding=pad)
+    den = F.conv2d(x.double().abs(), w.double().abs(), stride=stride, padding=pad)
+    rel = float(((y - ref).abs() / den).max())
+    print('prec %d %s: max |err| / sum|x||w| = %.3e (bound %.3e)' % (prec, (cin, cout, k, stride), rel, BOUND[prec]))
+    assert rel <= BOUND[prec]
+    # pad rows / columns of the packed buffer are zero (the kernels contract over cin_pad and kpad)
+    assert float(planes[0][0, cout:].abs().max() if planes[0].shape[1] > cout else 0.0) == 0.0
+    assert float(planes[0][0, :, :, cin:].abs().max() if planes[0].shape[3] > cin else 0.0) == 0.0
+
+
+@pytest.mark.parametrize('prec', [hip.PREC_F16X3, hip.PREC_BF16X6], ids=['f16x3', 'bf16x6'])
+def test_packed_transposed_conv_classes_reproduce_conv_transpose(prec):
+    """ConvTranspose2d 4x4 s2 p1 (the FlowNet2 deconvs) = 4 output-parity classes of 2x2 stride-1 convs: the class weights and
+    per-class paddings PackedConv derives, applied with the split operands, give F.conv_transpose2d"""
+    cin, cout = 64, 32
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, cin, 7, 9, generator=g)
+    w = torch.randn(cin, cout, 4, 4, generator=g) * 0.05
+    pc = nhwc.PackedConv(w, None, None, 2, 1, transposed=True, device=torch.device('cpu'), prec=prec)
+    assert pc.nclass == 4 and (pc.KH, pc.KW) == (2, 2)
+    planes = unpack_planes(pc)
+    xa = split_act(x, prec)
+    ref = F.conv_transpose2d(x.double(), w.double(), stride=2, padding=1)
+    den = F.conv_transpose2d(x.double().abs(), w.double().abs(), stride=2, padding=1)
+    y = torch.zeros_like(ref)
+    H, W = x.shape[2:]
+    for py in range(2):
+        for px in range(2):
+            cls = py * 2 + px
+            acc = torch.zeros(1, cout, H, W, dtype=torch.float64)
+            for pa, pb in zip(PA[prec], PB[prec]):
+                wp = planes[pb][cls, :cout, :, :cin].reshape(cout, 2, 2, cin).permute(0, 3, 1, 2)
+                # tap (uy, ux) of class (py, px) reads input (q + u - pad[class]) : pad the input so that a valid conv does it
+                ty, tx = pc.pad_y[py], pc.pad_x[px]
+                xp = F.pad(xa[pa], (tx, 1 - tx, ty, 1 - ty))
+                acc += F.conv2d(xp, wp)
+            if pc.scale is not None:
+                acc = acc * pc.scale.double().view(1, -1, 1, 1)
+            y[:, :, py::2, px::2] = acc
+    rel = float(((y - ref).abs() / den).max())
+    assert rel <= BOUND[prec], rel
