@@ -36,28 +36,36 @@ def test_oracle_matches_reference_function():
     assert n == 12 and int(np.load(GOLD)['clip1_nf2_counts'][:, 1].sum()) > 0        # the golden clips do contain matches
 
 
+def _ev():
+    from vps_amd import evaluate as ev
+    return ev
+
+
+# the per-frame device count (vps_pair_count) restated in NumPy: CPU stand-in for the tests of the HOST logic around it
+def _numpy_count(self, gt_json, pred_json, gt_pan, pred_pan, categories, extra_gt_ids=None):
+    ids = lambda q: (lambda u: u[:, :, 0] + u[:, :, 1] * 256 + u[:, :, 2] * 65536)(np.asarray(q).astype(np.int64))
+    g, p = ids(gt_pan), ids(pred_pan)
+    gt_segms, pred_segms = _ev()._merged(gt_json), _ev()._merged(pred_json)
+    labels, cnt = np.unique(p, return_counts=True)
+    pred_set = set(el['id'] for el in pred_json['segments_info'])
+    for label, c in zip(labels, cnt):
+        label = int(label)
+        if label not in pred_segms:
+            assert label == 0
+            continue
+        pred_segms[label]['area'] = int(c); pred_set.remove(label)
+    assert not pred_set
+    listed_g = set([0] + [el['id'] for el in gt_json['segments_info']] + list(extra_gt_ids or ()))
+    lab, c2 = np.unique(g * (1 << 24) + p, return_counts=True)
+    pairs = {(int(l >> 24), int(l & ((1 << 24) - 1))): int(c) for l, c in zip(lab, c2) if int(l >> 24) in listed_g}
+    return gt_segms, pred_segms, pairs
+
+
 def test_host_matching_logic_with_numpy_counts(monkeypatch):
     """CPU coverage of vps_amd/evaluate.py's host side (segment bookkeeping, window sums, matching): the per-frame device count
     is replaced by its NumPy definition and the result must still equal the reference function's statistics"""
     from vps_amd import evaluate as ev
-
-    def count(self, gt_json, pred_json, gt_pan, pred_pan, categories, extra_gt_ids=None):
-        ids = lambda q: (lambda u: u[:, :, 0] + u[:, :, 1] * 256 + u[:, :, 2] * 65536)(np.asarray(q).astype(np.int64))
-        g, p = ids(gt_pan), ids(pred_pan)
-        gt_segms, pred_segms = ev._merged(gt_json), ev._merged(pred_json)
-        labels, cnt = np.unique(p, return_counts=True)
-        pred_set = set(el['id'] for el in pred_json['segments_info'])
-        for label, c in zip(labels, cnt):
-            label = int(label)
-            if label not in pred_segms:
-                assert label == 0
-                continue
-            pred_segms[label]['area'] = int(c); pred_set.remove(label)
-        assert not pred_set
-        listed_g = set([0] + [el['id'] for el in gt_json['segments_info']] + list(extra_gt_ids or ()))
-        lab, c2 = np.unique(g * (1 << 24) + p, return_counts=True)
-        pairs = {(int(l >> 24), int(l & ((1 << 24) - 1))): int(c) for l, c in zip(lab, c2) if int(l >> 24) in listed_g}
-        return gt_segms, pred_segms, pairs
+    count = _numpy_count
     monkeypatch.setattr(ev.FrameCounts, 'count', count)
     monkeypatch.setattr(ev.FrameCounts, '__init__', lambda self, device='cuda': None)
     for ci, nf, frames, counts, iou in _clips():
@@ -93,3 +101,78 @@ def test_device_counts_full_size_and_error_paths(dev):
     extra = info(pr); extra['segments_info'].append({'id': 12345, 'category_id': 3, 'iscrowd': 0, 'area': 1})
     with pytest.raises(KeyError):
         ev.FrameCounts(dev).count(info(gt), extra, rgb(gt), rgb(pr), CATS)
+
+
+def _write_dataset(tmp_path, clips):
+    """the files tools/eval_vpq.py reads: <truth>/<name>_final_mask.png, <submit>/pan_pred/<id>.png, <submit>/pred.json, gt json"""
+    from PIL import Image
+    z = np.load(GOLD)
+    truth, submit = tmp_path / 'truth', tmp_path / 'submit'
+    (submit / 'pan_pred').mkdir(parents=True); truth.mkdir()
+    images, gt_ann, pred_ann, sets = [], [], [], []
+    for v, ci in enumerate(clips):
+        js = json.loads(bytes(z['clip%d_json' % ci]).decode())
+        gt, pred = z['clip%d_gt' % ci], z['clip%d_pred' % ci]
+        sets.append([(js[f][0], js[f][1], gt[f], pred[f], {}) for f in range(len(js))])
+        for f in range(len(js)):
+            iid = '%04d_%04d_city_%06d' % (v, f, f)
+            images.append({'id': iid, 'file_name': iid + '_newImg8bit.png'})
+            Image.fromarray(gt[f]).save(str(truth / (iid + '_final_mask.png')))
+            Image.fromarray(pred[f]).save(str(submit / 'pan_pred' / (iid + '.png')))
+            gt_ann.append(js[f][0]); pred_ann.append(js[f][1])
+    cats = [{'id': c, 'isthing': 1 if c >= 11 else 0, 'name': 'c%d' % c} for c in range(19)]
+    gj = tmp_path / 'gt.json'
+    gj.write_text(json.dumps({'images': images, 'annotations': gt_ann, 'categories': cats}))
+    (submit / 'pred.json').write_text(json.dumps({'annotations': pred_ann}))
+    return str(submit), str(truth), str(gj), sets
+
+
+def _expected_vpq(sets):
+    """the reference's averaging (eval_vpq.py:212-232, 303-330) over the oracle's per-clip statistics"""
+    from vps_amd.evaluate import PQStat
+    out = {'All': [], 'Things': [], 'Stuff': []}
+    for nf in (1, 2, 3, 4):
+        stat = PQStat()
+        for frames in sets:
+            o = oev.vpq_compute_single_core(frames, CATS, nframes=nf)
+            for c, cat in o.pq_per_cat.items():
+                stat[c].tp += cat.tp; stat[c].fp += cat.fp; stat[c].fn += cat.fn; stat[c].iou += cat.iou
+        for name, isthing in (('All', None), ('Things', True), ('Stuff', False)):
+            out[name].append(100 * stat.pq_average(CATS, isthing=isthing)[0]['pq'])
+    return {k: sum(v) / 4 for k, v in out.items()}
+
+
+def _load_cli():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('eval_vpq_device', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'eval_vpq_device.py'))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    return mod
+
+
+def test_eval_vpq_command_line_files_and_numbers(tmp_path, monkeypatch):
+    """tools/eval_vpq_device.py = tools/eval_vpq.py:main on this package: reads the PNG / json files of the reference's layout,
+    writes vpq-0/5/10/15.txt and vpq-final.txt; numbers equal the oracle's statistics pushed through the reference's averaging
+    (the device count replaced by its NumPy definition on the CPU)"""
+    ev = _ev()
+    monkeypatch.setattr(ev.FrameCounts, 'count', _numpy_count)
+    monkeypatch.setattr(ev.FrameCounts, '__init__', lambda self, device='cuda': None)
+    submit, truth, gj, sets = _write_dataset(tmp_path, (0, 3))
+    got = _load_cli().main(['--submit_dir', submit, '--truth_dir', truth, '--pan_gt_json_file', gj, '--nframes_per_video', '5', '--device', 'cpu'])
+    exp = _expected_vpq(sets)
+    for k in exp:
+        assert abs(got[k] - exp[k]) < 1e-9, (k, got[k], exp[k])
+    assert exp['All'] > 0
+    final = open(os.path.join(submit, 'vpq-final.txt')).read().split()
+    assert final == ['vpq_all:%.4f' % exp['All'], 'vpq_thing:%.4f' % exp['Things'], 'vpq_stuff:%.4f' % exp['Stuff']]
+    for k in (0, 5, 10, 15):
+        lines = open(os.path.join(submit, 'vpq-%d.txt' % k)).read().splitlines()
+        assert lines[0] == '=' * 48 and lines[3].startswith('All       |') and lines[6].startswith('IDX |') and len(lines) == 7 + 19
+
+
+@pytest.mark.gpu
+def test_eval_vpq_command_line_on_the_device(dev, tmp_path):
+    submit, truth, gj, sets = _write_dataset(tmp_path, (0, 3))
+    got = _load_cli().main(['--submit_dir', submit, '--truth_dir', truth, '--pan_gt_json_file', gj, '--nframes_per_video', '5', '--device', str(dev)])
+    exp = _expected_vpq(sets)
+    for k in exp:
+        assert abs(got[k] - exp[k]) < 1e-9, (k, got[k], exp[k])
