@@ -76,3 +76,32 @@ def test_device_resize_matches_cv2_restatement(dev, H0, W0, H, W):
     prep = pl.DeviceImagePrep(**NORM, device=dev)
     out = prep.resize(torch.from_numpy(img).to(dev), W, H)
     assert np.array_equal(out.cpu().numpy(), opl.cv2_resize_linear_u8(img, (W, H)))
+
+
+def test_imread_and_load_ref_image_decode_every_file_once(tmp_path):
+    """host side of SURVEY 8(f) row 1: mmcv.imread semantics (BGR uint8, grey -> 3 channels, alpha dropped) with PIL, and the
+    LoadRefImageFromFile mirror (datasets/pipelines/loading.py:33-68: same keys) that does not decode frame t-1 a second time
+    as frame t's reference"""
+    from PIL import Image
+    from vps_amd.pipeline import LoadRefImageFromFile, imread
+    rg = np.random.default_rng(0)
+    frames = [rg.integers(0, 256, (24, 40, 3), dtype=np.uint8) for _ in range(4)]           # RGB as stored in the file
+    for i, f in enumerate(frames):
+        Image.fromarray(f).save(str(tmp_path / ('f%d.png' % i)))
+    assert np.array_equal(imread(str(tmp_path / 'f0.png')), frames[0][:, :, ::-1])
+    Image.fromarray(frames[0][:, :, 0]).save(str(tmp_path / 'grey.png'))
+    g = imread(str(tmp_path / 'grey.png'))
+    assert g.shape == (24, 40, 3) and all(np.array_equal(g[:, :, c], frames[0][:, :, 0]) for c in range(3))
+    rgba = np.concatenate([frames[1], np.full((24, 40, 1), 77, np.uint8)], axis=2)
+    Image.fromarray(rgba).save(str(tmp_path / 'rgba.png'))
+    assert np.array_equal(imread(str(tmp_path / 'rgba.png')), frames[1][:, :, ::-1])
+    load = LoadRefImageFromFile()
+    for t in range(4):
+        ref = t - 1 if t else 0                                                             # the first frame is its own reference
+        res = load(dict(img_prefix=str(tmp_path), ref_prefix=str(tmp_path), img_info=dict(filename='f%d.png' % t, ref_filename='f%d.png' % ref, id=10001 + t)))
+        assert np.array_equal(res['img'], frames[t][:, :, ::-1]) and np.array_equal(res['ref_img'], frames[ref][:, :, ::-1])
+        assert res['img_shape'] == res['ori_shape'] == (24, 40, 3) and res['iid'] == 10001 + t
+        assert res['filename'] == str(tmp_path / ('f%d.png' % t))
+    assert load.decodes == 4                                                                # the reference decodes 8 times here
+    with pytest.raises(NotImplementedError):
+        load(dict(img_prefix='.', ref_prefix='.', img_info=dict(filename='x.png', id=1)))

@@ -9,9 +9,12 @@ video is its own reference) — the reference decodes and normalises every image
 
 Resize: at the dataset's native 1024x2048 the keep-ratio rescale to (2048, 1024) has scale factor 1.0 and copies the image;
 any other size goes through `vps_resize_u8`, OpenCV's 8-bit fixed-point bilinear (what mmcv.imrescale -> cv2.resize computes on
-the decoded image; restated from the published resize.cpp, no cv2 here to pin it). Image decoding itself (cv2.imread) stays
-on the host. No CPU path: the HIP library must load."""
+the decoded image; restated from the published resize.cpp, no cv2 here to pin it). Image decoding itself stays on the host:
+`imread` / `LoadRefImageFromFile` below mirror `mmcv.imread` (BGR uint8) and `datasets/pipelines/loading.py:33-68` with PIL (PNG is
+lossless, so the arrays equal cv2's for the datasets of the path) and decode every file ONCE — frame t's `ref_filename` is frame
+t-1's `filename`. No CPU path for the transforms: the HIP library must load."""
 import ctypes
+import os.path as osp
 
 import numpy as np
 import torch
@@ -119,3 +122,52 @@ class PairFeeder:
         ref = cur if self.prev is None else self.prev
         self.prev = cur
         return cur.unsqueeze(0), ref.unsqueeze(0)            # [1,3,Hp,Wp] each, what model(img=[..], ref_img=[..]) takes
+
+
+def imread(path):
+    """mmcv.imread(path) / cv2.imread(path, IMREAD_COLOR): uint8 [H,W,3] in BGR order; grey images are replicated to three
+    channels, an alpha channel is dropped"""
+    from PIL import Image
+    with Image.open(path) as im:
+        rgb = np.asarray(im.convert('RGB'))
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+class LoadRefImageFromFile:
+    """datasets/pipelines/loading.py:33-68, same `results` keys in and out (`img_prefix`, `ref_prefix`, `img_info{filename,
+    ref_filename, id}` -> `filename`, `img`, `img_shape`, `ori_shape`, `ref_img`, `iid`). The reference decodes the image and its
+    reference on every call; in a clip the reference of frame t is the image of frame t-1 (cityscapes_vps.py:137-148), so the last
+    decoded image is kept and a matching `ref_filename` costs no second decode."""
+
+    def __init__(self, sample=True, to_float32=False):
+        self.to_float32, self.sample = to_float32, sample
+        self._last = (None, None)
+        self.decodes = 0
+
+    def _read(self, path):
+        if self._last[0] == path:
+            return self._last[1]
+        self.decodes += 1
+        return imread(path)
+
+    def __call__(self, results):
+        assert results['ref_prefix'] is not None, 'ref_prefix must be specified.'
+        filename = osp.join(results['img_prefix'], results['img_info']['filename'])
+        if 'ref_filename' not in results['img_info']:
+            raise NotImplementedError('We need this implementation.')             # loading.py:55
+        ref_filename = osp.join(results['ref_prefix'], results['img_info']['ref_filename'])
+        ref_img = self._read(ref_filename)                                         # before `img` replaces the kept image
+        img = ref_img if ref_filename == filename else self._read(filename)
+        self._last = (filename, img)
+        if self.to_float32:
+            img, ref_img = img.astype(np.float32), ref_img.astype(np.float32)
+        results['filename'] = filename
+        results['img'] = img
+        results['img_shape'] = img.shape
+        results['ori_shape'] = img.shape
+        results['ref_img'] = ref_img
+        results['iid'] = results['img_info']['id']
+        return results
+
+    def __repr__(self):
+        return self.__class__.__name__ + '(to_float32={})'.format(self.to_float32)
