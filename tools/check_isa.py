@@ -39,8 +39,8 @@ def scan(lib):
             for line in txt.splitlines():
                 if PK.search(line):
                     npk += 1
-                    if BAD.search(line):
-                        bad.append(line.strip())
+                if BAD.search(line):
+                    bad.append(line.strip())
         return len(objs), npk, bad
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
