@@ -48,6 +48,16 @@ class ClipShardRunner:
         Returns on rank 0 the list of per-frame outputs for the WHOLE clip (frame order), elsewhere this rank's outputs
         without ids."""
         dist, rank, world = self.dist, self.rank, self.world
+        # every frame is loaded ONCE and the same tensor object is handed to the backend wherever the frame is needed (as the
+        # hand-off frame, as `img`, as the next call's `ref_img`, as the announced `next_img`): the detector matches its
+        # prefetched / handed-off work by tensor identity, and a loader that decodes or uploads per call would otherwise never
+        # match (every frame's image-only stages would run twice; ADVICE r2)
+        user_load, memo = load_frame, {}
+
+        def load_frame(t):
+            if t not in memo:
+                memo[t] = user_load(t)
+            return memo[t]
         parts = partition(nframes, world)
         s, e = parts[rank]
         be = self.backend
@@ -87,6 +97,7 @@ class ClipShardRunner:
             rec['t'] = t
             records.append(rec)
             prev = img
+            memo.pop(t - 1, None)            # frame t-1 is no longer needed (frame t stays: it is frame t+1's reference)
         for rq in reqs:
             rq.wait()
         # 3) sequential tracker replay on rank 0
@@ -184,7 +195,8 @@ class DetectorBackend:
     def __init__(self, detector, H, W, prefetch=True):
         self.det, self.H, self.W = detector, H, W
         self.prefetch = prefetch
-        detector.verify_ref_frame = False      # the runner hands frame t-1 to frame t as its reference by construction
+        # the runner hands frame t-1 to frame t as its reference by construction: the probe check is skipped per call (the
+        # detector's own setting is restored after every call, the model object may be shared with other callers)
 
     def ref_feature(self, img):
         return self.det.gathered_feature(img)
@@ -197,7 +209,11 @@ class DetectorBackend:
         from . import synth
         meta = synth.img_meta(self.H, self.W, iid)
         pf = (next_img, img) if (self.prefetch and next_img is not None) else None      # the next frame's reference is this frame
-        out = self.det.simple_test(img, [meta], ref_img=[ref_img], ref_feature=ref_feature, defer_tracking=True, prefetch=pf)
+        keep, self.det.verify_ref_frame = self.det.verify_ref_frame, False
+        try:
+            out = self.det.simple_test(img, [meta], ref_img=[ref_img], ref_feature=ref_feature, defer_tracking=True, prefetch=pf)
+        finally:
+            self.det.verify_ref_frame = keep
         rec = dict(out[2])
         rec.update(self.det._track_record)
         return rec

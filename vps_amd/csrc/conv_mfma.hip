@@ -1932,8 +1932,8 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
     const long tiles2d8 = (long)d.N * ((d.Qh + 7) / 8) * ((d.Qw + 31) / 32);
     const bool h8 = halo && BN == 128 && (d.prec == VPS_PREC_F16X3 || d.prec == VPS_PREC_BF16X3 || d.prec == VPS_PREC_BF16) &&
                     tiles2d8 * 256 * 2 <= (long)M * 3 && tiles2d8 * tiles_n * d.nclass * d.ksplit >= 256;
-    // EXPERIMENTAL (VPS_S2_HALO=1): stride-2 3x3 / 5x5 layers on the phase-split 8-wave halo kernel
-    static const bool s2_enabled = getenv("VPS_S2_HALO") != nullptr;
+    // stride-2 3x3 / 5x5 layers on the phase-split 8-wave halo kernel (VPS_S2_HALO=0 in the environment switches it off: A/B runs)
+    static const bool s2_enabled = !(getenv("VPS_S2_HALO") && getenv("VPS_S2_HALO")[0] == '0');
     const bool h8s2 = s2_enabled && BN == 128 && (d.prec == VPS_PREC_F16X3 || d.prec == VPS_PREC_BF16X3 || d.prec == VPS_PREC_BF16) && !d.offset &&
                       d.stride == 2 && d.nclass == 1 && d.korder == 1 && d.KH == d.KW && (d.KH == 3 || d.KH == 5) &&
                       d.pad_y[0] == d.KH / 2 && d.pad_x[0] == d.KW / 2 && tiles2d8 * 256 * 2 <= (long)M * 3 &&
@@ -2020,7 +2020,7 @@ extern "C" int vps_conv2d(const vps_conv_desc* dp, void* stream) {
     if (d.offset && (d.nclass != 1 || d.off_ld < 2 * d.KH * d.KW || d.KH * d.KW > 9 || d.H > 65535 || d.W > 65535)) return VPS_EARG(9);
     if (((uintptr_t)d.in & 15) || ((uintptr_t)d.w & 15) || ((uintptr_t)d.w_split & 15)) return VPS_EARG(10);
     // GroupNorm sums in the epilogue: the deformable kernel of the split-operand modes only, unsplit, float4 stores, groups of 4 | 8 | 16 ...
-    if (d.gn_stats && (!d.offset || d.prec == VPS_PREC_F32 || d.ksplit != 1 || d.gn_rep < 1 || (d.gn_rep & (d.gn_rep - 1)) || d.cout % d.gn_cpg || (d.gn_cpg != 4 && (d.gn_cpg < 8 || (d.gn_cpg & 7))) ||
+    if (d.gn_stats && (!d.offset || d.prec == VPS_PREC_F32 || d.ksplit != 1 || d.gn_rep < 1 || (d.gn_rep & (d.gn_rep - 1)) || (d.gn_cpg != 4 && (d.gn_cpg < 8 || (d.gn_cpg & 7))) || d.cout % d.gn_cpg ||
                        ((d.cout | d.out_ld | d.out_coff) & 3) || ((uintptr_t)d.out & 15) || d.res || ((uintptr_t)d.gn_stats & 7)))
         return VPS_EARG(15);
     const long Ml = (long)d.N * d.Qh * d.Qw;

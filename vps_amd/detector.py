@@ -216,8 +216,11 @@ class PanopticFuseTrack(HipModule):
             if self._side is None or self._side.device != dev:
                 self._side = torch.cuda.Stream(device=dev)
             side = self._side
-        flow = cat = aux = None
-        if not self.with_fusion:
+        flow = cat = aux = levels = None
+        if inject is not None and 'neck_out' in inject:
+            # tests: the neck output itself is injected (five NCHW levels) — the image-only stages and the neck are skipped
+            x = [nhwc.from_nchw(l.to(dev), ws, 'inj.neck%d' % i) for i, l in enumerate(inject['neck_out'])]
+        elif not self.with_fusion:
             # PanopticTrack (panoptic_track.py:447): the FPN outputs feed the heads directly
             levels = self.neck.run(self.backbone.run(nhwc.from_nchw(img, ws, 'img_nhwc'), ws, 'bb.'), ws, 'fpn.')
             x = levels
@@ -231,7 +234,15 @@ class PanopticFuseTrack(HipModule):
                 self._mark('flownet2')
             else:
                 if pf is not None:
-                    self._flip ^= 1           # an unused prefetch: its 'neck.cat' buffer is the one to overwrite, not the previous frame's
+                    # an unused prefetch (the caller announced other tensors than it now passes): the side stream may still be
+                    # writing 'img_nhwc' / 'bb.*' / 'fpn.*' / 'fn2.*' / its 'neck.cat' buffer — the same workspace names this
+                    # frame is about to write — so the main stream orders itself behind it first, and that
+                    # 'neck.cat' buffer is the one to overwrite, not the previous frame's
+                    if main is not None:
+                        main.wait_event(pf['event'])
+                    else:
+                        pf['event'].synchronize()
+                    self._flip ^= 1
                 # (1) flow ---------------------------------------------------------------------------------------------
                 if side is not None:
                     side.wait_stream(main)

@@ -137,10 +137,13 @@ def vpq_compute_single_core(gt_pred_set, categories, nframes=2, device='cuda', _
     for idx in range(0, len(gt_pred_set) - nframes + 1):
         gts, preds, gt_pred_map = [], [], {}
         for off, (gt_json, pred_json, gt_pan, pred_pan, _) in enumerate(gt_pred_set[idx:idx + nframes]):
+            # keyed by the clip OBJECT: the entry keeps a reference to it and a hit is accepted only for the same object, so an
+            # id() recycled by CPython for another (freed and re-allocated) clip list can never return stale counts
             key = (id(gt_pred_set), idx + off)
-            if key not in cache:
-                cache[key] = fc.count(gt_json, pred_json, gt_pan, pred_pan, categories, clip_gt_ids)
-            g, p, pairs = cache[key]
+            ent = cache.get(key)
+            if ent is None or ent[0] is not gt_pred_set:
+                ent = cache[key] = (gt_pred_set, fc.count(gt_json, pred_json, gt_pan, pred_pan, categories, clip_gt_ids))
+            g, p, pairs = ent[1]
             gts.append(copy.deepcopy(g)); preds.append(copy.deepcopy(p))        # the reference rebuilds them per window
             for k, v in pairs.items():
                 gt_pred_map[k] = gt_pred_map.get(k, 0) + v

@@ -16,6 +16,8 @@ t-1's `filename`. No CPU path for the transforms: the HIP library must load."""
 import ctypes
 import os.path as osp
 
+import warnings
+
 import numpy as np
 import torch
 
@@ -127,8 +129,22 @@ class PairFeeder:
 def imread(path):
     """mmcv.imread(path) / cv2.imread(path, IMREAD_COLOR): uint8 [H,W,3] in BGR order; grey images are replicated to three
     channels, an alpha channel is dropped"""
+    try:
+        import cv2                          # the reference's own decoder when the host has it
+        img = cv2.imread(path, cv2.IMREAD_COLOR)
+        if img is None:
+            raise IOError('cv2.imread failed: %s' % path)
+        return img
+    except ImportError:
+        pass
     from PIL import Image
     with Image.open(path) as im:
+        # PIL equals cv2.imread bit for bit only for 8-bit PNG (lossless; the Cityscapes-VPS frames). A 16-bit PNG is not scaled
+        # like cv2 does -> refused; a JPEG (VIPER) decodes with another IDCT / EXIF handling -> decoded, with a warning (ADVICE r2)
+        if im.mode in ('I;16', 'I;16B', 'I', 'F'):
+            raise ValueError('imread: %s is not an 8-bit image (mode %s); cv2 is needed for cv2.imread semantics' % (path, im.mode))
+        if im.format != 'PNG':
+            warnings.warn('imread: %s decoded with PIL; pixels can differ from cv2.imread for lossy formats (%s)' % (path, im.format))
         rgb = np.asarray(im.convert('RGB'))
     return np.ascontiguousarray(rgb[:, :, ::-1])
 
@@ -157,8 +173,9 @@ class LoadRefImageFromFile:
             raise NotImplementedError('We need this implementation.')             # loading.py:55
         ref_filename = osp.join(results['ref_prefix'], results['img_info']['ref_filename'])
         ref_img = self._read(ref_filename)                                         # before `img` replaces the kept image
-        img = ref_img if ref_filename == filename else self._read(filename)
+        img = ref_img.copy() if ref_filename == filename else self._read(filename)    # independent arrays, like the reference
         self._last = (filename, img)
+        img.setflags(write=False)          # the kept array is next frame's ref_img: an in-place transform must not corrupt it
         if self.to_float32:
             img, ref_img = img.astype(np.float32), ref_img.astype(np.float32)
         results['filename'] = filename

@@ -86,13 +86,27 @@ def synth_tensor(key, shape, seed=0):
     return torch.randn(shape, generator=g) * 0.1
 
 
-def synth_state_dict(shapes, seed=0, prefix=''):
-    """shapes: dict key -> shape (e.g. {k: v.shape for k, v in model.state_dict().items()})"""
-    return {k: synth_tensor(prefix + k, tuple(s), seed) for k, s in shapes.items()}
+def synth_state_dict(shapes, seed=0, prefix='', overrides=None):
+    """shapes: dict key -> shape (e.g. {k: v.shape for k, v in model.state_dict().items()}). `overrides`: key -> tensor replacing
+    the seeded one (tests/golden/separated_fc_cls.npz: a classification layer fitted so that every listing decision of the
+    full-size golden clip has a margin — tests/golden/search_separated.py)"""
+    sd = {k: synth_tensor(prefix + k, tuple(s), seed) for k, s in shapes.items()}
+    for k, v in (overrides or {}).items():
+        assert prefix + k in sd or k in sd, k
+        kk = k if k in sd else prefix + k
+        assert tuple(v.shape) == tuple(sd[kk].shape), (k, tuple(v.shape), tuple(sd[kk].shape))
+        sd[kk] = torch.as_tensor(v).float().clone()
+    return sd
 
 
-def load_synth(model, seed=0):
-    sd = synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, seed)
+def separated_overrides(path):
+    """-> overrides dict of the fitted, well-separated box classification layer stored at `path` (.npz: weight, bias)"""
+    z = np.load(path)
+    return {'bbox_head.fc_cls.weight': torch.from_numpy(z['weight']), 'bbox_head.fc_cls.bias': torch.from_numpy(z['bias'])}
+
+
+def load_synth(model, seed=0, overrides=None):
+    sd = synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, seed, overrides=overrides)
     model.load_state_dict(sd)
     return sd
 
