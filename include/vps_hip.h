@@ -304,6 +304,54 @@ int vps_panoptic_combine(const float* fcn_score, int score_ld, int Hs, int Ws, i
                          const vps_pan_inst* inst, int k, const float* mask_logits, int S,
                          uint8_t* pan, uint8_t* sem, int H, int W, void* stream);
 
+/* same, with the instance count read from DEVICE memory (k_dev[0] <= kmax; k_dev[0] > 255 - nstuff raises status bit 0 of
+ * k_dev[2] and writes nothing): the table comes from vps_pan_instances, the host never sees the kept list before the launch */
+int vps_panoptic_combine_dev(const float* fcn_score, int score_ld, int Hs, int Ws, int nclass, int nstuff,
+                             const vps_pan_inst* inst, const int32_t* k_dev, const float* mask_logits, int S,
+                             uint8_t* pan, uint8_t* sem, int H, int W, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Device-resident detection post-processing (csrc/head_ops.hip): the order-defining HOST code of the reference's heads as
+ * single-workgroup kernels, so that a frame needs ONE mid-frame D2H (the detection list) and one at its end (kept list + ids).
+ * -------------------------------------------------------------------------------------------- */
+/* ref: models/anchor_heads/rpn_head.py:94-104 (`mlvl_proposals` cat, `[:nms_post]` per level, top `max_num` by score).
+ * boxes [nlv][nmax][5] per level in descending score order, keep [nlv][nmax] / nkeep [nlv] as written by vps_nms_batched.
+ * out [max_num][5] (rows >= n_out[0] zeroed), n_out[0] = min(max_num, sum_l min(nkeep[l], nms_post)). nlv*nms_post <= 8192. */
+int vps_rpn_collect(const float* boxes, const int32_t* keep, const int32_t* nkeep, int nlv, int nmax, int nms_post, int max_num,
+                    float* out, int32_t* n_out, void* stream);
+
+/* ref: models/utils/mask_roi.py:43-95 (class_agnostic=True, clip_boxes=True) + utils/upsnet/bbox/bbox_transform.py:45-60,290-330
+ * + utils/upsnet/nms/gpu_nms.pyx:23-38 (`order = scores.argsort()[::-1]`).
+ * rois [n][5], bbox_delta [n][4*nc], cls_prob [n][nc]; n_valid (device, may be NULL): rows >= n_valid[0] are ignored.
+ * Candidates q = roi*(nc-1) + cls-1 with prob > score_thresh, sorted by descending score (equal scores: larger q first),
+ * refined + clipped boxes in fp32 in the reference's operation order -> dets [<= 8192][5] (x1,y1,x2,y2,score), cand [<= 8192] = q,
+ * m_out[0] = count, m_out[1] = 1 if more than 8192 candidates passed (the list is then truncated), m_out[2] = rois considered.
+ * reg_weights: host float[4]. */
+int vps_maskroi_select(const float* rois, const float* bbox_delta, const float* cls_prob, int n, const int32_t* n_valid,
+                       int num_classes, float score_thresh, const float* reg_weights, float im_h, float im_w, float* dets,
+                       int32_t* cand, int32_t* m_out, void* stream);
+
+/* ref: models/utils/mask_roi.py:96-147 (post-NMS list, `max_det` cap by VALUE: `>= image_thresh` keeps ties; dummy row).
+ * keep / nkeep: output of vps_nms_batched on `dets`. res: float [8 + 8*kcap]: res[0] = K, res[1] = candidates, res[2] = post-NMS
+ * count, res[3] = status (bit 0: candidate overflow, bit 1: more than kcap detections), res[4] = rois considered, then K rows
+ * (0, x1, y1, x2, y2, score, class, candidate index). */
+int vps_maskroi_finish(const float* dets, const int32_t* cand, const int32_t* m_in, const int32_t* keep, const int32_t* nkeep,
+                       int num_classes, int max_det, int kcap, float* res, void* stream);
+
+/* ref: models/detectors/panoptic_fusetrack.py:424-469 (arg-max of comp_scores, greedy assignment with undo, new ids, memory
+ * update). comp [K][M+1]; emb [K][E], box [K][ldb], label [K]; prev_emb [>= M+K][E], prev_box [>= M+K][4], prev_label [>= M+K]
+ * are updated in place; scratch int32 [M + 3K]; ids [K]; m_out[0] = new memory size. */
+int vps_track_assign(const float* comp, int K, int M, const float* emb, int E, const float* box, int ldb, const int64_t* label,
+                     float* prev_emb, float* prev_box, int64_t* prev_label, int32_t* scratch, int32_t* ids, int32_t* m_out,
+                     void* stream);
+
+/* ref: models/utils/mask_removal.py:81-91 (kept list; nothing kept -> [0] with zero logits) + utils/unary_logits.py:96-106
+ * (SegTerm crop of boxes*4*0.25). order [n] / flags [n] / tbox [n][4]: MaskRemoval's walk (vps_mask_level), rows [n][8]:
+ * vps_maskroi_finish. class_mapping: host int32 [num_classes]. -> inst [n], keep_out [n], k_out[0] = k, k_out[1] = masks valid. */
+int vps_pan_instances(const int32_t* order, const int32_t* flags, const float* rows, const int32_t* tbox, int n,
+                      const int32_t* class_mapping, int num_classes, vps_pan_inst* inst, int32_t* keep_out, int32_t* k_out,
+                      void* stream);
+
 /* ----------------------------------------------------------------------------------------------
  * Panoptic post-processing. Replaces the per-frame body of
  * tools/dataset/cityscapes_vps.py:183-224 (CityscapesVPS.get_unified_pan_result): ~250 boolean masks + np.unique over

@@ -1,7 +1,7 @@
 """CPU coverage of the HOST side of the HIP path: the three detectors run a 3-frame clip with every kernel launch replaced by a
 recording stub (outputs are meaningless; there is no CPU compute path in the product — the stubs live in this test only).
-Checks: the Python control flow of simple_test (fusion / tracking branches, reference-feature cache, MaskROI / MaskRemoval /
-tracker host logic, result assembly) executes, results have the reference's keys and shapes, every symbol the host calls is
+Checks: the Python control flow of simple_test (fusion / tracking branches, reference-feature cache, the host side of MaskROI /
+MaskRemoval / the tracker, the two host reads of a frame, result assembly) executes, results have the reference's keys and shapes, every symbol the host calls is
 declared in include/vps_hip.h, and the persistent workspace stops growing after the first frames (up to the small per-detection buffers)."""
 import ctypes
 import os
@@ -46,6 +46,35 @@ class _RecordingLib:
         if mode == 1:
             r = np.log(r)
         ctypes.memmove(out.value, r.ctypes.data, r.nbytes)
+        return 0
+
+    def _vps_maskroi_finish(self, dets, cand, m_in, keep, nkeep, nc, max_det, kcap, res, stream):
+        K = 12
+        r = np.zeros(8 + 8 * kcap, dtype=np.float32)
+        r[0], r[1], r[2], r[4] = K, 40, 40, 1000
+        rows = r[8:8 + 8 * K].reshape(K, 8)
+        rows[:, 1] = 10 + 18 * np.arange(K); rows[:, 2] = 20 + 5 * (np.arange(K) % 4)
+        rows[:, 3] = rows[:, 1] + 30; rows[:, 4] = rows[:, 2] + 40
+        rows[:, 5] = 0.95 - 0.02 * np.arange(K); rows[:, 6] = 1 + np.arange(K) % (nc - 1); rows[:, 7] = np.arange(K)
+        ctypes.memmove(res.value, r.ctypes.data, r.nbytes)
+        return 0
+
+    def _vps_pan_instances(self, order, flags, rows, tbox, n, cm, nclass, inst, keep_out, k_out, stream):
+        ko = (ctypes.c_int32 * 4).from_address(k_out.value)
+        kp = (ctypes.c_int32 * n).from_address(keep_out.value)
+        k = 0
+        for p in range(n):
+            if flags is None or flags.value is None or (ctypes.c_int32 * 1).from_address(flags.value + 4 * p)[0]:
+                kp[k] = p if order is None or order.value is None else (ctypes.c_int32 * 1).from_address(order.value + 4 * p)[0]
+                k += 1
+        ko[0], ko[1], ko[2] = max(k, 1), int(k > 0), 0
+        return 0
+
+    def _vps_track_assign(self, comp, K, M, emb, E, box, ldb, label, pe, pb, pl, scratch, ids, m_out, stream):
+        idv = (ctypes.c_int32 * K).from_address(ids.value)
+        for i in range(K):
+            idv[i] = i if i < M else M + (i - M)
+        (ctypes.c_int32 * 1).from_address(m_out.value)[0] = max(M, K)
         return 0
 
     def _vps_mask_level(self, *a):

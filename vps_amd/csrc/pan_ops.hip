@@ -199,8 +199,15 @@ void mask_level_commit_kernel(const float* __restrict__ logits, int S, const int
 // which still beats negative stuff logits: the FIRST such instance stays in the list (later ones cannot win: `>` is strict).
 __global__ __launch_bounds__(256)
 void panoptic_combine_kernel(const float* __restrict__ score, int score_ld, int Hs, int Ws, int nclass, int nstuff,
-                             const vps_pan_inst* __restrict__ inst, int k, const float* __restrict__ mask_logits, int S,
+                             const vps_pan_inst* __restrict__ inst, int k, const int* __restrict__ k_dev, const float* __restrict__ mask_logits, int S,
                              uint8_t* __restrict__ pan, uint8_t* __restrict__ sem, int H, int W, int up) {
+    if (k_dev) {
+        k = k_dev[0];
+        if (k > 255 - nstuff) {         // the uint8 map cannot name that many instances: refuse (status for the host), write nothing
+            if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicOr(const_cast<int*>(k_dev) + 2, 1);
+            return;
+        }
+    }
     __shared__ int list[256];
     __shared__ int nlist;
     const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 8;
@@ -323,6 +330,17 @@ extern "C" int vps_panoptic_combine(const float* fcn_score, int score_ld, int Hs
     if (k < 0 || k > 255 - nstuff || (k > 0 && (!inst || !mask_logits)) || nclass < nstuff || nstuff < 0) return VPS_EARG(2);
     if (H % Hs || W % Ws || H / Hs != W / Ws) return VPS_EARG(3);
     hipLaunchKernelGGL(panoptic_combine_kernel, dim3((W + 31) / 32, (H + 7) / 8), dim3(256), 0, (hipStream_t)stream,
-                       fcn_score, score_ld, Hs, Ws, nclass, nstuff, inst, k, mask_logits, S, pan, sem, H, W, H / Hs);
+                       fcn_score, score_ld, Hs, Ws, nclass, nstuff, inst, k, (const int*)nullptr, mask_logits, S, pan, sem, H, W, H / Hs);
+    return vps_launch_status();
+}
+
+extern "C" int vps_panoptic_combine_dev(const float* fcn_score, int score_ld, int Hs, int Ws, int nclass, int nstuff,
+                                        const vps_pan_inst* inst, const int32_t* k_dev, const float* mask_logits, int S,
+                                        uint8_t* pan, uint8_t* sem, int H, int W, void* stream) {
+    if (!fcn_score || !pan || !sem || !inst || !k_dev || !mask_logits || Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0) return VPS_EARG(1);
+    if (nclass < nstuff || nstuff < 0) return VPS_EARG(2);
+    if (H % Hs || W % Ws || H / Hs != W / Ws) return VPS_EARG(3);
+    hipLaunchKernelGGL(panoptic_combine_kernel, dim3((W + 31) / 32, (H + 7) / 8), dim3(256), 0, (hipStream_t)stream,
+                       fcn_score, score_ld, Hs, Ws, nclass, nstuff, inst, 0, k_dev, mask_logits, S, pan, sem, H, W, H / Hs);
     return vps_launch_status();
 }

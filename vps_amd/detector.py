@@ -27,11 +27,15 @@ from .flownet2 import FlowNet2
 from .panoptic_ops import MaskRemoval, MaskROI, panoptic_combine
 
 
+def _np(a):
+    return a.cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+
+
 def bbox2result(bboxes, labels, num_classes):
     """core/bbox/transforms.py:142-157: per-class list of [n, 5] arrays"""
     if bboxes.shape[0] == 0:
         return [np.zeros((0, 5), dtype=np.float32) for _ in range(num_classes - 1)]
-    bboxes = bboxes.cpu().numpy(); labels = labels.cpu().numpy()
+    bboxes = _np(bboxes); labels = _np(labels)
     return [bboxes[labels == i, :] for i in range(num_classes - 1)]
 
 
@@ -39,7 +43,7 @@ def bbox2result_with_id(bboxes, labels, obj_ids, num_classes):
     """core/bbox/transforms.py:159-180"""
     if bboxes.shape[0] == 0:
         return dict()
-    bboxes = bboxes.cpu().numpy(); labels = labels.cpu().numpy()
+    bboxes = _np(bboxes); labels = _np(labels)
     return {obj_id: {'bbox': bbox, 'label': label} for bbox, label, obj_id in zip(bboxes, labels, obj_ids) if obj_id >= 0}
 
 
@@ -119,6 +123,8 @@ class PanopticFuseTrack(HipModule):
         self.prev_bboxes = None
         self.prev_emb = None
         self.prev_det_labels = None
+        self._mem_n = 0              # memory entries (host view; exact after every end-of-frame read)
+        self._mem_count = None       # the same number on the device, written by vps_track_assign
 
     def pack(self, device):
         for m in (self.backbone, self.neck, self.extra_neck, self.panopticFPN, self.rpn_head, self.bbox_head,
@@ -300,22 +306,17 @@ class PanopticFuseTrack(HipModule):
             fcn_score = nhwc.from_nchw(inject['fcn_score'].to(dev), ws, 'inj.fcn_score')
         self._mark('semantic_head')
         # (5) RPN ------------------------------------------------------------------------------------------------
+        nprop = None                          # device int32 [1]: rows of `proposals` that exist (None = all)
         if inject is not None and 'proposals' in inject:
             proposals = inject['proposals'].to(dev)
         else:
-            proposals = self.rpn_head.run(x, ws, meta['img_shape'], self.test_cfg.rpn)
+            proposals, nprop = self.rpn_head.run(x, ws, meta['img_shape'], self.test_cfg.rpn)
         self._mark('rpn')
         # (6) bbox head + MaskROI + tracking ---------------------------------------------------------------------
-        det = self.simple_test_bboxes(x, meta, proposals, im_info, is_first, ws, inject, defer_tracking)
+        det = self.simple_test_bboxes(x, meta, proposals, im_info, is_first, ws, inject, defer_tracking, nprop)
         self._mark('bbox_track')
-        det_bboxes, det_labels, det_obj_ids = det['det_bboxes'], det['det_labels'], det['det_obj_ids']
+        det_bboxes, det_labels = det['det_bboxes'], det['det_labels']
         cls_prob, mask_rois, cls_idx = det['cls_prob'], det['det_rois'], det['cls_idx']
-        if not self.with_track:
-            bbox_results = bbox2result(det_bboxes, det_labels, self.bbox_head.num_classes)      # panoptic_fuse.py:425-426
-        else:
-            if defer_tracking:
-                det_obj_ids = np.full((det_bboxes.size(0),), -1, dtype=np.int64)
-            bbox_results = bbox2result_with_id(det_bboxes, det_labels, det_obj_ids, self.bbox_head.num_classes)
         mask_results = [[] for _ in range(self.mask_head.num_classes - 1)]       # simple_test_mask: `or True` stub
         # (8) mask head ------------------------------------------------------------------------------------------
         mask_feats = self.mask_roi_extractor.run(x, mask_rois)
@@ -331,19 +332,46 @@ class PanopticFuseTrack(HipModule):
         self._mark('mask_head')
         if side is not None:
             main.wait_event(sem_done)      # the combine kernel reads fcn_score (prefetched work behind it is not waited for)
-        # (9)-(11) MaskRemoval + SegTerm + combine ---------------------------------------------------------------
-        keep_inds, ref_boxes, masks_valid = self.mask_removal(mask_rois[:, 1:], cls_prob, mask_score, cls_idx, (H, W), ws)
-        nhwc.check_f16_range(dev)          # f16x3 only (no-op otherwise): every convolution of the frame has run by now
-        rois_np = mask_rois[:, 1:].cpu().numpy()
-        cls_np = cls_idx.cpu().numpy()
-        pan, sem = panoptic_combine(fcn_score, rois_np, cls_np, ref_boxes, keep_inds, mask_score, self.class_mapping,
-                                    self.panopticFPN.num_stuff_classes, self.panopticFPN.num_classes, (H, W), ws, masks_valid)
-        keep_t = torch.from_numpy(keep_inds).to(dev)
+        # (9)-(11) MaskRemoval + SegTerm + combine: the kept list stays on the device -------------------------------
+        last = self.mask_roi_panoptic.last
+        removal = self.mask_removal(last['rows_h'], last['rows_d'], mask_score, (H, W), ws, self.class_mapping)
+        pan, sem = panoptic_combine(fcn_score, removal, mask_score, self.panopticFPN.num_stuff_classes, self.panopticFPN.num_classes,
+                                    (H, W), ws)
         h0, w0 = meta['img_shape'][0], meta['img_shape'][1]
         pan = pan[:, 0:h0, 0:w0].clone(); sem = sem[:, 0:h0, 0:w0].clone()     # fresh tensors: the workspace is reused next frame
         if self.int64_outputs:
             pan, sem = pan.long(), sem.long()
         self._mark('panoptic_combine')
+        # ---- the frame's END-OF-FRAME host read: kept list, ids, tracker memory size, fp16-range words (one D2H) ----------
+        K = mask_rois.size(0)
+        tail = ws.get('frame.tail', (2 * MaskROI.KCAP + 8,), dtype=torch.int32, zero=False)
+        tail[0:4].copy_(removal['kinfo'])
+        tail[8:8 + K].copy_(removal['keep'][:K])
+        has_ids = self.with_track and not defer_tracking
+        if has_ids:
+            tail[8 + MaskROI.KCAP:8 + MaskROI.KCAP + K].copy_(det['ids_dev'][:K])
+            tail[4:5].copy_(self._mem_count)
+        tail[5:6].copy_(nhwc.f16_status(dev))
+        th = tail.cpu().numpy()
+        k, masks_valid, cstat = int(th[0]), bool(th[1]), int(th[2])
+        if cstat & 1:
+            raise hip.VpsHipError('vps_panoptic_combine: %d kept instances do not fit the uint8 panoptic map (at most %d)'
+                                  % (k, 255 - self.panopticFPN.num_stuff_classes))
+        nhwc.raise_f16_range(dev, int(th[5]))          # f16x3 only (0 otherwise): every convolution of the frame has run by now
+        keep_inds = th[8:8 + k].astype(np.int64)
+        det_obj_ids = None
+        if has_ids:
+            det_obj_ids = th[8 + MaskROI.KCAP:8 + MaskROI.KCAP + K].astype(np.int64)
+            self._mem_n = int(th[4])
+        det['det_obj_ids'] = det_obj_ids
+        keep_t = removal['keep'][:k].long()
+        # boxes / labels of the result lists come from the host copy of the detection list (no further D2H)
+        boxes_h = last['rows_h'][:, 1:5].astype(np.float32); labels_h = last['rows_h'][:, 6].astype(np.int64) - 1
+        if not self.with_track:
+            bbox_results = bbox2result(boxes_h, labels_h, self.bbox_head.num_classes)      # panoptic_fuse.py:425-426
+        else:
+            ids_out = np.full((K,), -1, dtype=np.int64) if defer_tracking else det_obj_ids
+            bbox_results = bbox2result_with_id(boxes_h, labels_h, ids_out, self.bbox_head.num_classes)
         pano_results = {
             'fcn_outputs': sem,
             'panoptic_cls_inds': cls_idx[keep_t],
@@ -352,11 +380,12 @@ class PanopticFuseTrack(HipModule):
         }
         if self.with_track:                                    # panoptic_fuse.py:467-472 returns the four keys above only
             pano_results['panoptic_det_labels'] = det_labels[keep_t]
-            pano_results['panoptic_det_obj_ids'] = torch.from_numpy(np.asarray(det_obj_ids).astype(np.int64)).to(dev)[keep_t]
+            ids_t = det['ids_dev'][:K].long() if has_ids else torch.full((K,), -1, dtype=torch.long, device=dev)
+            pano_results['panoptic_det_obj_ids'] = ids_t[keep_t]
         self._track_record = dict(det_bboxes=det_bboxes, det_labels=det_labels, cls_prob=cls_prob, emb=det['emb'],
                                   keep_inds=keep_inds)
         self._aux = dict(flow=flow, levels=levels, cat=cat, neck_out=x, neck_aux=aux, fcn_score=fcn_score, det=det,
-                         mask_score=mask_score, keep_inds=keep_inds, proposals=proposals, masks_valid=masks_valid)
+                         mask_score=mask_score, keep_inds=keep_inds, proposals=proposals[:last['nrois']], masks_valid=masks_valid)
         return bbox_results, mask_results, pano_results
 
     # ------------------------------------------------------------------------------------------------------
@@ -403,72 +432,72 @@ class PanopticFuseTrack(HipModule):
         return cat.t[..., :C].contiguous()
 
     def track_assign(self, rec, is_first):
-        """sequential tracker step on a deferred record (clip_shard.py)"""
+        """sequential tracker step on a deferred record (clip_shard.py) -> ids (host array: the replay is the consumer)"""
         dev = rec['emb'].device
         if self._ws is None or self._ws.device != dev:
             self._ws = nhwc.Workspace(dev)
         ids, _ = self._assign_ids(rec['det_bboxes'], rec['det_labels'], rec['cls_prob'], rec['emb'], is_first, self._ws)
-        return ids
+        K = rec['det_bboxes'].size(0)
+        buf = torch.cat([ids[:K], self._mem_count])
+        h = buf.cpu().numpy()
+        self._mem_n = int(h[K])
+        return h[:K].astype(np.int64)
+
+    def _mem_reserve(self, dev, need, E):
+        """tracker memory = fixed-capacity device buffers (embeddings [cap,E], boxes [cap,4], labels [cap]); grown by doubling"""
+        cap = 0 if self.prev_emb is None else self.prev_emb.size(0)
+        if cap >= need and self.prev_emb.device == dev:
+            return
+        new = max(1024, 2 * cap, need)
+        emb = torch.zeros(new, E, device=dev); box = torch.zeros(new, 4, device=dev); lab = torch.zeros(new, dtype=torch.long, device=dev)
+        if cap and self._mem_n:
+            emb[:self._mem_n] = self.prev_emb[:self._mem_n]; box[:self._mem_n] = self.prev_bboxes[:self._mem_n]
+            lab[:self._mem_n] = self.prev_det_labels[:self._mem_n]
+        self.prev_emb, self.prev_bboxes, self.prev_det_labels = emb, box, lab
 
     def _assign_ids(self, det_bboxes, det_labels, cls_prob, emb, is_first, ws):
-        """panoptic_fusetrack.py:400-469 (tracking block of simple_test_bboxes)"""
+        """panoptic_fusetrack.py:400-469 (tracking block of simple_test_bboxes), device-resident: the comprehensive scores, their
+        row arg-max, the greedy assignment (undo branch included) and the memory update are kernels; ids and the new memory size
+        stay on the device (`self._mem_count`) until the frame's end-of-frame read. `self._mem_n` = memory size known to the host
+        (it sizes the launches). -> (ids int32 [K] device, comp_scores or None)"""
         lib = hip.load()
         dev = emb.device
-        K = det_bboxes.size(0)
+        K, E = det_bboxes.size(0), emb.size(1)
         comp_scores = None
-        if is_first or self.prev_bboxes is None:
-            det_obj_ids = np.arange(K)
-            self.prev_bboxes = det_bboxes.clone(); self.prev_emb = emb; self.prev_det_labels = det_labels.clone()
+        if self._mem_count is None or self._mem_count.device != dev:
+            self._mem_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        ids = ws.get('trk.ids', (MaskROI.KCAP,), dtype=torch.int32, zero=False)
+        if is_first or self.prev_emb is None or self._mem_n == 0:
+            self._mem_n = 0
+            self._mem_reserve(dev, 2 * K, E)
+            ids[:K].copy_(torch.arange(K, dtype=torch.int32, device=dev))
+            self.prev_emb[:K] = emb; self.prev_bboxes[:K] = det_bboxes[:, :4]; self.prev_det_labels[:K] = det_labels
+            self._mem_n = K
+            self._mem_count.fill_(K)
         else:
-            M = self.prev_bboxes.size(0)
-            match_score = self.track_head.match_scores(emb, self.prev_emb, ws).contiguous()
+            M = self._mem_n
+            self._mem_reserve(dev, M + K, E)
+            pb = self.prev_bboxes[:M]
+            match_score = self.track_head.match_scores(emb, self.prev_emb[:M], ws).contiguous()
             match_logprob = torch.empty_like(match_score)
             hip.check(lib.vps_row_softmax(hip.ptr(match_score), hip.ptr(match_logprob), K, M + 1, 1, hip.stream_ptr()), 'log_softmax')
-            label_delta = (self.prev_det_labels == det_labels.view(-1, 1)).float()
-            db = det_bboxes.contiguous(); pb = self.prev_bboxes.contiguous()
+            label_delta = (self.prev_det_labels[:M] == det_labels.view(-1, 1)).float()
+            db = det_bboxes.contiguous()
             bbox_ious = torch.empty(K, M, device=dev)
             hip.check(lib.vps_bbox_overlaps(hip.ptr(db), db.shape[1], K, hip.ptr(pb), pb.shape[1], M, hip.ptr(bbox_ious),
                                             hip.stream_ptr()), 'vps_bbox_overlaps')
             comp_scores = self.track_head.compute_comp_scores(match_logprob, cls_prob.view(-1, 1), bbox_ious, label_delta,
-                                                              add_bbox_dummy=True)
-            match_likelihood, match_ids = torch.max(comp_scores, dim=1)
-            match_likelihood = match_likelihood.cpu().numpy()
-            match_ids = match_ids.cpu().numpy().astype(np.int32)
-            det_obj_ids = np.ones((K), dtype=np.int32) * (-1)
-            best_match_scores = np.ones((M)) * (-100)
-            best_match_ids = np.ones((M), dtype=np.int32) * (-1)
-            mem = M
-            adds, sets = [], {}
-            for idx, match_id in enumerate(match_ids):          # panoptic_fusetrack.py:434-459
-                if match_id == 0:
-                    det_obj_ids[idx] = mem; mem += 1; adds.append(idx)
-                else:
-                    obj_id = match_id - 1
-                    if match_likelihood[idx] > best_match_scores[obj_id]:
-                        det_obj_ids[idx] = obj_id
-                        if best_match_ids[obj_id] >= 0:
-                            det_obj_ids[best_match_ids[obj_id]] = -1
-                        best_match_scores[obj_id] = match_likelihood[idx]
-                        best_match_ids[obj_id] = idx
-                        sets[obj_id] = idx                   # the last assignment wins, as in the in-place updates
-            for idx, oid in enumerate(det_obj_ids):              # :463-469
-                if oid >= 0:
-                    continue
-                det_obj_ids[idx] = mem; mem += 1; adds.append(idx)
-            # apply the memory updates in one batch (same final state as the reference's sequential torch.cat's)
-            if sets:
-                oid = torch.tensor(list(sets.keys()), dtype=torch.long, device=dev)
-                src = torch.tensor(list(sets.values()), dtype=torch.long, device=dev)
-                self.prev_emb[oid] = emb[src]; self.prev_bboxes[oid] = det_bboxes[src]
-            if adds:
-                a = torch.tensor(adds, dtype=torch.long, device=dev)
-                self.prev_emb = torch.cat((self.prev_emb, emb[a]), dim=0)
-                self.prev_bboxes = torch.cat((self.prev_bboxes, det_bboxes[a]), dim=0)
-                self.prev_det_labels = torch.cat((self.prev_det_labels, det_labels[a]), dim=0)
-        return det_obj_ids, comp_scores
+                                                              add_bbox_dummy=True).contiguous()
+            scratch = ws.get('trk.scratch', (self.prev_emb.size(0) + 3 * MaskROI.KCAP,), dtype=torch.int32, zero=False)
+            embc = emb.contiguous(); lab = det_labels.contiguous()
+            hip.check(lib.vps_track_assign(hip.ptr(comp_scores), K, M, hip.ptr(embc), E, hip.ptr(db), db.shape[1], hip.ptr(lab),
+                                           hip.ptr(self.prev_emb), hip.ptr(self.prev_bboxes), hip.ptr(self.prev_det_labels),
+                                           hip.ptr(scratch), hip.ptr(ids), hip.ptr(self._mem_count), hip.stream_ptr()), 'vps_track_assign')
+            self._mem_n = None           # unknown to the host until the end-of-frame read (simple_test / track_assign) delivers it
+        return ids, comp_scores
 
     # ------------------------------------------------------------------------------------------------------
-    def simple_test_bboxes(self, x, meta, proposals, im_info, is_first, ws, inject=None, defer_tracking=False):
+    def simple_test_bboxes(self, x, meta, proposals, im_info, is_first, ws, inject=None, defer_tracking=False, nprop=None):
         """panoptic_fusetrack.py:358-471"""
         lib = hip.load()
         dev = proposals.device
@@ -480,18 +509,16 @@ class PanopticFuseTrack(HipModule):
         cls_prob_all = torch.empty_like(cls_score)
         hip.check(lib.vps_row_softmax(hip.ptr(cls_score), hip.ptr(cls_prob_all), cls_score.shape[0], cls_score.shape[1], 0,
                                       hip.stream_ptr()), 'vps_row_softmax')
-        cls_prob, det_rois, cls_idx = self.mask_roi_panoptic(rois, bbox_pred, cls_prob_all, im_info, ws)
+        cls_prob, det_rois, cls_idx = self.mask_roi_panoptic(rois, bbox_pred, cls_prob_all, im_info, ws, nprop)
         det_labels = cls_idx - 1
-        det_rois = det_rois.contiguous()
         det_roi_feats = self.bbox_roi_extractor.run(x, det_rois)
         det_bboxes = det_rois[:, 1:]
-        K = det_bboxes.size(0)
-        det_obj_ids, comp_scores, emb = None, None, None
+        ids_dev, comp_scores, emb = None, None, None
         if self.with_track:
             emb = self.track_head.embed(det_roi_feats, ws)
         if self.with_track and not defer_tracking:
-            det_obj_ids, comp_scores = self._assign_ids(det_bboxes, det_labels, cls_prob, emb, is_first, ws)
-        return dict(det_bboxes=det_bboxes, det_labels=det_labels, det_obj_ids=det_obj_ids, cls_score=cls_score,
+            ids_dev, comp_scores = self._assign_ids(det_bboxes, det_labels, cls_prob, emb, is_first, ws)
+        return dict(det_bboxes=det_bboxes, det_labels=det_labels, det_obj_ids=None, ids_dev=ids_dev, cls_score=cls_score,
                     bbox_pred=bbox_pred, cls_prob=cls_prob, det_rois=det_rois, cls_idx=cls_idx, comp_scores=comp_scores,
                     det_roi_feats=det_roi_feats, emb=emb)
 

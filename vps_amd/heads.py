@@ -144,7 +144,8 @@ class RPNHead(HipModule):
 
     def run(self, levels, ws, img_shape, cfg, tag='rpn.'):
         """rpn_head.py:30-35 (forward_single per level) + anchor_head.py:198-223 + rpn_head.py:55-104.
-        Returns proposals [<=max_num, 5] on the device. NHWC makes the reference's permute(1,2,0) a no-op."""
+        Returns (proposals [max_num, 5], n int32 [1]) on the device: rows >= n are zero (fewer than max_num boxes survived —
+        tiny images only). NHWC makes the reference's permute(1,2,0) a no-op."""
         dev = levels[0].t.device
         self.ensure_packed(dev)
         lib = hip.load()
@@ -152,7 +153,7 @@ class RPNHead(HipModule):
         nlv = len(levels)
         nms_pre = cfg.nms_pre
         boxes = ws.get(tag + 'boxes', (nlv, nms_pre, 5), zero=True)
-        counts, orders = [], []
+        counts = []
         for li, x in enumerate(levels):
             t = self._conv(x, ws=ws, name='%sconv%d' % (tag, li))
             cls = self._cls(t, ws=ws, name='%scls%d' % (tag, li))
@@ -163,9 +164,8 @@ class RPNHead(HipModule):
             if nms_pre > 0 and scores.shape[0] > nms_pre:
                 scores, topk = scores.topk(nms_pre)
                 deltas = deltas[topk, :]; anchors = anchors[topk, :]
-                order = None
             else:
-                # the reference hands unsorted boxes to nms(), which sorts internally and returns ascending indices
+                # the reference hands unsorted boxes to nms(), which sorts them by score internally
                 scores, order = torch.sort(scores, descending=True, stable=True)
                 deltas = deltas[order, :]; anchors = anchors[order, :]
             n = scores.shape[0]
@@ -173,29 +173,27 @@ class RPNHead(HipModule):
             hip.check(lib.vps_delta2bbox(hip.ptr(anchors), hip.ptr(deltas), hip.ptr(scores), hip.ptr(boxes[li]), n,
                                          self.target_stds[0], self.target_stds[1], self.target_stds[2], self.target_stds[3],
                                          float(img_shape[0]), float(img_shape[1]), hip.stream_ptr()), 'vps_delta2bbox')
-            counts.append(n); orders.append(order)
+            counts.append(n)
             self._keepalive = (deltas, anchors, scores)
         assert cfg.min_bbox_size == 0 and not cfg.nms_across_levels
         cb = (nms_pre + 63) // 64
-        counts_d = torch.tensor(counts, dtype=torch.int32, device=dev)
+        ck = (tuple(counts), str(dev))
+        if getattr(self, '_counts_key', None) != ck:          # uploaded once per frame size
+            self._counts_d, self._counts_key = torch.tensor(counts, dtype=torch.int32, device=dev), ck
+        counts_d = self._counts_d
         mask = ws.get(tag + 'nmsmask', (nlv * nms_pre * cb,), dtype=torch.int64, zero=False)
         keep = ws.get(tag + 'keep', (nlv, nms_pre), dtype=torch.int32, zero=False)
         nkeep = ws.get(tag + 'nkeep', (nlv,), dtype=torch.int32)
         hip.check(lib.vps_nms_batched(hip.ptr(boxes), nlv, nms_pre, hip.ptr(counts_d), float(cfg.nms_thr), hip.ptr(mask),
                                       hip.ptr(keep), hip.ptr(nkeep), hip.stream_ptr()), 'vps_nms_batched')
-        nk = nkeep.cpu().tolist()                     # the one host sync of the RPN (5 ints)
-        mlvl = []
-        for li in range(nlv):
-            k = keep[li, :nk[li]].long()
-            if orders[li] is not None:                # back to the original (anchor) order, ascending (nms_kernel.cu:127-130)
-                orig = torch.sort(orders[li][k])[0]
-                inv = torch.empty_like(orders[li]); inv[orders[li]] = torch.arange(orders[li].numel(), device=dev)
-                k = inv[orig]
-            mlvl.append(boxes[li][k][:cfg.nms_post])
-        props = torch.cat(mlvl, 0)
-        num = min(cfg.max_num, props.shape[0])
-        _, topk = props[:, 4].topk(num)
-        return props[topk, :]
+        # rpn_head.py:94-104 on the device (no host sync): kept boxes of every level, `[:nms_post]` each, the `max_num` best by
+        # score. The per-level order the reference returns them in (ascending anchor index for the levels it hands to nms()
+        # unsorted) is irrelevant behind the final top-k by score.
+        props = ws.get(tag + 'props', (cfg.max_num, 5), zero=False)
+        nprops = ws.get(tag + 'nprops', (1,), dtype=torch.int32, zero=False)
+        hip.check(lib.vps_rpn_collect(hip.ptr(boxes), hip.ptr(keep), hip.ptr(nkeep), nlv, nms_pre, int(cfg.nms_post), int(cfg.max_num),
+                                      hip.ptr(props), hip.ptr(nprops), hip.stream_ptr()), 'vps_rpn_collect')
+        return props, nprops
 
 
 # ------------------------------------------------------------------------------------------------------------

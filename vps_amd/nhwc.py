@@ -62,6 +62,14 @@ def check_f16_range(device):
                                       'fp16 split is not fp32-grade there. Run this checkpoint with VPS_PREC=bf16x6 (or f32).')
 
 
+def raise_f16_range(device, word):
+    """`word`: the value of f16_status(device) the caller fetched with its own end-of-frame read. Non-zero: clear and raise."""
+    if word:
+        f16_status(device).zero_()
+        raise hip.VpsHipError('f16x3: an activation exceeded the fp16 range (|x| > 65504) in a convolution of this frame; the '
+                              'fp16 split is not fp32-grade there. Run this checkpoint with VPS_PREC=bf16x6 (or f32).')
+
+
 class FMap:
     __slots__ = ('t', 'C', 'coff')
 

@@ -1,9 +1,10 @@
 """UPSNet-style panoptic head logic of the FuseTrack detector: MaskROI, MaskRemoval, SegTerm + logit combine.
 
 Mirrors mmdet/models/utils/mask_roi.py:24-147, utils/mask_removal.py:23-92, utils/unary_logits.py:70-108 and
-detectors/panoptic_fusetrack.py:585-597. The order-defining host logic (numpy argsort, score cap, per-box
-sequential overlap rule) stays on the host exactly as in the reference because it defines instance ids; every
-per-pixel / per-box-pair computation runs in HIP kernels, and nothing of size [k, H, W] is ever materialised.
+detectors/panoptic_fusetrack.py:585-597. The order-defining logic of MaskROI (decode, threshold, sort, NMS, cap) and the
+kept-list / instance-table construction run on the device (csrc/head_ops.hip); the host sees the detection list once per
+frame (it needs K to size the launches behind it) and builds MaskRemoval's walk from that copy. Every per-pixel / per-box-pair
+computation runs in HIP kernels, and nothing of size [k, H, W] is ever materialised.
 """
 import ctypes
 
@@ -14,40 +15,16 @@ import torch.nn as nn
 from . import hip
 
 
-def _bbox_transform(boxes, deltas, weights):
-    """utils/upsnet/bbox/bbox_transform.py:290-330 (numpy, dtype of deltas)"""
-    if boxes.shape[0] == 0:
-        return np.zeros((0, deltas.shape[1]), dtype=deltas.dtype)
-    boxes = boxes.astype(deltas.dtype, copy=False)
-    widths = boxes[:, 2] - boxes[:, 0] + 1.0
-    heights = boxes[:, 3] - boxes[:, 1] + 1.0
-    ctr_x = boxes[:, 0] + 0.5 * widths
-    ctr_y = boxes[:, 1] + 0.5 * heights
-    wx, wy, ww, wh = weights
-    dx = deltas[:, 0::4] / wx; dy = deltas[:, 1::4] / wy
-    dw = np.minimum(deltas[:, 2::4] / ww, np.log(1000. / 16.)); dh = np.minimum(deltas[:, 3::4] / wh, np.log(1000. / 16.))
-    pcx = dx * widths[:, np.newaxis] + ctr_x[:, np.newaxis]
-    pcy = dy * heights[:, np.newaxis] + ctr_y[:, np.newaxis]
-    pw = np.exp(dw) * widths[:, np.newaxis]; ph = np.exp(dh) * heights[:, np.newaxis]
-    out = np.zeros(deltas.shape, dtype=deltas.dtype)
-    out[:, 0::4] = pcx - 0.5 * pw; out[:, 1::4] = pcy - 0.5 * ph
-    out[:, 2::4] = pcx + 0.5 * pw - 1; out[:, 3::4] = pcy + 0.5 * ph - 1
-    return out
-
-
-def _clip_boxes(boxes, im_shape):
-    """bbox_transform.py:45-60"""
-    boxes[:, 0::4] = np.maximum(np.minimum(boxes[:, 0::4], im_shape[1] - 1), 0)
-    boxes[:, 1::4] = np.maximum(np.minimum(boxes[:, 1::4], im_shape[0] - 1), 0)
-    boxes[:, 2::4] = np.maximum(np.minimum(boxes[:, 2::4], im_shape[1] - 1), 0)
-    boxes[:, 3::4] = np.maximum(np.minimum(boxes[:, 3::4], im_shape[0] - 1), 0)
-    return boxes
-
-
 class MaskROI(nn.Module):
     """utils/mask_roi.py:24-147 for the configured mode (class_agnostic=True, clip_boxes=True,
     bbox_class_agnostic=False). `bbox_reg_weights` / `max_det` are the UPSNet yaml-config values
-    (tools/config/config.py:47,169) that the reference reads from a global."""
+    (tools/config/config.py:47,169) that the reference reads from a global.
+
+    Device-resident (csrc/head_ops.hip): decode + clip + threshold + descending sort (`vps_maskroi_select`), the class-agnostic
+    NMS (`vps_nms_batched`, count read on the device), the `max_det` cap / dummy row (`vps_maskroi_finish`). The host reads the
+    finished list ONCE (8 KB: the frame's one mid-frame stream drain) — it needs K to size the launches that follow."""
+
+    KCAP = 256        # rows of the result buffer; the uint8 panoptic map names at most 244 instances anyway
 
     def __init__(self, clip_boxes, bbox_class_agnostic, top_n, num_classes, nms_thresh, score_thresh,
                  class_agnostic=False, bbox_reg_weights=(10., 10., 5., 5.), max_det=100):
@@ -56,81 +33,85 @@ class MaskROI(nn.Module):
         self.top_n, self.num_classes = top_n, num_classes
         self.nms_thresh, self.score_thresh = nms_thresh, score_thresh
         self.bbox_reg_weights, self.max_det = tuple(bbox_reg_weights), max_det
+        self.last = None
 
-    def forward(self, bottom_rois, bbox_delta, cls_prob, im_info, ws=None):
+    def forward(self, bottom_rois, bbox_delta, cls_prob, im_info, ws, n_valid=None):
         """-> (cls_prob [K], rois [K,5], cls_idx [K] in 1..num_classes-1) device tensors; one dummy row when empty
-        (mask_roi.py:136-142)."""
-        dev = bottom_rois.device
-        rois_np = bottom_rois.detach().cpu().numpy()
-        delta_np = bbox_delta.detach().cpu().numpy()
-        prob_cpu = cls_prob.detach().cpu()
-        prob_np = prob_cpu.numpy()
-        n = rois_np.shape[0]
-        nc = self.num_classes
-        proposal = _bbox_transform(rois_np[:, 1:], delta_np, self.bbox_reg_weights)
-        proposal = _clip_boxes(proposal, im_info[0, :2])
-        # class-agnostic flattening: candidate q = roi*(nc-1) + (cls-1)  (mask_roi.py:60-74)
-        cand_prob = prob_np[:, 1:].reshape(-1)
-        cand_box = proposal.reshape((n, -1, 4))[:, 1:, :].reshape((-1, 4))
-        cand_cls = np.tile(np.arange(1, nc), n)
-        inds = np.where(cand_prob > self.score_thresh)[0]
-        scores_j = cand_prob[inds]
-        dets_j = np.hstack((cand_box[inds], scores_j[:, np.newaxis])).astype(np.float32)
-        if len(dets_j) == 0:
-            return (torch.ones(1, device=dev), torch.zeros(1, 5, device=dev), torch.zeros(1, dtype=torch.long, device=dev))
-        # gpu_nms (utils/upsnet/nms/gpu_nms.pyx:23-38): order = scores.argsort()[::-1]; device bitmask + device greedy
-        order = dets_j[:, 4].argsort()[::-1]
-        sorted_dets = np.ascontiguousarray(dets_j[order, :])
-        m = sorted_dets.shape[0]
+        (mask_roi.py:136-142). `self.last` keeps the host copy of the list (rows [K,8]: 0,x1,y1,x2,y2,score,class,candidate) and
+        the device row buffer for the stages behind it. n_valid: device int32 [1], rows of `bottom_rois` that exist."""
         lib = hip.load()
-        bd = torch.from_numpy(sorted_dets).to(dev)
-        cb = (m + 63) // 64
-        mask = torch.empty(m * cb, dtype=torch.int64, device=dev)
-        keep = torch.empty(m, dtype=torch.int32, device=dev)
-        nkeep = torch.zeros(1, dtype=torch.int32, device=dev)
-        cnt = torch.tensor([m], dtype=torch.int32, device=dev)
-        hip.check(lib.vps_nms_batched(hip.ptr(bd), 1, m, hip.ptr(cnt), float(self.nms_thresh), hip.ptr(mask), hip.ptr(keep),
-                                      hip.ptr(nkeep), hip.stream_ptr()), 'vps_nms_batched')
-        nk = int(nkeep.item())
-        keep_np = order[keep[:nk].cpu().numpy().astype(np.int64)]     # list(order[keep])
-        nms_dets = dets_j[keep_np, :]
-        sel = inds[keep_np]
-        if self.max_det > 0 and len(nms_dets) > self.max_det:     # mask_roi.py:106-121
-            image_thresh = np.sort(nms_dets[:, -1])[-self.max_det]
-            k2 = np.where(nms_dets[:, -1] >= image_thresh)[0]
-            nms_dets = nms_dets[k2, :]; sel = sel[k2]
-        boxes = np.zeros((nms_dets.shape[0], 5))
-        boxes[:, 1:] = nms_dets[:, :-1]
-        scores_th = prob_cpu[:, 1:].contiguous().view(-1)[torch.from_numpy(sel).long()]   # from the torch tensor (mask_roi.py:94)
-        return (scores_th.to(dev), torch.from_numpy(boxes).float().to(dev), torch.from_numpy(cand_cls[sel]).long().to(dev))
+        dev = bottom_rois.device
+        n, nc = bottom_rois.shape[0], self.num_classes
+        cap = min(n * (nc - 1), 8192)
+        rois = bottom_rois.contiguous(); delta = bbox_delta.contiguous(); prob = cls_prob.contiguous()
+        assert delta.shape == (n, 4 * nc) and prob.shape == (n, nc), (delta.shape, prob.shape)
+        dets = ws.get('mroi.dets', (cap, 5), zero=False)
+        cand = ws.get('mroi.cand', (cap,), dtype=torch.int32, zero=False)
+        mcnt = ws.get('mroi.m', (4,), dtype=torch.int32, zero=False)
+        cb = (cap + 63) // 64
+        mask = ws.get('mroi.mask', (cap * cb,), dtype=torch.int64, zero=False)
+        keep = ws.get('mroi.keep', (cap,), dtype=torch.int32, zero=False)
+        nkeep = ws.get('mroi.nkeep', (1,), dtype=torch.int32, zero=False)
+        res = ws.get('mroi.res', (8 + 8 * self.KCAP,), zero=False)
+        sp = hip.stream_ptr()
+        wts = (ctypes.c_float * 4)(*self.bbox_reg_weights)
+        hip.check(lib.vps_maskroi_select(hip.ptr(rois), hip.ptr(delta), hip.ptr(prob), n, hip.ptr(n_valid), nc, float(self.score_thresh), wts,
+                                         float(im_info[0, 0]), float(im_info[0, 1]), hip.ptr(dets), hip.ptr(cand), hip.ptr(mcnt), sp),
+                  'vps_maskroi_select')
+        hip.check(lib.vps_nms_batched(hip.ptr(dets), 1, cap, hip.ptr(mcnt), float(self.nms_thresh), hip.ptr(mask), hip.ptr(keep),
+                                      hip.ptr(nkeep), sp), 'vps_nms_batched')
+        hip.check(lib.vps_maskroi_finish(hip.ptr(dets), hip.ptr(cand), hip.ptr(mcnt), hip.ptr(keep), hip.ptr(nkeep), nc, int(self.max_det),
+                                         self.KCAP, hip.ptr(res), sp), 'vps_maskroi_finish')
+        host = res.cpu().numpy()                  # the ONE mid-frame host sync of the detection branch
+        K, status = int(host[0]), int(host[3])
+        if status & 1:
+            raise hip.VpsHipError('MaskROI: more than 8192 candidates above score_thresh')
+        if status & 2:
+            raise hip.VpsHipError('MaskROI: more than %d detections after the max_det cap (tied scores)' % self.KCAP)
+        rows_h = host[8:8 + 8 * K].reshape(K, 8).copy()
+        rows_d = res[8:8 + 8 * K].view(K, 8)
+        self.last = dict(K=K, rows_h=rows_h, rows_d=rows_d, ncand=int(host[1]), npost=int(host[2]), nrois=int(host[4]))
+        return rows_d[:, 5].contiguous(), rows_d[:, 0:5].contiguous(), rows_d[:, 6].long()
 
 
 class MaskRemoval(nn.Module):
     """utils/mask_removal.py:23-92. The box loop order (numpy argsort of cls_prob, reversed) and the skip rule are the
     reference's; the cv2.resize + binarise + overlap count + occupancy update of each box run on the device with the
-    keep decision taken on the device; boxes are batched into dependency levels (2 launches per level) and there is ONE host sync."""
+    keep decision taken on the device; boxes are batched into dependency levels (2 launches per level). The walk order and the
+    levels are built on the host from the detection list MaskROI already fetched (no D2H here), the kept flags STAY on the
+    device: `vps_pan_instances` turns them into the kept list + the instance table of the combine kernel."""
 
     def __init__(self, fraction_threshold=0.3):
         super().__init__()
         self.fraction_threshold = fraction_threshold
 
-    def forward(self, mask_rois, cls_prob, mask_prob, cls_idx, im_shape, ws):
-        """mask_rois [n,4], cls_prob [n], mask_prob [n,S,S] (device), cls_idx [n] -> (keep_inds np.int64 in score order,
-        ref_boxes np.int32 [n,4] truncated boxes, masks_valid). When nothing is kept the reference returns keep_inds=[0]
-        with an all-zero mask_energy (mask_removal.py:51-53,89-91): masks_valid=False."""
+    def forward(self, rows_h, rows_d, mask_prob, im_shape, ws, class_mapping):
+        """rows_h / rows_d: the detection list (host numpy / device, [n,8]: 0,x1,y1,x2,y2,score,class,q), mask_prob [n,S,S] device.
+        -> dict(inst: device vps_pan_inst table, kinfo: device int32 [4] = (k, masks_valid, status, -), keep: device int32 [n])"""
         dev = mask_prob.device
         H, W = int(im_shape[0]), int(im_shape[1])
-        rois_np = mask_rois.detach().cpu().numpy()
-        prob_np = cls_prob.detach().cpu().numpy()
-        cls_np = cls_idx.detach().cpu().numpy()
-        n = rois_np.shape[0]
+        lib = hip.load()
+        sp = hip.stream_ptr()
+        n = rows_h.shape[0]
         S = mask_prob.shape[-1]
+        inst = ws.get('mr.inst', (MaskROI.KCAP * ctypes.sizeof(hip.PanInst),), dtype=torch.uint8, zero=False)
+        keep_d = ws.get('mr.keep', (MaskROI.KCAP,), dtype=torch.int32, zero=False)
+        kinfo = ws.get('mr.kinfo', (4,), dtype=torch.int32, zero=False)
+        kinfo.zero_()
+        nclass = max(class_mapping) + 1
+        cm = (ctypes.c_int32 * nclass)(*[int(class_mapping.get(c, 0)) for c in range(nclass)])
+        rois_np = rows_h[:, 1:5]
+        prob_np = rows_h[:, 5]
+        cls_np = rows_h[:, 6].astype(np.int64)
+        cls0 = cls_np - 1
+        out = dict(inst=inst, kinfo=kinfo, keep=keep_d)
+        if n == 1 and cls0[0] == -1:
+            # the dummy row (mask_removal.py:51-53): keep = [0], all-zero mask logits
+            hip.check(lib.vps_pan_instances(None, None, hip.ptr(rows_d), None, 1, cm, nclass, hip.ptr(inst), hip.ptr(keep_d), hip.ptr(kinfo), sp),
+                      'vps_pan_instances')
+            return out
         sorted_inds = np.argsort(prob_np)[::-1]
         ref_boxes = rois_np.astype(np.int32)
-        cls0 = cls_np - 1
-        if n == 1 and cls0[0] == -1:
-            return np.array([0], dtype=np.int64), ref_boxes, False
-        lib = hip.load()
         ncls = int(np.max(cls_np))
         occ = ws.get('mr.occ', (ncls, H, W), dtype=torch.uint8, zero=False)
         flags = ws.get('mr.flags', (max(n, 1),), dtype=torch.int32, zero=False)
@@ -150,56 +131,33 @@ class MaskRemoval(nn.Module):
         nlv = int(lvl.max()) + 1
         starts = np.searchsorted(lvl[order], np.arange(nlv + 1))
         host = np.concatenate([sb.reshape(-1), sc, sorted_inds, order]).astype(np.int32)
-        meta = torch.from_numpy(host).to(dev)
+        meta = torch.from_numpy(host).to(dev, non_blocking=True)
         counts = ws.get('mr.counts', (max(n, 1), 2), dtype=torch.int32, zero=False)
         occ.zero_(); counts.zero_()
         base = meta.data_ptr()
-        sp = hip.stream_ptr()
         for l in range(nlv):
             a, b = int(starts[l]), int(starts[l + 1])
             hip.check(lib.vps_mask_level(hip.ptr(mp), S, ctypes.c_void_p(base), ctypes.c_void_p(base + 16 * n),
                                          ctypes.c_void_p(base + 20 * n), ctypes.c_void_p(base + 24 * n + 4 * a), b - a,
                                          int(area[order[a:b]].max()), H, W, hip.ptr(occ), hip.ptr(counts),
                                          float(self.fraction_threshold), hip.ptr(flags), sp), 'vps_mask_level')
-        fl = flags[:n].cpu().numpy()
-        keep_inds = [int(sorted_inds[pos]) for pos in range(n) if fl[pos]]
-        if len(keep_inds) == 0:
-            return np.array([0], dtype=np.int64), ref_boxes, False
-        return np.array(keep_inds, dtype=np.int64), ref_boxes, True
+        hip.check(lib.vps_pan_instances(ctypes.c_void_p(base + 20 * n), hip.ptr(flags), hip.ptr(rows_d), ctypes.c_void_p(base), n, cm, nclass,
+                                        hip.ptr(inst), hip.ptr(keep_d), hip.ptr(kinfo), sp), 'vps_pan_instances')
+        out['_meta'] = meta          # keeps the uploaded walk alive until the kernels have run
+        return out
 
 
-def panoptic_combine(fcn_score, mask_rois_np, cls_idx_np, ref_boxes, keep_inds, mask_prob, class_mapping, num_stuff,
-                     num_classes, out_hw, ws, masks_valid=True):
+def panoptic_combine(fcn_score, removal, mask_prob, num_stuff, num_classes, out_hw, ws):
     """SegTerm (utils/unary_logits.py:81-108 with boxes = mask_rois*4.0*0.25) + logit concat + argmax
-    (panoptic_fusetrack.py:588-597), fused. keep_inds index the ORIGINAL detections; instance j of the panoptic map
-    is keep_inds[j]. masks_valid=False: the pasted mask logits are all zero (MaskRemoval kept nothing)."""
+    (panoptic_fusetrack.py:588-597), fused. `removal`: MaskRemoval's output — the instance table and its length live on the
+    device (instance j of the panoptic map is kept detection j)."""
     H, W = out_hw
-    dev = fcn_score.t.device
-    k = len(keep_inds)
-    inst = (hip.PanInst * max(k, 1))()
-    for j, i in enumerate(keep_inds):
-        b = (mask_rois_np[i].astype(np.float32) * np.float32(4.0)) * (1 / 4.0)     # float32 * 4.0, then numpy * 0.25
-        it = inst[j]
-        c = int(cls_idx_np[i])
-        if c == 0:
-            it.sx0 = it.sy0 = it.sx1 = it.sy1 = 0; it.seg_ch = 0
-        else:
-            it.sy0 = int(b[1]); it.sy1 = int(b[3].round() + 1)
-            it.sx0 = int(b[0]); it.sx1 = int(b[2].round() + 1)
-            it.seg_ch = int(class_mapping[c])
-        if not masks_valid:
-            it.bx1, it.by1, it.bx2, it.by2 = 0, 0, -1, -1     # empty paste region
-        else:
-            rb = ref_boxes[i]
-            it.bx1, it.by1, it.bx2, it.by2 = int(rb[0]), int(rb[1]), int(rb[2]), int(rb[3])
-        it.mask_idx = int(i)
-    inst_d = torch.frombuffer(bytearray(bytes(inst)), dtype=torch.uint8).to(dev)
     pan = ws.get('pan.out', (1, H, W), dtype=torch.uint8, zero=False)
     sem = ws.get('sem.out', (1, H, W), dtype=torch.uint8, zero=False)
     S = mask_prob.shape[-1]
-    rc = hip.load().vps_panoptic_combine(fcn_score.ptr(), fcn_score.ld, fcn_score.H, fcn_score.W, num_classes, num_stuff,
-                                         hip.ptr(inst_d), k, hip.ptr(mask_prob), S, hip.ptr(pan), hip.ptr(sem), H, W,
-                                         hip.stream_ptr())
-    hip.check(rc, 'vps_panoptic_combine(k=%d, S=%d, mask_prob %s, score %dx%d ld %d, out %dx%d, classes %d/%d)' % (
-        k, S, tuple(mask_prob.shape), fcn_score.H, fcn_score.W, fcn_score.ld, H, W, num_stuff, num_classes))
+    rc = hip.load().vps_panoptic_combine_dev(fcn_score.ptr(), fcn_score.ld, fcn_score.H, fcn_score.W, num_classes, num_stuff,
+                                             hip.ptr(removal['inst']), hip.ptr(removal['kinfo']), hip.ptr(mask_prob), S, hip.ptr(pan),
+                                             hip.ptr(sem), H, W, hip.stream_ptr())
+    hip.check(rc, 'vps_panoptic_combine_dev(S=%d, mask_prob %s, score %dx%d ld %d, out %dx%d, classes %d/%d)' % (
+        S, tuple(mask_prob.shape), fcn_score.H, fcn_score.W, fcn_score.ld, H, W, num_stuff, num_classes))
     return pan, sem
