@@ -4,6 +4,7 @@ container, with the import shims of ref_shims.py (third-party stubs + oracle-bac
 
     python tests/golden/make_golden.py [fusetrack|fuse|track]   # needs /root/reference; writes tests/golden/<variant>_clip.npz
     python tests/golden/make_golden.py fullsize                  # 2 frames at 1024x2048 -> tests/golden/fusetrack_fullsize.npz
+    python tests/golden/make_golden.py fullsize_sep              # 4 frames at 1024x2048, fitted well-separated box classifier (strict fixture)
     python tests/golden/make_golden.py r101                      # ResNet-101 variant (BASELINE config 5), 2 frames at 128x256
     python tests/golden/make_golden.py seed1                     # FuseTrack, weight / clip seed 1, 3 frames at 128x192
 
@@ -29,7 +30,7 @@ H, W, NFRAMES, SEED = 128, 256, 3, 0
 FULL_H, FULL_W, FULL_NFRAMES = 1024, 2048, 2          # `fullsize`: the BASELINE frame size (configs[1]), FuseTrack only
 
 
-def main(variant='fusetrack', H=H, W=W, NFRAMES=NFRAMES, out_name=None, full=False, depth=None, seed=SEED):
+def main(variant='fusetrack', H=H, W=W, NFRAMES=NFRAMES, out_name=None, full=False, depth=None, seed=SEED, separated=False):
     """full=True: the 1024x2048 golden — same quantities, the dense stage tensors strided so the file stays a few MB"""
     import ref_shims
     mods = ref_shims.install()
@@ -44,7 +45,8 @@ def main(variant='fusetrack', H=H, W=W, NFRAMES=NFRAMES, out_name=None, full=Fal
     # --- shapes of every parameter, from OUR containers; the reference model must expose exactly the same keys ---
     ours = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
     shapes = {k: tuple(v.shape) for k, v in ours.state_dict().items()}
-    sd = synth.synth_state_dict(shapes, seed)
+    # separated=True: the box classification layer fitted by search_separated.py (every listing decision has a margin)
+    sd = synth.synth_state_dict(shapes, seed, overrides=synth.separated_overrides(os.path.join(HERE, 'separated_fc_cls.npz')) if separated else None)
 
     # --- the reference detector; its __init__ loads FlowNet2 from cwd/work_dirs/flownet/FlowNet2_checkpoint.pth.tar ---
     tmp = tempfile.mkdtemp(prefix='vps_golden_')
@@ -145,6 +147,9 @@ if __name__ == '__main__':
     v = sys.argv[1] if len(sys.argv) > 1 else 'fusetrack'
     if v == 'fullsize':
         main('fusetrack', FULL_H, FULL_W, FULL_NFRAMES, 'fusetrack_fullsize.npz', full=True)
+    elif v == 'fullsize_sep':
+        # the STRICT full-size fixture: 4 frames at 1024x2048, well-separated detections (tests/golden/separated_fc_cls.npz)
+        main('fusetrack', FULL_H, FULL_W, 4, 'fusetrack_fullsize_sep.npz', full=True, separated=True)
     elif v == 'r101':
         main('fusetrack', H, W, 2, 'fusetrack_r101_clip.npz', depth=101)
     elif v == 'seed1':

@@ -6,8 +6,11 @@ Tolerances: stage tensors within `tol` of max|ref|; semantic map <
 the golden frame found with the same class and a score within 2e-3 (at most `max_unmatched` per frame on either side: the
 synthetic heads put up to 100 detections into a narrow score band, a borderline one may flip); track ids of the matched detections
 equal up to ONE relabelling over the clip (`id_map` / `id_back` are carried from frame to frame by the caller); the panoptic map is
-compared pixel by pixel only when the listing is identical (instance numbers are listing positions)."""
+compared pixel by pixel when the listing is identical, and as a map of (stuff class | instance class + relabelled track id)
+when it is not (instance numbers are listing positions)."""
 import numpy as np
+
+NSTUFF = 11      # panoptic ids below are stuff classes, NSTUFF + j = j-th listed instance
 
 
 def relmax(got, ref):
@@ -50,4 +53,17 @@ def compare_frame(rec, g, p, id_map, id_back, tol=2e-3, max_unmatched=1, pan_tol
     if rep['strict']:
         rep['pan_mismatch'] = float((np.asarray(rec['panoptic_outputs']).reshape(-1) != g[p + 'panoptic_outputs'].reshape(-1)).mean())
         assert rep['pan_mismatch'] < pan_tol, rep
+    else:
+        # the listing differs (instance numbers are listing positions): compare the maps as maps of (stuff class | instance class,
+        # track id through the clip's relabelling). An unmatched detection occupies pixels the other side gives to something else.
+        def labels(pan, cls, ids, relabel):
+            lut = np.arange(256, dtype=np.int64)
+            for j in range(len(cls)):
+                i = int(ids[j])
+                lut[NSTUFF + j] = 1000 + 100000 * int(cls[j]) + (relabel.get(i, 50000 + i) if relabel is not None else i)
+            return lut[np.asarray(pan).astype(np.int64).reshape(-1)]
+        mine = labels(rec['panoptic_outputs'], oc, oid, {k: v for k, v in id_map.items() if k != 'violations'})
+        gold = labels(g[p + 'panoptic_outputs'], gc, gid, None)
+        rep['pan_mismatch'] = float((mine != gold).mean())
+        assert rep['pan_mismatch'] < (pan_tol if rep['unmatched'] == (0, 0) else 2e-2), rep
     return rep

@@ -137,7 +137,7 @@ def test_semantic_head_hands_groupnorm_sums_to_the_unsplit_deformable_layers(mon
     monkeypatch.setattr(_RecordingLib, '_vps_groupnorm_apply', lambda self, *a: log.append(('apply', a[-3].value, a[-2])) or 0, raising=False)
     monkeypatch.setattr(_RecordingLib, '_vps_groupnorm_relu', lambda self, *a: log.append(('relu', a[-2].value)) or 0, raising=False)
     monkeypatch.setattr(nhwc, 'DEFAULT_PREC', nhwc.PREC_NAMES[prec])
-    monkeypatch.setattr(nhwc, 'f16_status', lambda device: torch.zeros(1, dtype=torch.int32))
+    monkeypatch.setattr(nhwc, 'f16_status', lambda device: torch.zeros(nhwc.F16_SLOTS, dtype=torch.int32))
     cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', 'fusetrack.py'))
     head = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg).panopticFPN
     ws = nhwc.Workspace(torch.device('cpu'))

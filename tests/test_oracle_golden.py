@@ -179,3 +179,58 @@ def test_fullsize_oracle_matches_reference(full_gold, full_oracle_run, t):
     pan = r['panoptic_outputs'].numpy().astype(np.uint8); sem = r['fcn_outputs'].numpy().astype(np.uint8)
     assert (pan != g[p + 'panoptic_outputs']).mean() < 1e-4
     assert (sem != g[p + 'fcn_outputs']).mean() < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the STRICT full-size fixture (tests/golden/make_golden.py fullsize_sep: 4 frames at 1024x2048, box classification layer of
+# tests/golden/separated_fc_cls.npz — every listing decision has a margin, tests/golden/search_separated.py). The oracle must
+# reproduce the REAL reference's listing exactly. Frames 0-1 by default (~70 s of CPU), all four with VPS_SLOW_TESTS=1.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def sep_gold():
+    return np.load(os.path.join(ROOT, 'tests', 'golden', 'fusetrack_fullsize_sep.npz'))
+
+
+@pytest.fixture(scope='module')
+def sep_oracle_run(sep_gold):
+    H, W, n, seed = [int(v) for v in sep_gold['meta']]
+    assert (H, W, n) == (1024, 2048, 4)
+    n = n if os.environ.get('VPS_SLOW_TESTS') else 2
+    cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', 'fusetrack.py'))
+    model = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    over = synth.separated_overrides(os.path.join(ROOT, 'tests', 'golden', 'separated_fc_cls.npz'))
+    sd = synth.synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, seed, overrides=over)
+    o = FuseTrackOracle(sd)
+    frames = synth.synth_clip(H, W, n, seed)
+    res, prev = [], None
+    with torch.no_grad():
+        for t in range(n):
+            r = o.simple_test(frames[t], frames[t - 1] if t else frames[0], t == 0, ref_x=prev, return_aux=True)
+            prev = r['pre_neck']                       # frame t's FPN output is frame t+1's reference feature (same computation)
+            r.pop('mask_score', None)
+            res.append(r)
+    return res
+
+
+def test_separated_fixture_margins_are_what_the_file_says():
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'separated_fc_cls.npz'))
+    m = z['margins']                                   # per frame: detections, |score - 0.6| min, adjacent score gap min, |IoU - 0.5| min
+    assert m.shape == (4, 4) and (m[:, 0] >= 3).all()
+    assert m[:, 1].min() >= 4e-2 and m[:, 2].min() >= 2.4e-2 and m[:, 3].min() >= 0.4
+
+
+def test_separated_fullsize_oracle_matches_reference(sep_gold, sep_oracle_run):
+    g = sep_gold
+    s1, s2, c5 = [int(v) for v in g['strides']]
+    for t, r in enumerate(sep_oracle_run):
+        p = 'f%d.' % t
+        _close(r['flow_full'][0][:, ::s1, ::s1].numpy(), g[p + 'flow_full'])
+        _close(r['feats'][0][0, :8, ::s2, ::s2].numpy(), g[p + 'neck_out_p2'], 2e-4, 2e-4)
+        _close(r['det']['cls_score'].numpy(), g[p + 'cls_score'], 5e-4, 5e-4)
+        assert np.array_equal(r['panoptic_cls_inds'].numpy(), g[p + 'panoptic_cls_inds'])
+        assert np.array_equal(r['panoptic_det_labels'].numpy(), g[p + 'panoptic_det_labels'])
+        assert np.array_equal(r['panoptic_det_obj_ids'].numpy(), g[p + 'panoptic_det_obj_ids'])
+        _close(r['panoptic_cls_prob'].numpy(), g[p + 'panoptic_cls_prob'], 1e-5, 1e-6)
+        pan = r['panoptic_outputs'].numpy().astype(np.uint8); sem = r['fcn_outputs'].numpy().astype(np.uint8)
+        assert (pan != g[p + 'panoptic_outputs']).mean() < 1e-4
+        assert (sem != g[p + 'fcn_outputs']).mean() < 1e-4

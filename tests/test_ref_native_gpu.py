@@ -129,7 +129,8 @@ def test_deform_conv_three_way(dev, cin, cout, H, W):
     ref = (w.to(dev).reshape(cout, -1).double() @ col.double()).float().view(1, cout, H, W)   # deform_conv_cuda.cpp:233-236 (addmm_)
     ora = O.deform_conv(x, off, w, 1, 1)
     _close(ora, ref, 2e-5, 'deform_conv oracle vs reference im2col + GEMM')
-    for prec, tol, name in ((hip.PREC_F32, 2e-5, 'f32'), (hip.PREC_BF16X6, 2e-5, 'bf16x6')):
+    # all three fp32-grade modes, the benchmarked f16x3 included (its 22-bit operands: 3 * 2^-22 per product, same bound as the others)
+    for prec, tol, name in ((hip.PREC_F32, 2e-5, 'f32'), (hip.PREC_BF16X6, 2e-5, 'bf16x6'), (hip.PREC_F16X3, 2e-5, 'f16x3')):
         pc = nhwc.PackedConv(w, None, None, 1, 1, device=dev, deform=True, prec=prec)
         out = pc(nhwc.from_nchw(xd), ws=nhwc.Workspace(dev), name='o', offset=nhwc.from_nchw(od)).to_nchw()
         _close(out, ref, tol, 'deform_conv libvpship (%s) vs reference im2col + GEMM' % name)

@@ -46,9 +46,12 @@ def test_second_seed_clip_matches_reference_golden(dev, prec):
         rec['fpn_p5'] = a['levels'][3].to_nchw().cpu().numpy()[0]
         rec['neck_out_p2'] = a['neck_out'][0].to_nchw().cpu().numpy()[0, :8]
         rec['fcn_score'] = a['fcn_score'].to_nchw().cpu().numpy()[0]
-        # 24 576 pixels with ~55 instances: a handful of boundary pixels whose two best logits are closer than the 2.5e-4 stage error
-        # flip (measured in f16x3: frame 0 identical listing, 4 pixels; frame 1 identical listing, 38 pixels = 0.15 %)
-        rep = compare_frame(rec, g, 'f%d.' % t, id_map, id_back, max_unmatched=3, pan_tol=1e-2, max_id_violations=2)
+        # Tolerances from a complete measured run (profiles/r03_seed1_report.txt: 3 frames x 3 modes): every listing strictly
+        # identical, no unmatched detection, no id violation; panoptic map 0 / 4 / 38 differing pixels of 24 576 (<= 0.155 %) — the
+        # SAME pixels in the exact-fp32 kernels and in both split modes, i.e. boundary pixels whose two best logits differ by less
+        # than the 2.5e-4 stage error, not an arithmetic-mode effect. Hence: strict listing, pan_tol 2.5e-3.
+        rep = compare_frame(rec, g, 'f%d.' % t, id_map, id_back, max_unmatched=0, pan_tol=2.5e-3, max_id_violations=0)
+        assert rep['strict'], rep
         print('[seed 1, %s] frame %d: %s' % (prec, t, rep))
         os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
         with open(os.path.join(ROOT, 'gpurun_out', 'seed1_report.txt'), 'a') as f:

@@ -181,6 +181,44 @@ class PanopticFuseTrack(HipModule):
     @torch.no_grad()
     def simple_test(self, img, img_meta, proposals=None, rescale=False, ref_img=None, inject=None, ref_feature=None,
                     defer_tracking=False, prefetch=None):
+        """panoptic_fusetrack.py:502-606 (see `_simple_test_once`). f16x3 arithmetic only: a layer that staged an activation
+        beyond the fp16 range (|x| > 65504; reported per layer through vps_conv_desc.status, read with the frame's end-of-frame
+        read) is switched to bf16x6 for good and the frame is computed again from the state it started in — no exception, no
+        wrong result; `nhwc.F16_FALLBACKS` counts the switched layers."""
+        guard = nhwc._F16_NEXT[0] > 1 and img.is_cuda
+        for attempt in range(4):
+            snap = self._tracker_snapshot() if guard and self.with_track and not defer_tracking else None
+            out = self._simple_test_once(img, img_meta, proposals, rescale, ref_img, inject, ref_feature, defer_tracking,
+                                         prefetch if attempt == 0 else None)
+            if out is not None:
+                return out
+            nhwc.f16_fallback(img.device)
+            # back to the state the frame started in: tracker memory, no cached / prefetched features (they may come from the
+            # layer that overflowed: the reference-frame features are recomputed like the reference does)
+            if snap is not None:
+                self._tracker_restore(snap)
+            pf, self._pf = self._pf, None
+            if pf is not None:
+                pf['event'].synchronize()
+            self._cache = None
+            self._handoff = None
+        raise hip.VpsHipError('f16x3: the frame still overflows the fp16 range after three rounds of per-layer bf16x6 fallback')
+
+    def _tracker_snapshot(self):
+        if self.prev_emb is None or not self._mem_n:
+            return (0, None, None, None)
+        M = self._mem_n
+        return (M, self.prev_emb[:M].clone(), self.prev_bboxes[:M].clone(), self.prev_det_labels[:M].clone())
+
+    def _tracker_restore(self, snap):
+        M, emb, box, lab = snap
+        self._mem_n = M
+        if M:
+            self.prev_emb[:M] = emb; self.prev_bboxes[:M] = box; self.prev_det_labels[:M] = lab
+            self._mem_count.fill_(M)
+
+    def _simple_test_once(self, img, img_meta, proposals=None, rescale=False, ref_img=None, inject=None, ref_feature=None,
+                          defer_tracking=False, prefetch=None):
         """panoptic_fusetrack.py:502-606. `inject` (tests/bench only): dict overriding head inputs at the operator
         boundaries of SURVEY §8d config 2 (fcn_score, proposals, cls_score, bbox_pred, mask_score).
         ref_feature / defer_tracking (clip_shard.py): gathered pre-neck feature of the previous frame received from the
@@ -351,13 +389,14 @@ class PanopticFuseTrack(HipModule):
         if has_ids:
             tail[8 + MaskROI.KCAP:8 + MaskROI.KCAP + K].copy_(det['ids_dev'][:K])
             tail[4:5].copy_(self._mem_count)
-        tail[5:6].copy_(nhwc.f16_status(dev))
+        tail[5:6].copy_(nhwc.f16_status(dev).amax().view(1))
         th = tail.cpu().numpy()
+        if th[5]:
+            return None              # f16x3: a layer overflowed the fp16 range -> simple_test falls back and recomputes the frame
         k, masks_valid, cstat = int(th[0]), bool(th[1]), int(th[2])
         if cstat & 1:
             raise hip.VpsHipError('vps_panoptic_combine: %d kept instances do not fit the uint8 panoptic map (at most %d)'
                                   % (k, 255 - self.panopticFPN.num_stuff_classes))
-        nhwc.raise_f16_range(dev, int(th[5]))          # f16x3 only (0 otherwise): every convolution of the frame has run by now
         keep_inds = th[8:8 + k].astype(np.int64)
         det_obj_ids = None
         if has_ids:

@@ -8,6 +8,7 @@ zero (buffers come from `Workspace.get(..., zero=True)` once and pads are never 
 import ctypes
 import math
 import os
+import weakref
 from ctypes import c_float, c_int, c_void_p
 
 import torch
@@ -27,19 +28,47 @@ PREC_NAMES = _PREC_NAMES
 # number of 16-bit weight planes / MFMA products per fp32 product of each split mode
 _PLANES = {hip.PREC_BF16: 1, hip.PREC_BF16X3: 2, hip.PREC_BF16X6: 3, hip.PREC_F16X3: 3}
 MFMA_PRODUCTS = {hip.PREC_F32: 1, hip.PREC_BF16: 1, hip.PREC_BF16X3: 3, hip.PREC_BF16X6: 6, hip.PREC_F16X3: 3}
-# f16x3: one device word per device; a conv launch ORs bit 0 into it when it staged an activation beyond the fp16 range
+# f16x3 range report: one device word PER LAYER (vps_conv_desc.status points at the layer's slot); a conv launch ORs bit 0 into it
+# when it staged an activation beyond the fp16 range. Slot 0 is shared by anonymous layers (per-frame GEMMs built from device
+# matrices), every persistent PackedConv owns one of the others and can fall back to bf16x6 on its own (`f16_fallback`).
+F16_SLOTS = 4096
 _F16_STATUS = {}
+_F16_LAYERS = {}          # slot -> weakref of the PackedConv that owns it
+_F16_NEXT = [1]
+F16_FALLBACKS = [0]       # layers switched to bf16x6 so far (reported by bench.py)
 
 
 def f16_status(device):
-    """the range-report word of the f16x3 mode on `device` (int32 tensor [1]); PanopticFuseTrack checks and clears it every frame"""
+    """the range-report words of the f16x3 mode on `device` (int32 tensor [F16_SLOTS]); PanopticFuseTrack reads their maximum with
+    its end-of-frame read"""
     device = torch.device(device)
     key = (device.type, device.index if device.index is not None else (torch.cuda.current_device() if device.type == 'cuda' else 0))
     t = _F16_STATUS.get(key)
     if t is None:
-        t = torch.zeros(1, dtype=torch.int32, device=device)
+        t = torch.zeros(F16_SLOTS, dtype=torch.int32, device=device)
         _F16_STATUS[key] = t
     return t
+
+
+def f16_fallback(device):
+    """f16x3: the layers that reported an activation beyond the fp16 range switch to bf16x6 (three bf16 planes, the fp32 exponent
+    range: no range restriction, same fp32-grade error) FOR GOOD, the report is cleared. -> number of layers switched. An
+    anonymous layer (slot 0) cannot switch: raises. The caller re-runs whatever those launches produced."""
+    st = f16_status(device)
+    flagged = torch.nonzero(st).flatten().cpu().tolist()
+    st.zero_()
+    n = 0
+    for slot in flagged:
+        ref = _F16_LAYERS.get(slot)
+        pc = ref() if ref is not None else None
+        if pc is None:
+            raise hip.VpsHipError('f16x3: an activation exceeded the fp16 range (|x| > 65504) in a per-frame GEMM that has no bf16x6 '
+                                  'fallback. Run this checkpoint with VPS_PREC=bf16x6 (or f32).')
+        n += pc.use_fallback(device)
+    F16_FALLBACKS[0] += n
+    return n
+
+
 if os.environ.get('VPS_PREC', 'f32') not in _PREC_NAMES:
     raise ValueError('VPS_PREC must be one of %s' % sorted(_PREC_NAMES))
 DEFAULT_PREC = _PREC_NAMES[os.environ.get('VPS_PREC', 'f32')]
@@ -52,22 +81,14 @@ GN_REP = 32   # copies of the GroupNorm sums a conv epilogue spreads its atomics
 
 def check_f16_range(device):
     """f16x3 mode: raise if a convolution since the last check staged an activation beyond the fp16 range (|x| > 65504): its result
-    is not fp32-grade (fp16 overflow). Call at a point where the stream is already drained (one 4-byte D2H)."""
+    is not fp32-grade (fp16 overflow). For callers of single layers; the detector falls back per layer instead (`f16_fallback`)."""
     device = torch.device(device)
     for key, t in _F16_STATUS.items():
         if key[0] == device.type and (device.index is None or key[1] == device.index):
-            if int(t.item()) != 0:
+            if int(t.amax().item()) != 0:
                 t.zero_()
-                raise hip.VpsHipError('f16x3: an activation exceeded the fp16 range (|x| > 65504) in a convolution of this frame; the '
-                                      'fp16 split is not fp32-grade there. Run this checkpoint with VPS_PREC=bf16x6 (or f32).')
-
-
-def raise_f16_range(device, word):
-    """`word`: the value of f16_status(device) the caller fetched with its own end-of-frame read. Non-zero: clear and raise."""
-    if word:
-        f16_status(device).zero_()
-        raise hip.VpsHipError('f16x3: an activation exceeded the fp16 range (|x| > 65504) in a convolution of this frame; the '
-                              'fp16 split is not fp32-grade there. Run this checkpoint with VPS_PREC=bf16x6 (or f32).')
+                raise hip.VpsHipError('f16x3: an activation exceeded the fp16 range (|x| > 65504) in a convolution; the fp16 split is '
+                                      'not fp32-grade there. Run it with prec=bf16x6 (or f32).')
 
 
 class FMap:
@@ -209,6 +230,16 @@ class PackedConv:
         for c, b in enumerate(blocks):
             packed[c, :O, :K] = b
         wscale = self._set_weights(packed, device)
+        self._fb = None
+        self.f16_slot = 0
+        if self.prec == hip.PREC_F16X3:
+            # what `use_fallback` needs to re-pack this layer for bf16x6: the fp32 weights in packed layout (host) — the epilogue
+            # scale without the f16x3 pre-scaling is restored below
+            self.f16_slot = _F16_NEXT[0] if _F16_NEXT[0] < F16_SLOTS else 0
+            if self.f16_slot:
+                _F16_NEXT[0] += 1
+                _F16_LAYERS[self.f16_slot] = weakref.ref(self)
+                self._fb = dict(packed=packed)
         # epilogue: y = acc*scale + shift
         scale = torch.ones(O)
         shift = torch.zeros(O) if bias is None else bias.detach().float().cpu().clone()
@@ -221,12 +252,26 @@ class PackedConv:
             self.has_scale = True
         else:
             self.has_scale = False
+        if self._fb is not None:
+            self._fb.update(scale=scale.clone() if self.has_scale else None, has_scale=self.has_scale)
         if wscale is not None:
             # f16x3: the weights were pre-scaled per output channel by a power of two; undone exactly here
             scale = scale * wscale[:O].cpu()
             self.has_scale = True
         self.scale = scale.to(device) if self.has_scale else None
         self.shift = shift.to(device) if (bias is not None or bn is not None) else None
+
+    def use_fallback(self, device):
+        """f16x3 -> bf16x6 for this layer, for good (an activation beyond the fp16 range was staged here). -> 1 if switched"""
+        if self.prec != hip.PREC_F16X3 or self._fb is None:
+            return 0
+        fb, self._fb = self._fb, None
+        self.prec = hip.PREC_BF16X6
+        self._set_weights(fb['packed'], device)
+        self.has_scale = fb['has_scale']
+        self.scale = fb['scale'].to(device) if fb['has_scale'] else None
+        self.__dict__.pop('_dcache', None)
+        return 1
 
     def _pack_taps(self, wt, cin_pad):
         """wt [O, ntap, I] -> [O, K] in the kernel's k order (see vps_conv_desc.korder)"""
@@ -292,6 +337,7 @@ class PackedConv:
         w = torch.zeros(1, self.cout_pad, D, dtype=torch.float32, device=mat.device)
         w[0, :M] = mat
         self.prec = DEFAULT_PREC if prec is None else prec
+        self._fb, self.f16_slot = None, 0
         wscale = self._set_weights(w, mat.device)
         self.scale, self.shift, self.has_scale = None, None, False
         if wscale is not None:
@@ -357,7 +403,7 @@ class PackedConv:
             d.offset = offset.t.data_ptr(); d.off_ld = offset.ld
         d.tile_n = self.tile_n
         if self.prec == hip.PREC_F16X3:
-            d.status = f16_status(x.t.device).data_ptr()
+            d.status = f16_status(x.t.device).data_ptr() + 4 * getattr(self, 'f16_slot', 0)
         # split-K for launches that cannot fill 256 CUs
         M = x.N * d.Qh * d.Qw
         tiles = ((M + 127) // 128) * (self.cout_pad // self.tile_n) * d.nclass
