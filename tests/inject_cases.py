@@ -17,11 +17,12 @@ def _gen(seed):
     return torch.Generator().manual_seed(seed)
 
 
-def make_inject(seed, K, tie_from=None, masks='random', jitter_of=None, extra_same_object=0, extra_offset=0.6):
+def make_inject(seed, K, tie_from=None, masks='random', jitter_of=None, extra_same_object=0, extra_offset=0.6, extra_first=False):
     """-> dict of injected tensors producing (about) K candidates above the 0.6 score threshold.
     tie_from: candidates tie_from.. share one score (the max_det cap `>=` keeps all of them, mask_roi.py:106-121).
     jitter_of: a previous inject dict — object boxes are that frame's boxes moved by a few pixels (same classes) so the tracker
-    has matches; extra_same_object: additional detections of the same class overlapping object 0..n (forces the undo branch)."""
+    has matches; extra_same_object: additional detections of the same class overlapping object 0..n; extra_first: each of them scores
+    0.05 above its object (listed first: forces the undo branch)."""
     g = _gen(seed)
     ncell = max(K + extra_same_object, 1)
     gy = max(int(math.sqrt(ncell / 2.0)), 1); gx = (ncell + gy - 1) // gy
@@ -57,6 +58,12 @@ def make_inject(seed, K, tie_from=None, masks='random', jitter_of=None, extra_sa
     props[:, 0::2] = props[:, 0::2].clamp(0, W - 1); props[:, 1::2] = props[:, 1::2].clamp(0, H - 1)
     # scores: distinct probabilities in (0.62, 0.99) for the objects, background rows below the threshold
     p = 0.62 + 0.37 * torch.rand(NPROP, generator=g)
+    if extra_first:
+        # every extra detection is listed BEFORE the object it competes with (higher class score, weaker match): it takes the memory
+        # entry first and is undone when the object itself comes (panoptic_fusetrack.py:446-453)
+        for j in range(extra_same_object):
+            p[j] = 0.62 + 0.28 * float(p[j] - 0.62) / 0.37
+            p[K + j] = p[j] + 0.05
     if tie_from is not None:
         # one class for the tied rows: the softmax of identical logit vectors is bitwise identical, whatever the summation order
         cls[tie_from:nobj] = cls[tie_from]
@@ -81,7 +88,7 @@ CASES = {
     # name: [(frame inject kwargs)...]  — frame 1's boxes jitter frame 0's
     'K32_M32': [dict(K=32), dict(K=32, jitter=True)],
     'K100_M100': [dict(K=100), dict(K=100, jitter=True)],
-    'K32_M100_undo': [dict(K=100), dict(K=32, jitter=True, extra_same_object=12)],
+    'K32_M100_undo': [dict(K=100), dict(K=32, jitter=True, extra_same_object=12, extra_first=True)],
     'K100_M32': [dict(K=32), dict(K=100, jitter=True)],
     'ties_at_cap_M0': [dict(K=130, tie_from=90)],
     'dummy_row_M32': [dict(K=32), dict(K=0)],
@@ -104,7 +111,8 @@ def frames_of(case):
     out, prev = [], None
     for t, spec in enumerate(CASES[case]):
         inj = make_inject(100 * t + 7, spec['K'], spec.get('tie_from'), spec.get('masks', 'random'),
-                          prev if spec.get('jitter') else None, spec.get('extra_same_object', 0), spec.get('extra_offset', 0.6))
+                          prev if spec.get('jitter') else None, spec.get('extra_same_object', 0), spec.get('extra_offset', 0.6),
+                          spec.get('extra_first', False))
         prev = inj
         out.append(inj)
     return out

@@ -452,6 +452,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 template <class T> using vec8 = T __attribute__((ext_vector_type(8)));
 template <class T> using vec4 = T __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer-addressed 16-byte loads (buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen): the 128-bit resource and the scalar offset
+// live in SGPRs, the lane contributes a 32-bit byte offset - no 64-bit VALU address arithmetic per load - and a lane whose offset
+// is >= the buffer's byte count reads ZEROS: out-of-image taps and channel pads are masked by the address (one select on the
+// offset) instead of a select per loaded element. Tensors are < 4 GiB (checked by vps_conv2d).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, const unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+template <class V>
+__device__ __forceinline__ V buffer_load16(const __amdgpu_buffer_rsrc_t r, const unsigned voff, const unsigned soff) {
+    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
 constexpr int LDS_LDH = 32;   // 16-bit elements per LDS row = 64 bytes, no padding: the four 16-byte chunks of a row are
                               // XOR-swizzled with (row>>2)&3, which makes the 8-byte/16-byte staging writes of two consecutive
                               // rows cover all 32 banks once and the 16-lane groups of the fragment ds_read_b128 hit 16
@@ -498,13 +511,27 @@ __device__ __forceinline__ f32x16 split_mfma(const vec8<typename Split<MODE>::el
 template <int MODE>
 __device__ __forceinline__ void split_act(const f32x4 v, vec4<typename Split<MODE>::elem> (&out)[Split<MODE>::NSA], float& amax) {
     if constexpr (MODE == VPS_PREC_F16X3) {
+        // per PAIR of elements: one packed RNE conversion for h0 (v_cvt_pk_f16_f32), the exact residual x - h0 as one mixed-precision
+        // FMA reading the fp16 half directly (v_fma_mix_f32: no convert-back, no separate subtract; the compiler does not form it), the exact scaling by 2^11, one
+        // packed conversion for h1, one three-operand maximum for the range report: 3.5 instead of ~6 VALU instructions per staged
+        // element. Same values bit for bit as h0 = fp16(x), h1 = fp16((x - h0) * 2^11).
+        typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const _Float16 h0 = (_Float16)v[e];
-            out[0][e] = h0;
-            out[1][e] = (_Float16)((v[e] - (float)h0) * 2048.f);
+        for (int e = 0; e < 4; e += 2) {
+            const f32x2 x = {v[e], v[e + 1]};
+            const h16x2 h0 = __builtin_convertvector(x, h16x2);
+            // x - h0 with the fp16 half read in place (src0 = low / high half of the packed register, op_sel on src0 only)
+            float r0, r1;
+            const unsigned h0bits = __builtin_bit_cast(unsigned, h0);
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h0bits), "v"(x[0]));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h0bits), "v"(x[1]));
+            const f32x2 r = {r0 * 2048.f, r1 * 2048.f};
+            const h16x2 h1 = __builtin_convertvector(r, h16x2);
+            out[0][e] = h0[0]; out[0][e + 1] = h0[1];
+            out[1][e] = h1[0]; out[1][e + 1] = h1[1];
+            amax = fmaxf(fmaxf(amax, fabsf(x[0])), fabsf(x[1]));
         }
-        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     } else {
         f32x4 r = v;
 #pragma unroll
@@ -797,7 +824,10 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
 //     wave keeps the matrix pipe, the LDS pipe and the memory pipe busy at the same time instead of in turns.
 // The loop body is branch-free: loads past the last k-step are clamped / masked rather than skipped.
 // ================================================================================================
-template <int TM, int TN, int WAVES_M, int WAVES_N, int MODE>
+// TAPMAJOR: k = tap * cin_pad + ci (small channel counts: the first layers) - the (tap, channel) of a staged group differs per
+// thread. Otherwise one k-step = one (32-channel chunk, tap), the same for all threads (chunk-major order; a 1x1 layer is its
+// one-tap case), and the step's part of the byte offset is scalar.
+template <int TM, int TN, int WAVES_M, int WAVES_N, int MODE, bool TAPMAJOR>
 __global__ __launch_bounds__(256, 2)
 void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_m, const int tiles_n,
                             const int ksteps_per_split) {
@@ -850,63 +880,70 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
     // k ordering as in the kernels above. korder 1: one k-step = one (32-channel chunk, tap), the same for all threads.
     const int korder = d.korder, ntap = KH * KW;
     int ky = 0, kx = 0, chunk = 0, astep = kstep0;   // state of the next activation tile to load
-    if (korder == 1) {
+    if constexpr (!TAPMAJOR) {
         chunk = kstep0 / ntap;
         const int tap = kstep0 - chunk * ntap;
         ky = tap / KW;
         kx = tap - ky * KW;
     }
+    (void)korder;
 
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
     // B fragments of this wave: 32-column blocks nb0 .. nb0+TN-1, k-slab ks, plane p
     const int nbt = d.cout_pad >> 5, kst = d.kpad >> 4;
+    // weights: one buffer resource over the whole split-weight tensor; this wave's fragment base is a SCALAR byte offset, the lane
+    // adds its 16 bytes -> `buffer_load_dwordx4 v, v_lane, s[rsrc], s_off offen`: the per-load address arithmetic is scalar
     const size_t wplane = (size_t)d.nclass * nbt * kst * 512;
-    const elem_t* __restrict__ wfrag = reinterpret_cast<const elem_t*>(d.w_split) +
-        ((size_t)(cls * nbt + tile_n * (BN / 32) + wn * TN) * kst + 2 * (size_t)kstep0) * 512 + lane * 8;
+    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(d.w_split, (unsigned)(wplane * NSB * sizeof(elem_t)));
+    const unsigned wbase = (unsigned)((((size_t)(cls * nbt + tile_n * (BN / 32) + wn * TN) * kst + 2 * (size_t)kstep0) * 512) * sizeof(elem_t));
+    const unsigned wlane = (unsigned)lane * 16u;
+    // activations: one resource over the input tensor; a staged row contributes pix * in_ld * 4 (+ channel bytes) as a 32-bit offset
+    const unsigned in_bytes = (unsigned)((size_t)d.N * H * W * d.in_ld * sizeof(float));
+    const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(d.in, in_bytes);
+    const unsigned ld4 = (unsigned)d.in_ld * 4u;
+    const unsigned acoff = (unsigned)(d.in_coff + k4 * 4) * 4u;      // this thread's 4-channel group inside a 32-channel chunk
+    unsigned rowoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rowoff[i] = (unsigned)(ri[i].pixbase + ri[i].iy0 * W + ri[i].ix0) * ld4 + acoff;   // wraps for rows outside: masked
 
     // activation tiles in flight in registers: tile T waits in slot T & 1 from the step T-3 that requested it until step T-1
     // stages it (two full k-steps: a 3-product k-step is 24 MFMAs = 0.4 us, shorter than a trip to HBM)
     f32x4 areg[2][4];
-    unsigned aok[2] = {0u, 0u};   // bit i: staged row i is inside the image and inside the channel range
     x8 bnext[2][NSB][TN];
     float amax = 0.f;
 
     // next activation tile -> registers of `slot` (sequential: every call advances the k state by one step)
     auto load_A = [&](const int slot) {
-        int kyc, kxc, cic;
+        int kyc, kxc;
+        unsigned stepoff;      // byte offset = rowoff[i] (k-invariant, per thread) + the step's (tap, channel) part
         bool kv;
-        if (korder == 1) {
+        if constexpr (!TAPMAJOR) {
+            // scalar state: the step's offset is an SGPR, one vector add per staged row
             kyc = ky; kxc = kx;
-            cic = chunk * BK + k4 * 4;
-            kv = cic < cin_pad;
+            kv = chunk * BK + k4 * 4 < cin_pad;
+            stepoff = (unsigned)(kyc * W + kxc) * ld4 + (unsigned)chunk * (BK * 4u);
             if (++kx == KW) {
                 kx = 0;
                 if (++ky == KH) { ky = 0; ++chunk; }
             }
-        } else if (ntap == 1) {
-            kyc = 0; kxc = 0;
-            cic = astep * BK + k4 * 4;
-            kv = cic < cin_pad;
         } else {
-            // tap-major with a small channel count (the first layers)
             const int kk = astep * BK + k4 * 4;
             const int tap = kk / cin_pad;
-            cic = kk - tap * cin_pad;
+            const int cic = kk - tap * cin_pad;
             kyc = tap / KW;
             kxc = tap - kyc * KW;
             kv = tap < ntap;
+            stepoff = (unsigned)(kyc * W + kxc) * ld4 + (unsigned)(cic - k4 * 4) * 4u;
         }
         ++astep;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            // branch-free: out-of-image / out-of-range taps read pixel 0 (always mapped) and are zeroed when staged
+            // out-of-image / out-of-range taps: offset beyond the buffer -> the load returns zeros (no branch, no select on the data)
             const int iy = ri[i].iy0 + kyc, ix = ri[i].ix0 + kxc;
             const bool ok = kv && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            const int pix = ri[i].pixbase + (ok ? iy * W + ix : 0);
-            areg[slot][i] = *reinterpret_cast<const f32x4*>(d.in + ((size_t)pix * d.in_ld + d.in_coff + (ok ? cic : 0)));
-            aok[slot] = (aok[slot] & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+            areg[slot][i] = buffer_load16<f32x4>(arsrc, ok ? rowoff[i] + stepoff : 0xFFFFFFF0u, 0u);
         }
     };
 
@@ -914,14 +951,13 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
     auto load_B = [&](int step, int m, int p) {
 #pragma unroll
         for (int b = 0; b < TN; ++b)
-            bnext[m][p][b] = *reinterpret_cast<const x8*>(wfrag + (size_t)p * wplane + ((size_t)b * kst + 2 * step + m) * 512);
+            bnext[m][p][b] = buffer_load16<x8>(wrsrc, wlane, wbase + (unsigned)(((size_t)p * wplane + ((size_t)b * kst + 2 * step + m) * 512) * sizeof(elem_t)));
     };
 
     // split staged row i of `slot` and write it into activation buffer `buf`
     auto store_A = [&](int i, int buf, const int slot) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         x4 sp[NSA];
-        split_act<MODE>(((aok[slot] >> i) & 1u) ? areg[slot][i] : z, sp, amax);
+        split_act<MODE>(areg[slot][i], sp, amax);
         const int row = r0 + 32 * i;
 #pragma unroll
         for (int p = 0; p < NSA; ++p)
@@ -1969,6 +2005,7 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
         else { if (d.KH == 3) VPS_HALO_LAUNCH(VPS_PREC_BF16X6, 3); else VPS_HALO_LAUNCH(VPS_PREC_BF16X6, 2); }
 #undef VPS_HALO_LAUNCH
     } else {
+    const bool tapmajor = d.korder == 0 && ntap > 1;      // small channel counts; a 1x1 layer is the one-tap case of the chunk-major order
 #define VPS_CONV_LAUNCH(KERNEL)                                                                              \
     hipLaunchKernelGGL((KERNEL), dim3((unsigned)nblk), dim3(256), 0, s, d, M, tiles_m, tiles_n, per_split)
     if (d.prec == VPS_PREC_F32) {
@@ -1976,16 +2013,20 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
         else VPS_CONV_LAUNCH((conv_mfma_f32_kernel<TM, TN, WAVES_M, WAVES_N, false>));
     } else if (d.prec == VPS_PREC_BF16) {
         if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16, true>));
-        else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16>));
+        else if (tapmajor) VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16, true>));
+        else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16, false>));
     } else if (d.prec == VPS_PREC_BF16X3) {
         if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X3, true>));
-        else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X3>));
+        else if (tapmajor) VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X3, true>));
+        else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X3, false>));
     } else if (d.prec == VPS_PREC_F16X3) {
         if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_F16X3, true>));
-        else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_F16X3>));
+        else if (tapmajor) VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_F16X3, true>));
+        else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_F16X3, false>));
     } else {
         if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X6, true>));
-        else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X6>));
+        else if (tapmajor) VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X6, true>));
+        else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X6, false>));
     }
 #undef VPS_CONV_LAUNCH
     }
@@ -2019,6 +2060,8 @@ extern "C" int vps_conv2d(const vps_conv_desc* dp, void* stream) {
     if (d.ksplit < 1 || (d.ksplit > 1 && !d.ws)) return VPS_EARG(8);
     if (d.offset && (d.nclass != 1 || d.off_ld < 2 * d.KH * d.KW || d.KH * d.KW > 9 || d.H > 65535 || d.W > 65535)) return VPS_EARG(9);
     if (((uintptr_t)d.in & 15) || ((uintptr_t)d.w & 15) || ((uintptr_t)d.w_split & 15)) return VPS_EARG(10);
+    // the split-operand kernels address the input and the weights through 32-bit buffer offsets
+    if (d.prec != VPS_PREC_F32 && (size_t)d.N * d.H * d.W * d.in_ld * sizeof(float) >= 0xFFFFFFF0ull) return VPS_EARG(16);
     // GroupNorm sums in the epilogue: the deformable kernel of the split-operand modes only, unsplit, float4 stores, groups of 4 | 8 | 16 ...
     if (d.gn_stats && (!d.offset || d.prec == VPS_PREC_F32 || d.ksplit != 1 || d.gn_rep < 1 || (d.gn_rep & (d.gn_rep - 1)) || (d.gn_cpg != 4 && (d.gn_cpg < 8 || (d.gn_cpg & 7))) || d.cout % d.gn_cpg ||
                        ((d.cout | d.out_ld | d.out_coff) & 3) || ((uintptr_t)d.out & 15) || d.res || ((uintptr_t)d.gn_stats & 7)))
