@@ -46,7 +46,7 @@ def _canonical(scores, rois, keep, pano, bbox_ids, pan_map, first_frame):
     rank = np.empty_like(perm); rank[perm] = np.arange(len(perm))
     kc = rank[keep]                                                                   # canonical rank of every kept detection
     ko = np.argsort(kc, kind='stable')                                                # kept list in canonical order
-    pano = {k: np.asarray(v)[ko] for k, v in pano.items()}
+    pano = {k: np.asarray(pano[k])[ko] for k in ('panoptic_cls_inds', 'panoptic_cls_prob', 'panoptic_det_labels', 'panoptic_det_obj_ids')}
     if first_frame and 'panoptic_det_obj_ids' in pano:                                # ids = positions in the first frame
         pano['panoptic_det_obj_ids'] = rank[pano['panoptic_det_obj_ids']]
     inv = np.empty_like(ko); inv[ko] = np.arange(len(ko))

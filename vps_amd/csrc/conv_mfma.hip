@@ -521,12 +521,10 @@ __device__ __forceinline__ void split_act(const f32x4 v, vec4<typename Split<MOD
         for (int e = 0; e < 4; e += 2) {
             const f32x2 x = {v[e], v[e + 1]};
             const h16x2 h0 = __builtin_convertvector(x, h16x2);
-            // x - h0 with the fp16 half read in place (src0 = low / high half of the packed register, op_sel on src0 only)
-            float r0, r1;
-            const unsigned h0bits = __builtin_bit_cast(unsigned, h0);
-            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h0bits), "v"(x[0]));
-            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h0bits), "v"(x[1]));
-            const f32x2 r = {r0 * 2048.f, r1 * 2048.f};
+            // (x - h0) * 2^11 as ONE mixed-precision FMA per element on top of the scaling multiply: fma(h0, -2^11, x * 2^11) is exact
+            // (the difference is representable) and, with a multiplier other than -1, the compiler selects v_fma_mix_f32 reading the
+            // fp16 half in place (with -1 it folds the FMA into convert + subtract; inline asm would make the staging loops convergent)
+            const f32x2 r = {__builtin_fmaf((float)h0[0], -2048.f, x[0] * 2048.f), __builtin_fmaf((float)h0[1], -2048.f, x[1] * 2048.f)};
             const h16x2 h1 = __builtin_convertvector(r, h16x2);
             out[0][e] = h0[0]; out[0][e + 1] = h0[1];
             out[1][e] = h1[0]; out[1][e + 1] = h1[1];
