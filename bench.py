@@ -77,10 +77,33 @@ def cpu_baseline(seed):
     finally:
         torch.set_num_threads(old)
     med = statistics.median(small)
-    return dict(value=round(1.0 / dt, 5), unit='frames/s', cores=cores, kind='port',
+    return dict(value=round(1.0 / dt, 5), unit='frames/s', cores=cores, kind='port', n=1,
                 sample='1 real FuseTrack frame at %dx%d (the benched size), oracle/ on PyTorch-CPU fp32, %d threads, timed once: %.1f s; '
                        'spread: 256x512 frame pair, 1 warm-up + 3 timed, median %.2f s (min %.2f max %.2f) = %.5f frames/s scaled by pixel count'
                        % (H, W, cores, dt, med, min(small), max(small), (h * w) / float(H * W) / med))
+
+
+class _TraceLib:
+    """proxy of the loaded libvpship: HIP events (torch's current stream = the launch stream) around EVERY C-ABI launch, by symbol.
+    Used for the instrumented single-stream frame only: in-frame durations of the non-conv kernels (the micro-benchmark below
+    times the same kernels alone, on synthetic operands)."""
+
+    def __init__(self, lib):
+        self._lib, self.trace = lib, []
+
+    def __getattr__(self, name):
+        f = getattr(self._lib, name)
+        if not name.startswith('vps_') or name in ('vps_abi_version', 'vps_build_info'):
+            return f
+
+        def call(*a):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = f(*a)
+            e1.record()
+            self.trace.append((name, e0, e1))
+            return rc
+        return call
 
 
 def hbm_kernels(dev):
@@ -325,6 +348,25 @@ def main():
         del m2, r2
         torch.cuda.empty_cache()
 
+    # ---- untimed: what an UNMODIFIED tools/test_vpq.py:41-63 loop gets: one model(...) call per frame, no `prefetch=`, the two maps
+    # and the instance vectors fetched to the host after every frame -------------------------------------------------------------
+    plain = None
+    if rank == 0 and not args.no_extras and args.variant == 'fusetrack':
+        reset()
+        for t in range(3):
+            plain_step(t, 7)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        nfr = 20
+        for t in range(3, 3 + nfr):
+            r = plain_step(t, 7)
+            r[2]['fcn_outputs'].cpu(); r[2]['panoptic_outputs'].cpu(); r[2]['panoptic_cls_inds'].cpu(); r[2]['panoptic_det_obj_ids'].cpu()
+        c1 = time.perf_counter() - c0
+        plain = dict(frames=nfr, frames_per_s=round(nfr / c1, 3), ms_per_frame=round(1e3 * c1 / nfr, 3),
+                     note='per-frame model(...) calls as tools/test_vpq.py:41-63 makes them (no prefetch hint), D2H of the two uint8 maps and '
+                          'the instance vectors after every frame; 1 mid-frame + 1 end-of-frame host read inside the detector')
+        reset()
+
     # ---- instrumented extra frame (outside the timed region): per-stage and per-conv-launch HIP events, ONE stream ---------------
     roof, stages, hbm = None, None, None
     if rank == 0:
@@ -332,8 +374,16 @@ def main():
         plain_step(0, 4); plain_step(1, 4)
         model.profile = {}
         nhwc.CONV_TRACE = []
-        plain_step(2, 4)
-        torch.cuda.synchronize()
+        real_lib = hip.load()
+        hip._lib = tl = _TraceLib(real_lib)
+        try:
+            plain_step(2, 4)
+            torch.cuda.synchronize()
+        finally:
+            hip._lib = real_lib
+        in_frame = {}
+        for name, e0, e1 in tl.trace:
+            in_frame.setdefault(name, []).append(round(1e3 * e0.elapsed_time(e1), 1))
         stages = {k: round(v, 3) for k, v in model.stage_times_ms()}
         fl = sum(c[0] for c in nhwc.CONV_TRACE)
         ms = sum(c[1].elapsed_time(c[2]) for c in nhwc.CONV_TRACE)
@@ -369,16 +419,32 @@ def main():
                     conv_ms_per_frame=round(ms, 3), avg_launch_us=round(1e3 * ms / max(nl, 1), 2))
         # HBM traffic of the conv kernels per frame: separate rocprofv3 --pmc passes (tools/pmc_traffic.py), not collectable from
         # inside this process; the newest committed measurement for this arithmetic mode is attached
-        for rnd in ('r02', 'r01'):
+        for rnd in ('r03', 'r02', 'r01'):
             pmc = os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s.json' % (rnd, args.prec))
             if os.path.exists(pmc):
                 roof['traffic'] = round(json.load(open(pmc))['conv_hbm_bytes_per_frame'])
                 roof['traffic_over_algorithmic'] = round(roof['traffic'] / max(abytes, 1), 3)
                 roof['traffic_source'] = 'profiles/' + os.path.basename(pmc) + ' (bytes per frame over all conv launches, like algorithmic_bytes_per_frame)'
                 break
+        # every non-conv C-ABI launch of the instrumented frame, by symbol: [us per call] (HIP events, one stream)
+        roof['in_frame_launch_us'] = {k: v for k, v in sorted(in_frame.items()) if k != 'vps_conv2d'}
+        roof['in_frame_non_conv_ms'] = round(sum(sum(v) for k, v in in_frame.items() if k != 'vps_conv2d') * 1e-3, 3)
         if not args.no_extras and (Hh, Ww) == (H, W):
             hbm = hbm_kernels(dev)
+            # the same kernels INSIDE the frame (real operands, neighbours in the caches): achieved GB/s from the in-frame duration
+            frame_calls = {'flow_warp': ('vps_flow_warp', 0), 'correlation_flownetc_441ch': ('vps_correlation', 0),
+                           'correlation_lite_81ch': ('vps_correlation', 1), 'flow_stage': ('vps_flow_stage_full', 0),
+                           'panoptic_combine': ('vps_panoptic_combine_dev', 0), 'roi_align_1000x7x7': ('vps_roi_align', 0),
+                           'bfp_gather': ('vps_bfp_gather', 0)}
+            for k, (sym, idx) in frame_calls.items():
+                calls = in_frame.get(sym, [])
+                if k in hbm and idx < len(calls) and calls[idx] > 0:
+                    hbm[k]['in_frame_us'] = calls[idx]
+                    hbm[k]['in_frame_GBs'] = round(hbm[k]['algorithmic_MB'] * 1e6 / (calls[idx] * 1e-6) / 1e9, 1)
+                    hbm[k]['in_frame_frac_of_8TBs'] = round(hbm[k]['in_frame_GBs'] / PEAK_HBM_GBS, 4)
             roof['hbm_kernels'] = hbm
+            roof['hbm_kernels_note'] = ('us / achieved_GBs: the kernel alone on synthetic operands (20 launches); in_frame_*: the same launch inside the '
+                                        'instrumented frame (real flows / features) - quote these')
     if rank == 0:
         fps = total_frames / dt
         line = {
@@ -404,8 +470,12 @@ def main():
             'roofline': roof, 'stage_ms': stages,
             'stage_ms_note': 'instrumented extra frame on ONE stream; the timed frames overlap FlowNet2 with backbone+FPN and the semantic head with the detection heads on two streams',
         }
-        if os.environ.get('VPS_S2_HALO'):
-            line['config']['experimental'] = 'VPS_S2_HALO: stride-2 3x3/5x5 layers on the phase-split 8-wave halo kernel (opt-in, not the validated configuration)'
+        if os.environ.get('VPS_S2_HALO', '1')[0] == '0':
+            line['config']['experimental'] = 'VPS_S2_HALO=0: the phase-split stride-2 halo kernel switched off (A/B run, not the default configuration)'
+        if plain is not None:
+            line['test_vpq_loop'] = plain
+        line['config']['host_reads_per_frame'] = '2 (the detection list after MaskROI: 8 KB; kept list + track ids + range report at the end: 2 KB)'
+        line['f16_fallbacks'] = int(nhwc.F16_FALLBACKS[0])        # layers switched from f16x3 to bf16x6 by the fp16 range report (0 here)
         if clip30 is not None:
             line['clip30'] = clip30
         if other is not None:

@@ -112,6 +112,11 @@ typedef struct vps_conv_desc {
      * cout/out_ld/out_coff multiples of 4; VPS_EARG otherwise. */
     double* gn_stats;
     int32_t gn_cpg, gn_rep;
+    /* ksplit > 1: int32 [nclass * tiles] tickets, ZERO on entry (the launch leaves them zero). Non-NULL: the block that finishes a
+     * tile's last split sums the partials (in split order) and applies the epilogue itself; NULL: a separate reduce launch does.
+     * tiles = ceil(M/128) * cout_pad/tile_n for the pipelined kernels; the halo kernels tile in 8x16 / 8x32 patches:
+     * N * ceil(Qh/8) * ceil(Qw/16) * cout_pad/tile_n is an upper bound for all of them. */
+    int32_t* tile_counter;
 } vps_conv_desc;
 
 int vps_conv2d(const vps_conv_desc* d, void* stream);

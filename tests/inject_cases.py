@@ -80,6 +80,10 @@ def make_inject(seed, K, tie_from=None, masks='random', jitter_of=None, extra_sa
         mask_score = -mask_score.abs() - 0.1
     elif masks == 'positive_bias':
         mask_score = mask_score + 2.0
+    if tie_from is not None:
+        # the mask bank is indexed by LIST POSITION and the order of exactly tied detections is undefined in the reference
+        # (numpy's unstable argsort): every position a tied detection can land on holds the same mask
+        mask_score[tie_from:nobj] = mask_score[tie_from].clone()
     fcn_score = torch.randn(1, 19, H // 4, W // 4, generator=g)
     return dict(proposals=props, cls_score=cls_score, bbox_pred=bbox_pred, mask_score=mask_score, fcn_score=fcn_score, _K=nobj, _cls=cls)
 
@@ -101,9 +105,19 @@ CASES = {
 
 
 def neck_features(seed=11):
-    """five FPN-neck levels [1,256,H/s,W/s], s = 4..64: the tensors the box / track / mask RoI extractors read"""
+    """five FPN-neck levels [1,256,H/s,W/s], s = 4..64: the tensors the box / track / mask RoI extractors read. SMOOTH fields
+    (noise drawn at 1/8 of each level's resolution, bilinearly upsampled) plus a little white noise: RoIs that overlap see
+    correlated features, distant ones independent features — like a real feature pyramid, and what makes a second detection of
+    an object compete for that object's memory entry (the tracker's undo case)."""
+    import torch.nn.functional as F
     g = _gen(seed)
-    return [torch.randn(1, 256, H // s, W // s, generator=g) for s in (4, 8, 16, 32, 64)]
+    out = []
+    for s_ in (4, 8, 16, 32, 64):
+        h, w = H // s_, W // s_
+        base = torch.randn(1, 256, max(h // 8, 1), max(w // 8, 1), generator=g)
+        lvl = F.interpolate(base, size=(h, w), mode='bilinear', align_corners=False) + 0.1 * torch.randn(1, 256, h, w, generator=g)
+        out.append(lvl.contiguous())
+    return out
 
 
 def frames_of(case):

@@ -1,5 +1,6 @@
 """CPU / gloo, world_size 2: the clip-sharding protocol of vps_amd/clip_shard.py (frame partition, ONE point-to-point
-hand-off of the gathered pre-neck feature per shard boundary, sequential tracker replay on rank 0) gives exactly the
+hand-off of the gathered pre-neck feature per shard boundary, fixed-layout detection records streamed to rank 0, which assigns
+the track ids frame by frame in clip order) gives exactly the
 outputs of the sequential single-process run. The compute backend injected here is oracle-backed (tests may use the
 oracle); on the GPU the same runner drives vps_amd.clip_shard.DetectorBackend.
 """
@@ -36,6 +37,14 @@ class OracleBackend:
         self.o = OF.FuseTrackOracle(sd)
         self.sd = self.o.sd
         self.prev = None          # tracker memory: (bboxes, feats, labels)
+
+    max_det = 128
+
+    def record_layout(self):
+        return [('det_bboxes', 4, torch.float32), ('det_labels', 1, torch.int64), ('cls_prob', 1, torch.float32), ('emb', 256 * 7 * 7, torch.float32)]
+
+    def map_shape(self):
+        return H, W
 
     def ref_feature(self, img):
         with torch.no_grad():
@@ -81,7 +90,7 @@ class OracleBackend:
 
     def assign(self, rec, is_first):
         OF = self.OF
-        bb, lab, feats, prob = rec['det_bboxes'], rec['det_labels'], rec['emb'], rec['cls_prob']
+        bb, lab, feats, prob = rec['det_bboxes'], rec['det_labels'], rec['emb'].reshape(-1, 256, 7, 7), rec['cls_prob']
         if is_first or self.prev is None:
             self.prev = [bb.clone(), feats.clone(), lab.clone()]
             return np.arange(bb.size(0))

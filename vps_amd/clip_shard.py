@@ -10,11 +10,14 @@ new design for BASELINE config 4:
   * the ONLY data-path exchange: rank r computes gather(FPN(frame e_r-1)) of its LAST frame first (it depends on that
     image alone) and sends it point-to-point to rank r+1 (134 MB fp32 at 1024x2048: one direct xGMI link, ~0.9 ms,
     overlapped with everything rank r+1 does before its neck). One send/recv per shard boundary, no ring, no all-reduce.
-  * instance ids depend on the whole history (panoptic_fusetrack.py:400-469): each rank ships its per-frame detection
-    records (boxes, labels, scores, 1024-d track embeddings: <0.5 MB/frame) to rank 0, which replays the greedy assignment
-    in frame order — exactly the sequential algorithm, so ids are identical to the single-GPU run.
+  * instance ids depend on the whole history (panoptic_fusetrack.py:400-469): each rank ships every finished frame's detection
+    record (boxes, labels, scores, 1024-d track embeddings, kept list: ONE fixed-layout fp32 tensor of ~1 MB) and its two maps
+    (one uint8 tensor) to rank 0 point-to-point, as soon as the frame is done; rank 0 runs the greedy assignment frame by frame
+    in clip order while the other ranks are still computing — exactly the sequential algorithm, so ids are identical to the
+    single-GPU run. No object collectives (nothing is pickled), no compute/replay barrier.
 
 `backend` protocol (product: DetectorBackend below; CPU tests inject an oracle-backed one):
+    record_layout() -> [(key, width, dtype)]       columns of the tracker record (the runner's `track_keys`), map_shape() -> (H, W)
     ref_feature(img) -> contiguous tensor          gathered pre-neck feature of a frame
     process(img, ref_img, ref_feature, iid, is_first) -> dict record (no ids yet)
     assign(record, is_first) -> np.ndarray ids     sequential tracker step (stateful)
@@ -38,15 +41,59 @@ def partition(nframes, world):
 
 
 class ClipShardRunner:
+    """Streams the clip: every rank works through its contiguous shard; a finished frame's detection record (ONE fixed-layout fp32
+    tensor) and its two maps (ONE uint8 tensor) go to rank 0 point-to-point as soon as the frame is done; rank 0 assigns the
+    track ids frame by frame in clip order — its own frames right away, the others' as their records arrive (it posted the
+    receives up front) — and assembles the outputs. No object collectives, no pickling, no barrier between "compute" and
+    "replay": the only serial work is the tracker step itself (two small kernels per frame)."""
+
     def __init__(self, backend, rank=0, world=1, dist=None, device=None, track_keys=('det_bboxes', 'det_labels', 'cls_prob', 'emb')):
         self.backend, self.rank, self.world, self.dist = backend, rank, world, dist
         self.device = device
         self.track_keys = track_keys
 
+    # ---- fixed record layout: [K, k, keep_inds[cap], per-instance vectors [cap] x3, then the tracker columns [cap, width] ...]
+    VEC_KEYS = ('panoptic_cls_inds', 'panoptic_cls_prob', 'panoptic_det_labels')
+
+    def _layout(self):
+        cap = int(getattr(self.backend, 'max_det', 256))
+        lay = list(self.backend.record_layout())                       # [(key, width, torch dtype)] for self.track_keys
+        assert [k for k, _, _ in lay] == list(self.track_keys), (lay, self.track_keys)
+        n = 2 + cap * (1 + len(self.VEC_KEYS)) + cap * sum(w for _, w, _ in lay)
+        return cap, lay, n
+
+    def _pack(self, rec, out):
+        cap, lay, n = self._layout()
+        K = int(rec[self.track_keys[0]].shape[0]); keep = torch.as_tensor(np.asarray(rec['keep_inds']).astype(np.int64))
+        k = int(keep.numel())
+        assert K <= cap and k <= cap, (K, k, cap)
+        out[0], out[1] = float(K), float(k)
+        o = 2
+        out[o:o + k] = keep.to(out.device, torch.float32); o += cap
+        for key in self.VEC_KEYS:
+            out[o:o + k] = torch.as_tensor(rec[key]).reshape(-1).to(out.device, torch.float32); o += cap
+        for key, w, _ in lay:
+            out[o:o + K * w] = rec[key].reshape(-1).to(torch.float32); o += cap * w
+        return out
+
+    def _unpack(self, buf, maps, t):
+        cap, lay, n = self._layout()
+        head = buf[:2].cpu()
+        K, k = int(head[0]), int(head[1])
+        rec = {'t': t}
+        o = 2
+        rec['keep_inds'] = buf[o:o + k].to(torch.int64).cpu().numpy(); o += cap
+        for key, dt in zip(self.VEC_KEYS, (torch.int64, torch.float32, torch.int64)):
+            rec[key] = buf[o:o + k].to(dt); o += cap
+        for key, w, dt in lay:
+            v = buf[o:o + K * w].to(dt)
+            rec[key] = v.reshape(K, w) if (w > 1 or key == 'det_bboxes') else v.reshape(K); o += cap * w
+        rec['fcn_outputs'], rec['panoptic_outputs'] = maps[1][None], maps[0][None]
+        return rec
+
     def run(self, load_frame, nframes, video_id=1):
         """load_frame(t) -> normalised frame tensor [1,3,H,W] on this rank's device (data loading is not the sharded path).
-        Returns on rank 0 the list of per-frame outputs for the WHOLE clip (frame order), elsewhere this rank's outputs
-        without ids."""
+        Returns on rank 0 the list of per-frame outputs for the WHOLE clip (frame order), elsewhere []."""
         dist, rank, world = self.dist, self.rank, self.world
         # every frame is loaded ONCE and the same tensor object is handed to the backend wherever the frame is needed (as the
         # hand-off frame, as `img`, as the next call's `ref_img`, as the announced `next_img`): the detector matches its
@@ -61,6 +108,8 @@ class ClipShardRunner:
         parts = partition(nframes, world)
         s, e = parts[rank]
         be = self.backend
+        if hasattr(be, 'inline_ids'):
+            be.inline_ids = rank == 0        # rank 0 owns the head of the clip: its frames get their ids inside the detector call
         recv_buf = None
         reqs = []
         # 1) hand-off: last frame's gathered feature -> next rank (computed first: it only needs that image).
@@ -75,8 +124,19 @@ class ClipShardRunner:
                 recv_buf = be.ref_feature_buffer(load_frame(s))
                 ops.append(dist.P2POp(dist.irecv, recv_buf, rank - 1))
             reqs = dist.batch_isend_irecv(ops) if ops else []
-        # 2) this rank's frames
-        records = []
+        # 2) rank 0 posts the receives of every other rank's records + maps, in clip order (per peer the order of its sends)
+        inbox = {}
+        if world > 1 and rank == 0:
+            cap, lay, n = self._layout()
+            dev = self.device if self.device is not None else load_frame(0).device
+            Hm, Wm = be.map_shape()
+            for r in range(1, world):
+                for t in range(*parts[r]):
+                    buf = torch.zeros(n, dtype=torch.float32, device=dev)
+                    maps = torch.empty(2, Hm, Wm, dtype=torch.uint8, device=dev)
+                    inbox[t] = (buf, maps, dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, r), dist.P2POp(dist.irecv, maps, r)]))
+        # 3) this rank's frames
+        outs, sent = [], []
         prev = None
         for t in range(s, e):
             img = load_frame(t)
@@ -95,108 +155,52 @@ class ClipShardRunner:
             else:
                 rec = be.process(img, ref_img, ref_feature, video_id * 10000 + t + 1, is_first)
             rec['t'] = t
-            records.append(rec)
+            if rank == 0:
+                outs.append(be.finalize(rec, be.assign(rec, is_first)))       # rank 0 owns the head of the clip: ids right away
+            else:
+                cap, lay, n = self._layout()
+                buf = self._pack(rec, torch.zeros(n, dtype=torch.float32, device=rec[self.track_keys[0]].device))
+                maps = torch.stack([torch.as_tensor(rec['panoptic_outputs'])[0], torch.as_tensor(rec['fcn_outputs'])[0]]).to(torch.uint8).contiguous()
+                sent.append((buf, maps, dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, 0), dist.P2POp(dist.isend, maps, 0)])))
             prev = img
             memo.pop(t - 1, None)            # frame t-1 is no longer needed (frame t stays: it is frame t+1's reference)
         for rq in reqs:
             rq.wait()
-        # 3) sequential tracker replay on rank 0
-        if world == 1:
-            return [be.finalize(r, be.assign(r, r['t'] == 0)) for r in records]
-        # detection records -> rank 0: the per-detection tensors of a rank (boxes, labels, scores, 1024-d embeddings: <0.5 MB per
-        # frame) are packed into ONE fp32 matrix [sum K, D] and sent point-to-point; only the layout (a few ints) goes as an object
-        def pack(recs):
-            meta, rows = [], []
-            for r in recs:
-                K = int(r[self.track_keys[0]].shape[0])
-                cols, lay = [], []
-                for k in self.track_keys:
-                    v = r[k]
-                    lay.append((k, tuple(v.shape[1:]), str(v.dtype).replace('torch.', '')))
-                    cols.append(v.reshape(K, -1).to(torch.float32))
-                meta.append((r['t'], K, lay))
-                rows.append(torch.cat(cols, 1))
-            return meta, (torch.cat(rows, 0).contiguous() if rows else None)
-
-        def unpack(meta, mat):
-            out, row = [], 0
-            for t, K, lay in meta:
-                r, col = {'t': t}, 0
-                for k, shp, dt in lay:
-                    w = 1
-                    for d_ in shp:
-                        w *= d_
-                    r[k] = mat[row:row + K, col:col + w].reshape((K,) + tuple(shp)).to(getattr(torch, dt))
-                    col += w
-                row += K
-                out.append(r)
-            return out
-
-        meta, mat = pack(records)
-        gathered = [None] * world if rank == 0 else None
-        dist.gather_object((meta, None if mat is None else tuple(mat.shape)), gathered, dst=0)
-        ids_per_rank = None
+        # 4) rank 0: the other shards' frames in clip order, each as soon as its record has arrived
         if rank == 0:
-            mats, ops = {0: mat}, []
-            for r in range(1, world):
-                if gathered[r][1] is not None:
-                    mats[r] = torch.empty(gathered[r][1], dtype=torch.float32, device=mat.device)
-                    ops.append(dist.P2POp(dist.irecv, mats[r], r))
-            for rq in (dist.batch_isend_irecv(ops) if ops else []):
-                rq.wait()
-            allrec = sorted([rec for r in range(world) if r in mats for rec in unpack(gathered[r][0], mats[r])], key=lambda r: r['t'])
-            ids = {}
-            for r in allrec:
-                ids[r['t']] = np.asarray(be.assign(r, r['t'] == 0))
-            ids_per_rank = [{t: ids[t] for t in range(a, b)} for a, b in parts]
-        elif mat is not None:
-            for rq in dist.batch_isend_irecv([dist.P2POp(dist.isend, mat, 0)]):
-                rq.wait()
-        mine = [None]
-        dist.scatter_object_list(mine, ids_per_rank, src=0)
-        outs = [be.finalize(r, mine[0][r['t']]) for r in records]
-        # collect the finished per-frame outputs on rank 0: the two maps of every frame (2 x 2 MB at 1024x2048) travel as ONE
-        # tensor per rank, point-to-point like the feature hand-off (RCCL over the direct xGMI link; no pickling of image-sized
-        # data), the per-instance vectors (a few hundred bytes per frame) as objects
-        map_keys = ('panoptic_outputs', 'fcn_outputs')
-        mine_maps = torch.stack([torch.stack([o[k][0] for k in map_keys]) for o in outs]) if outs else None      # [nf, 2, H, W]
-        bufs, ops = {}, []
-        if rank == 0:
-            for r in range(1, world):
-                nf = parts[r][1] - parts[r][0]
-                if nf > 0:
-                    bufs[r] = torch.empty((nf,) + tuple(mine_maps.shape[1:]), dtype=mine_maps.dtype, device=mine_maps.device)
-                    ops.append(dist.P2POp(dist.irecv, bufs[r], r))
-        elif mine_maps is not None:
-            ops.append(dist.P2POp(dist.isend, mine_maps.contiguous(), 0))
-        reqs = dist.batch_isend_irecv(ops) if ops else []
-        small = [{k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in o.items() if k not in map_keys} for o in outs]
-        res = [None] * world if rank == 0 else None
-        dist.gather_object(small, res, dst=0)
-        for rq in reqs:
-            rq.wait()
-        if rank == 0:
-            full = list(outs)
-            for r in range(1, world):
-                for i, o in enumerate(res[r]):
-                    o = dict(o)
-                    for j, k in enumerate(map_keys):
-                        o[k] = bufs[r][i, j][None]
-                    full.append(o)
-            return full
-        return outs
+            for t in sorted(inbox):
+                buf, maps, rq = inbox[t]
+                for q in rq:
+                    q.wait()
+                rec = self._unpack(buf, maps, t)
+                outs.append(be.finalize(rec, be.assign(rec, t == 0)))
+            return outs
+        for buf, maps, rq in sent:
+            for q in rq:
+                q.wait()
+        return []
 
 
 class DetectorBackend:
     """adapts vps_amd.detector.PanopticFuseTrack to the ClipShardRunner protocol"""
 
     supports_prefetch = True
+    inline_ids = True
 
     def __init__(self, detector, H, W, prefetch=True):
         self.det, self.H, self.W = detector, H, W
         self.prefetch = prefetch
         # the runner hands frame t-1 to frame t as its reference by construction: the probe check is skipped per call (the
         # detector's own setting is restored after every call, the model object may be shared with other callers)
+
+    max_det = 256
+
+    def record_layout(self):
+        E = self.det.track_head.fcs[1].out_features
+        return [('det_bboxes', 4, torch.float32), ('det_labels', 1, torch.int64), ('cls_prob', 1, torch.float32), ('emb', E, torch.float32)]
+
+    def map_shape(self):
+        return self.H, self.W
 
     def ref_feature(self, img):
         return self.det.gathered_feature(img)
@@ -211,14 +215,18 @@ class DetectorBackend:
         pf = (next_img, img) if (self.prefetch and next_img is not None) else None      # the next frame's reference is this frame
         keep, self.det.verify_ref_frame = self.det.verify_ref_frame, False
         try:
-            out = self.det.simple_test(img, [meta], ref_img=[ref_img], ref_feature=ref_feature, defer_tracking=True, prefetch=pf)
+            out = self.det.simple_test(img, [meta], ref_img=[ref_img], ref_feature=ref_feature, defer_tracking=not self.inline_ids, prefetch=pf)
         finally:
             self.det.verify_ref_frame = keep
         rec = dict(out[2])
         rec.update(self.det._track_record)
+        if self.inline_ids:
+            rec['ids'] = self.det._aux['det']['det_obj_ids']        # assigned inside the call (read with its end-of-frame read)
         return rec
 
     def assign(self, rec, is_first):
+        if 'ids' in rec:
+            return rec['ids']
         return self.det.track_assign(rec, is_first)
 
     def finalize(self, rec, ids):

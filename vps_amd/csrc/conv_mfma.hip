@@ -83,7 +83,7 @@ __device__ __forceinline__ void decode_tile(const vps_conv_desc& d, int swz, con
 template <int TM, int TN, int BN, bool TILE2D = false, int PWL = 4, bool GN = false>
 __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&acc)[TM][TN], const int M, const int tile_m,
                                               const int tile_n, const int cls, const int split, const int py, const int px,
-                                              const int wm, const int wn, const int lane) {
+                                              const int wm, const int wn, const int lane, const int tile_lin) {
     const int prow = lane & 31;
     const int cq = 4 * (lane >> 5);
     const int cbase = tile_n * BN + wn * TN * 32 + cq;       // + b*32 + 8*g: first of this lane's 4 channels
@@ -134,6 +134,7 @@ __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&a
         // partial sums [split][class][pixel][cout_pad]; pixel = linear (n, qy, qx) index whatever the tiling. cout_pad is a
         // multiple of 32 and the scratch buffer is 16-byte aligned: always float4
         const int Mpix = TILE2D ? d.N * d.Qh * d.Qw : M;
+        const size_t splane = (size_t)d.nclass * Mpix * d.cout_pad;              // floats per split
         float* __restrict__ ws = d.ws + ((size_t)(split * d.nclass + cls) * Mpix) * d.cout_pad;
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
@@ -146,7 +147,47 @@ __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&a
                     *reinterpret_cast<f32x4*>(&ws[(size_t)mlin[a] * d.cout_pad + cbase + b * 32 + 8 * g]) = v;
                 }
         }
-        return;
+        if (!d.tile_counter) return;             // reduced by conv_splitk_reduce_kernel
+        // LAST-BLOCK reduction: the block that finishes a tile's last split adds the partial sums up (in split order 0, 1, ...:
+        // the result does not depend on which block came last) and runs the epilogue itself - no reduce launch, the partials are
+        // read while they are still in the cache hierarchy. Release / acquire at device scope around the tile's ticket counter.
+        __shared__ int is_last;
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int ticket = atomicAdd(&d.tile_counter[tile_lin], 1);
+            is_last = ticket == d.ksplit - 1;
+            if (is_last) d.tile_counter[tile_lin] = 0;        // ready for the next launch that uses this scratch buffer
+        }
+        __syncthreads();
+        if (!is_last) return;
+        __threadfence();
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        const float* __restrict__ w0 = d.ws + ((size_t)cls * Mpix) * d.cout_pad;
+        for (int sp = 0; sp < d.ksplit; ++sp) {
+            f32x4 v[TM][TN][4];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        v[a][b][g] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(&w0[(size_t)sp * splane + (size_t)mlin[a] * d.cout_pad + cbase + b * 32 + 8 * g]));
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[a][b][4 * g + e] += v[a][b][g][e];
+        }
+        // fall through: the regular epilogue on the summed accumulators
     }
 
     const bool vec = !((d.cout | d.out_ld | d.out_coff) & 3) && !((uintptr_t)d.out & 15) &&
@@ -435,7 +476,7 @@ void conv_mfma_f32_kernel(const vps_conv_desc d, const int M, const int tiles_m,
         }
     }
 
-    conv_epilogue<TM, TN, BN>(d, acc, M, tile_m, tile_n, cls, split, py, px, wm, wn, lane);
+    conv_epilogue<TM, TN, BN>(d, acc, M, tile_m, tile_n, cls, split, py, px, wm, wn, lane, (cls * tiles_m + tile_m) * tiles_n + tile_n);
 }
 
 // ================================================================================================
@@ -798,7 +839,7 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
         }
     }
     report_range<MODE>(d, amax);
-    conv_epilogue<TM, TN, BN, false, 4, DEFORM>(d, acc, M, tile_m, tile_n, cls, split, py, px, wm, wn, lane);
+    conv_epilogue<TM, TN, BN, false, 4, DEFORM>(d, acc, M, tile_m, tile_n, cls, split, py, px, wm, wn, lane, (cls * tiles_m + tile_m) * tiles_n + tile_n);
 }
 
 // ================================================================================================
@@ -1055,7 +1096,7 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
         if (step + 1 < nsteps) kstep(step + 1, std::integral_constant<int, 1>{});
     }
     report_range<MODE>(d, amax);
-    conv_epilogue<TM, TN, BN>(d, acc, M, tile_m, tile_n, cls, split, py, px, wm, wn, lane);
+    conv_epilogue<TM, TN, BN>(d, acc, M, tile_m, tile_n, cls, split, py, px, wm, wn, lane, (cls * tiles_m + tile_m) * tiles_n + tile_n);
 }
 
 // ================================================================================================
@@ -1251,7 +1292,7 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
         __syncthreads();
     }
     report_range<MODE>(d, amax);
-    conv_epilogue<TM, TN, BN, true>(d, acc, tiles_m * BM, tile_m, tile_n, cls, split, py, px, wm, wn, lane);
+    conv_epilogue<TM, TN, BN, true>(d, acc, tiles_m * BM, tile_m, tile_n, cls, split, py, px, wm, wn, lane, (cls * tiles_m + tile_m) * tiles_n + tile_n);
 }
 
 // ================================================================================================
@@ -1456,7 +1497,7 @@ void conv_mfma_h8_kernel(const vps_conv_desc d, const int tiles_m, const int til
         }
     }
     report_range<MODE>(d, amax);
-    conv_epilogue<TM, TN, BN, true, 5>(d, acc, tiles_m * 256, tile_m, tile_n, cls, split, py, px, wm, wn, lane);
+    conv_epilogue<TM, TN, BN, true, 5>(d, acc, tiles_m * 256, tile_m, tile_n, cls, split, py, px, wm, wn, lane, (cls * tiles_m + tile_m) * tiles_n + tile_n);
 }
 
 // ================================================================================================
@@ -1684,7 +1725,7 @@ void conv_mfma_h8s2_kernel(const vps_conv_desc d, const int tiles_m, const int t
         });
     }
     report_range<MODE>(d, amax);
-    conv_epilogue<TM, TN, BN, true, 5>(d, acc, tiles_m * 256, tile_m, tile_n, cls, split, 0, 0, wm, wn, lane);
+    conv_epilogue<TM, TN, BN, true, 5>(d, acc, tiles_m * 256, tile_m, tile_n, cls, split, 0, 0, wm, wn, lane, (cls * tiles_m + tile_m) * tiles_n + tile_n);
 }
 
 // ================================================================================================
@@ -2030,7 +2071,7 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
     }
     int st = vps_launch_status();
     if (st) return st;
-    if (d.ksplit > 1) {
+    if (d.ksplit > 1 && !d.tile_counter) {
         const size_t total = (size_t)d.nclass * M * d.cout;
         const bool vec = !((d.cout | d.cout_pad | d.out_ld | d.out_coff) & 3) && !((uintptr_t)d.out & 15) &&
                          (!d.res || (!((d.res_ld | d.res_coff) & 3) && !((uintptr_t)d.res & 15)));

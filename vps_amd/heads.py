@@ -289,7 +289,9 @@ class TrackHead(HipModule):
         the memory embeddings as the weight panel)."""
         K, D = emb.shape
         M = mem_emb.shape[0]
-        pc = nhwc.PackedConv.from_matrix(mem_emb)
+        # exact-fp32 MFMA kernel: a [K x M x 1024] product is ~0.1 GFLOP, and the split modes would re-split the memory matrix
+        # into operand planes every frame (~30 small elementwise launches)
+        pc = nhwc.PackedConv.from_matrix(mem_emb, prec=hip.PREC_F32)
         prod = pc(nhwc.FMap(emb.contiguous().view(1, 1, K, D)), ws=ws, name=tag + 'prod').t.view(K, -1)[:, :M]
         return torch.cat([prod.new_zeros(K, 1), prod], dim=1)
 

@@ -76,6 +76,7 @@ DEFAULT_PREC = _PREC_NAMES[os.environ.get('VPS_PREC', 'f32')]
 # bench.py sets this to a list to time every vps_conv2d launch with HIP events on the launch stream:
 # entries (algorithmic_flops, start_event, end_event, shape tag, algorithmic_bytes). None = no instrumentation (the default).
 CONV_TRACE = None
+SPLITK_LAST_BLOCK = os.environ.get('VPS_SPLITK_LAST_BLOCK', '1') != '0'    # 0: separate reduce launch (A/B runs)
 GN_REP = 32   # copies of the GroupNorm sums a conv epilogue spreads its atomics over (vps_conv_desc.gn_rep)
 
 
@@ -431,6 +432,8 @@ class PackedConv:
                 self.gn_fused = True
         if ksplit > 1:
             need = ksplit * d.nclass * M * self.cout_pad
+            # tickets of the last-block reduction (vps_conv_desc.tile_counter): an upper bound of the tile count of every kernel family
+            ntick = d.nclass * (self.cout_pad // self.tile_n) * max((M + 127) // 128, x.N * ((d.Qh + 7) // 8) * ((d.Qw + 15) // 16))
             if ws is not None:
                 # one scratch buffer per stream: branches of the frame graph that run concurrently must not share it
                 key = '__splitk_ws_%x' % (getattr(hip.stream_ptr(), 'value', None) or 0)
@@ -438,10 +441,17 @@ class PackedConv:
                 if wsb is None or wsb.numel() < need:
                     wsb = torch.empty(max(need, 1 << 24), dtype=torch.float32, device=x.t.device)
                     ws.bufs[key] = wsb
+                tck = ws.bufs.get(key + '_tickets')
+                if tck is None or tck.numel() < ntick:
+                    tck = torch.zeros(max(ntick, 1 << 16), dtype=torch.int32, device=x.t.device)     # zero once: launches leave them zero
+                    ws.bufs[key + '_tickets'] = tck
             else:
                 wsb = torch.empty(need, dtype=torch.float32, device=x.t.device)
+                tck = torch.zeros(ntick, dtype=torch.int32, device=x.t.device)
             d.ws = wsb.data_ptr()
-            self._last_ws = wsb  # keep alive until the next call
+            if SPLITK_LAST_BLOCK:
+                d.tile_counter = tck.data_ptr()
+            self._last_ws = (wsb, tck)  # keep alive until the next call
         if CONV_TRACE is not None:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
