@@ -345,7 +345,7 @@ int vps_maskroi_finish(const float* dets, const int32_t* cand, const int32_t* m_
 
 /* ref: models/detectors/panoptic_fusetrack.py:424-469 (arg-max of comp_scores, greedy assignment with undo, new ids, memory
  * update). comp [K][M+1]; emb [K][E], box [K][ldb], label [K]; prev_emb [>= M+K][E], prev_box [>= M+K][4], prev_label [>= M+K]
- * are updated in place; scratch int32 [M + 3K]; ids [K]; m_out[0] = new memory size. */
+ * are updated in place; scratch int32 [M + 3K + 1]; ids [K]; m_out[0] = new memory size. */
 int vps_track_assign(const float* comp, int K, int M, const float* emb, int E, const float* box, int ldb, const int64_t* label,
                      float* prev_emb, float* prev_box, int64_t* prev_label, int32_t* scratch, int32_t* ids, int32_t* m_out,
                      void* stream);

@@ -186,13 +186,11 @@ void maskroi_finish_kernel(const float* __restrict__ dets, const int* __restrict
 // gets a new id; otherwise it takes memory entry obj = column-1 if its score beats the best one seen for obj so far (the
 // previous holder is undone -> -1 and receives a new id in the second loop). Memory update as the reference's in-place
 // writes leave it: entry obj holds the LAST detection assigned to it, new entries are appended in assignment order.
-// emb [K][E], box [K][ldb] (first 4 used), label [K] int64; prev_* have room for M + K rows. scratch: int32 [M + 3K].
+// emb [K][E], box [K][ldb] (first 4 used), label [K] int64; prev_* have room for M + K rows. scratch: int32 [M + 3K + 1].
 // out: ids [K] int32, m_out[0] = new M.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
-void track_assign_kernel(const float* __restrict__ comp, int K, int M, const float* __restrict__ emb, int E, const float* __restrict__ box,
-                         int ldb, const long long* __restrict__ label, float* __restrict__ prev_emb, float* __restrict__ prev_box,
-                         long long* __restrict__ prev_label, int* __restrict__ scratch, int* __restrict__ ids, int* __restrict__ m_out) {
+void track_assign_kernel(const float* __restrict__ comp, int K, int M, int* __restrict__ scratch, int* __restrict__ ids, int* __restrict__ m_out) {
     int* setsrc = scratch;            // [M] detection written into entry obj, -1 = untouched
     int* addlist = scratch + M;       // [K] detections appended, in order
     int* mi = scratch + M + K;        // [K] arg-max column, then the id of the detection
@@ -241,20 +239,24 @@ void track_assign_kernel(const float* __restrict__ comp, int K, int M, const flo
     }
     __syncthreads();
     for (int i = threadIdx.x; i < K; i += 256) ids[i] = mi[i];
-    __syncthreads();
-    // memory update
-    const int na = nadd;
-    for (int obj = blockIdx.x; obj < M; obj += gridDim.x) {
-        const int src = setsrc[obj];
+    if (threadIdx.x == 0) scratch[M + 3 * K] = nadd;
+}
+
+// memory update of the tracking block, one workgroup per touched entry: entry obj < M takes the LAST detection assigned to it,
+// entries M .. M+nadd-1 are the appended detections in assignment order
+__global__ __launch_bounds__(256)
+void track_update_kernel(int K, int M, const float* __restrict__ emb, int E, const float* __restrict__ box, int ldb,
+                         const long long* __restrict__ label, float* __restrict__ prev_emb, float* __restrict__ prev_box,
+                         long long* __restrict__ prev_label, const int* __restrict__ scratch) {
+    const int* setsrc = scratch;
+    const int* addlist = scratch + M;
+    const int na = scratch[M + 3 * K];
+    for (int dst = blockIdx.x; dst < M + na; dst += gridDim.x) {
+        const int src = dst < M ? setsrc[dst] : addlist[dst - M];
         if (src < 0) continue;
-        for (int e = threadIdx.x; e < E; e += 256) prev_emb[(size_t)obj * E + e] = emb[(size_t)src * E + e];
-        if (threadIdx.x < 4) prev_box[(size_t)obj * 4 + threadIdx.x] = box[(size_t)src * ldb + threadIdx.x];
-    }
-    for (int a = 0; a < na; ++a) {
-        const int src = addlist[a], dst = M + a;
         for (int e = threadIdx.x; e < E; e += 256) prev_emb[(size_t)dst * E + e] = emb[(size_t)src * E + e];
         if (threadIdx.x < 4) prev_box[(size_t)dst * 4 + threadIdx.x] = box[(size_t)src * ldb + threadIdx.x];
-        if (threadIdx.x == 0) prev_label[dst] = label[src];
+        if (dst >= M && threadIdx.x == 0) prev_label[dst] = label[src];
     }
 }
 
@@ -345,9 +347,10 @@ extern "C" int vps_track_assign(const float* comp, int K, int M, const float* em
                                 void* stream) {
     if (!comp || !emb || !box || !label || !prev_emb || !prev_box || !prev_label || !scratch || !ids || !m_out) return VPS_EARG(1);
     if (K < 1 || M < 1 || E < 1 || ldb < 4) return VPS_EARG(2);
-    // ONE workgroup: the sequential assignment and the memory update that follows it must see each other without a grid barrier
-    hipLaunchKernelGGL(track_assign_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, comp, K, M, emb, E, box, ldb,
-                       reinterpret_cast<const long long*>(label), prev_emb, prev_box, reinterpret_cast<long long*>(prev_label), scratch, ids, m_out);
+    // the sequential assignment on ONE workgroup, then the memory update spread over the touched entries
+    hipLaunchKernelGGL(track_assign_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, comp, K, M, scratch, ids, m_out);
+    hipLaunchKernelGGL(track_update_kernel, dim3((unsigned)min(M + K, 2048)), dim3(256), 0, (hipStream_t)stream, K, M, emb, E, box, ldb,
+                       reinterpret_cast<const long long*>(label), prev_emb, prev_box, reinterpret_cast<long long*>(prev_label), scratch);
     return vps_launch_status();
 }
 

@@ -527,7 +527,7 @@ class PanopticFuseTrack(HipModule):
                                             hip.stream_ptr()), 'vps_bbox_overlaps')
             comp_scores = self.track_head.compute_comp_scores(match_logprob, cls_prob.view(-1, 1), bbox_ious, label_delta,
                                                               add_bbox_dummy=True).contiguous()
-            scratch = ws.get('trk.scratch', (self.prev_emb.size(0) + 3 * MaskROI.KCAP,), dtype=torch.int32, zero=False)
+            scratch = ws.get('trk.scratch', (self.prev_emb.size(0) + 3 * MaskROI.KCAP + 1,), dtype=torch.int32, zero=False)
             embc = emb.contiguous(); lab = det_labels.contiguous()
             hip.check(lib.vps_track_assign(hip.ptr(comp_scores), K, M, hip.ptr(embc), E, hip.ptr(db), db.shape[1], hip.ptr(lab),
                                            hip.ptr(self.prev_emb), hip.ptr(self.prev_bboxes), hip.ptr(self.prev_det_labels),

@@ -76,7 +76,11 @@ DEFAULT_PREC = _PREC_NAMES[os.environ.get('VPS_PREC', 'f32')]
 # bench.py sets this to a list to time every vps_conv2d launch with HIP events on the launch stream:
 # entries (algorithmic_flops, start_event, end_event, shape tag, algorithmic_bytes). None = no instrumentation (the default).
 CONV_TRACE = None
-SPLITK_LAST_BLOCK = os.environ.get('VPS_SPLITK_LAST_BLOCK', '1') != '0'    # 0: separate reduce launch (A/B runs)
+# split-K partial sums are added up by a separate reduce launch. VPS_SPLITK_LAST_BLOCK=1 lets the block that finishes a tile's last
+# split do it (vps_conv_desc.tile_counter): measured 31.2 instead of 42.2 frames/s (profiles/r03_bench_splitk_last_block_ab.json) -
+# the device-scope release / acquire around the ticket (buffer_wbl2 / buffer_inv: the partials of a tile come from blocks on
+# different XCDs, each with its own L2) writes back and invalidates a whole L2 per block. Kept as an option, OFF.
+SPLITK_LAST_BLOCK = os.environ.get('VPS_SPLITK_LAST_BLOCK', '0') == '1'
 GN_REP = 32   # copies of the GroupNorm sums a conv epilogue spreads its atomics over (vps_conv_desc.gn_rep)
 
 

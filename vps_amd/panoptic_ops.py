@@ -12,7 +12,11 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+import os
+
 from . import hip
+
+MASK_REMOVAL_SINGLE_LAUNCH = os.environ.get('VPS_MASK_REMOVAL', '') == 'single'
 
 
 class MaskROI(nn.Module):
@@ -135,6 +139,11 @@ class MaskRemoval(nn.Module):
         counts = ws.get('mr.counts', (max(n, 1), 2), dtype=torch.int32, zero=False)
         occ.zero_(); counts.zero_()
         base = meta.data_ptr()
+        if MASK_REMOVAL_SINGLE_LAUNCH:
+            # A/B switch: the whole walk in ONE launch, one workgroup per class walking its boxes in order (csrc/pan_ops.hip)
+            hip.check(lib.vps_mask_removal(hip.ptr(mp), S, ctypes.c_void_p(base), ctypes.c_void_p(base + 16 * n), ctypes.c_void_p(base + 20 * n),
+                                           n, ncls, H, W, hip.ptr(occ), float(self.fraction_threshold), hip.ptr(flags), sp), 'vps_mask_removal')
+            nlv = 0
         for l in range(nlv):
             a, b = int(starts[l]), int(starts[l + 1])
             hip.check(lib.vps_mask_level(hip.ptr(mp), S, ctypes.c_void_p(base), ctypes.c_void_p(base + 16 * n),
