@@ -7,7 +7,7 @@
 
 (separate passes, no other trace domain: MI355X_MICROARCH.md "HBM" / "rocprofv3 PMC slots"). FETCH_SIZE / WRITE_SIZE are
 in KiB; on gfx950 FETCH_SIZE counts 128-byte requests of wide (16 B/lane) coalesced reads as 64 bytes, so it is doubled
-(all loads of the conv kernels are global_load_dwordx4); WRITE_SIZE is taken as reported (uncalibrated, see the guide).
+(all loads of the conv kernels are global_load_dwordx4 / buffer_load_dwordx4); WRITE_SIZE is taken as reported (uncalibrated, see the guide).
 The third argument is the number of frames the profiled command ran (warmup + steps + 1 instrumented frame)."""
 import csv
 import glob
@@ -28,13 +28,14 @@ def total(directory, counter, match):
 def main():
     fetch_dir, write_dir, frames = sys.argv[1], sys.argv[2], int(sys.argv[3])
     out = {'frames': frames, 'kernels': {}}
-    for name in ('conv_mfma_h8_kernel', 'conv_mfma_bf16h_kernel', 'conv_mfma_bf16p_kernel', 'conv_mfma_bf16s_kernel', 'conv_mfma_f32_kernel', 'conv_small3x3_kernel',
+    for name in ('conv_mfma_h8_kernel', 'conv_mfma_h8s2_kernel', 'conv_mfma_bf16h_kernel', 'conv_mfma_bf16p_kernel', 'conv_mfma_bf16s_kernel', 'conv_mfma_f32_kernel', 'conv_small3x3_kernel',
                  'conv_small_kernel', 'conv_splitk_reduce_kernel'):
         f, nf = total(fetch_dir, 'FETCH_SIZE', name)
         w, nw = total(write_dir, 'WRITE_SIZE', name)
         if nf or nw:
             out['kernels'][name] = {'launches_per_frame': nf / frames, 'fetch_bytes_per_frame': 2.0 * f * 1024 / frames,
-                                    'write_bytes_per_frame': w * 1024 / frames}
+                                    'write_bytes_per_frame': w * 1024 / frames,
+                                    'raw': {'FETCH_SIZE_KiB_sum': f, 'fetch_dispatches': nf, 'WRITE_SIZE_KiB_sum': w, 'write_dispatches': nw}}
     out['conv_hbm_bytes_per_frame'] = sum(k['fetch_bytes_per_frame'] + k['write_bytes_per_frame'] for k in out['kernels'].values())
     out['note'] = 'FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE as reported; Infinity-Cache hits are counted'
     print(json.dumps(out, indent=1))
