@@ -133,7 +133,10 @@ def test_full_size_reference_feature_cache_equals_recompute(dev, clip, default_r
 # therefore: every kept detection of the golden frame is found with the same class and a score within 2e-3 (at most one
 # borderline detection per frame may differ), object ids equal up to one bijection over the clip while the listings agree,
 # panoptic map equal as a map of (stuff class | instance class) in < 0.1 % of the pixels. Whether the STRICT comparison
-# (identical arrays, the 128x256 criterion) also holds is recorded in the report; it does for the benchmarked bf16x6 mode.
+# (identical arrays, the 128x256 criterion) also holds is recorded in the report. Every listing position that differs from the
+# reference in the first frame is printed with the span of the scores between the two positions, which must be < 2e-3 (a flip across
+# a larger margin fails the test). The DECIDABLE fixture - margins 20..40x the error, strict array_equal in all three modes - is
+# tests/test_fullsize_sep_gpu.py.
 # ---------------------------------------------------------------------------------------------------------------------
 GOLD_FULL = os.path.join(ROOT, 'tests', 'golden', 'fusetrack_fullsize.npz')
 NSTUFF = 11
@@ -153,7 +156,7 @@ def test_full_size_outputs_match_reference_golden(dev, prec_name):
     s1, s2, c5 = [int(v) for v in g['strides']]
     frames = [f.to(dev) for f in synth.synth_clip(H, W, n, seed)]
     m = _model(nhwc.PREC_NAMES[prec_name])
-    lines, fails = [], []
+    lines, fails, flips = [], [], []
     id_map, id_back, consistent = {}, {}, True
     for t in range(n):
         out = m(return_loss=False, rescale=True, img=[frames[t]], img_meta=[[synth.img_meta(H, W, 10000 + t + 1)]],
@@ -194,6 +197,17 @@ def test_full_size_outputs_match_reference_golden(dev, prec_name):
                 ia, ib = int(r['panoptic_det_obj_ids'][i]), int(gi[j])
                 if not (id_map.setdefault(ia, ib) == ib and id_back.setdefault(ib, ia) == ia):
                     fails.append('f%d object id %d maps to %d: not one bijection' % (t, ia, ib))
+                if t == 0 and ia != ib:
+                    # first frame: ids ARE positions of the score-sorted detection list (panoptic_fusetrack.py:400-402), so a differing
+                    # id is a detection listed at another position than in the reference run. That is only legitimate between
+                    # scores closer than the arithmetic error: the margin of every flipped listing decision is printed and asserted
+                    # to be below the score tolerance (2e-3; measured score error <= 9e-4, profiles/r03_separated_fixture_selection.json)
+                    plist = a['det']['cls_prob'].cpu().numpy()
+                    lo, hi = min(ia, ib), max(ia, ib)
+                    margin = float(plist[lo] - plist[hi]) if hi < len(plist) else float('inf')
+                    flips.append('f0 detection listed at %d instead of %d: scores in between span %.2e' % (ia, ib, margin))
+                    if not margin < 2e-3:
+                        fails.append('f0 listing flip %d <-> %d has a margin of %.2e >= 2e-3' % (ia, ib, margin))
         unmatched += len(gc) - len(used)
         consistent = consistent and unmatched == 0          # a kept / dropped box changes the tracker memory of later frames
         dsem = float((r['fcn_outputs'] != g[p + 'fcn_outputs']).mean())
@@ -211,6 +225,8 @@ def test_full_size_outputs_match_reference_golden(dev, prec_name):
         if not (dsem < 1e-3 and dcls < (1e-3 if unmatched == 0 else 2e-2)):
             fails.append('f%d maps: class-map %.5f sem %.5f' % (t, dcls, dsem))
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    for fl in flips:
+        print('   [%s] %s' % (prec_name, fl))
     with open(os.path.join(ROOT, 'gpurun_out', 'fullsize_golden_report.txt'), 'a') as f:
-        f.write('\n'.join(lines) + '\n')
+        f.write('\n'.join(lines + ['   [%s] %s' % (prec_name, fl) for fl in flips]) + '\n')
     assert not fails, fails

@@ -54,7 +54,7 @@ def uint8_frame(H, W, seed, shift):
     return synth.synth_frame(H, W, seed=seed, shift=shift, noise=2.0 if shift != (0, 0) else 0.0).astype(np.uint8)
 
 
-def run_model(prec, videos, nframes, H, W, dev):
+def run_model(prec, videos, nframes, H, W, dev, separated=False):
     """test_vpq.py:129-149 + single_gpu_test (:28-69) on `videos` synthetic clips -> pano_results with DEVICE maps"""
     import vps_amd
     from vps_amd import nhwc, synth
@@ -64,7 +64,8 @@ def run_model(prec, videos, nframes, H, W, dev):
     try:
         cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', 'fusetrack.py'))
         model = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
-        synth.load_synth(model, 0)
+        over = synth.separated_overrides(os.path.join(ROOT, 'tests', 'golden', 'separated_fc_cls.npz')) if separated else None
+        synth.load_synth(model, 0, overrides=over)
         model.ensure_packed(dev)
     finally:
         nhwc.DEFAULT_PREC = old
@@ -133,26 +134,27 @@ def main():
     ap.add_argument('--width', type=int, default=512)
     ap.add_argument('--prec', default='f16x3')
     ap.add_argument('--gt-prec', default=None, help='take the "ground truth" from a second run in this arithmetic mode (default: the prediction itself)')
+    ap.add_argument('--separated', action='store_true', help='box classification layer of tests/golden/separated_fc_cls.npz (few, well-separated detections)')
     ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'vps_synth'))
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     labeled_fid, lambda_ = 20, 5
     nper = len(range(labeled_fid // lambda_, args.frames, lambda_))
-    res, dt = run_model(args.prec, args.videos, args.frames, args.height, args.width, dev)
+    res, dt = run_model(args.prec, args.videos, args.frames, args.height, args.width, dev, args.separated)
     t0 = time.perf_counter()
     names, pans, pj = postprocess(res, os.path.join(args.out, 'pred'), args.videos, dev, labeled_fid, lambda_, nper)
     dpost = time.perf_counter() - t0
     pred = (pans, pj)
     gt = pred
     if args.gt_prec:
-        res2, _ = run_model(args.gt_prec, args.videos, args.frames, args.height, args.width, dev)
+        res2, _ = run_model(args.gt_prec, args.videos, args.frames, args.height, args.width, dev, args.separated)
         _, pans2, pj2 = postprocess(res2, os.path.join(args.out, 'gt'), args.videos, dev, labeled_fid, lambda_, nper)
         gt = (pans2, pj2)
     t0 = time.perf_counter()
     score = vpq(gt, pred, args.videos, nper, dev)
     deval = time.perf_counter() - t0
     files = sorted(os.listdir(os.path.join(args.out, 'pred', 'pan_pred')))
-    report = dict(videos=args.videos, frames_per_video=args.frames, size=[args.height, args.width], prec=args.prec, gt=args.gt_prec or 'self',
+    report = dict(videos=args.videos, frames_per_video=args.frames, size=[args.height, args.width], prec=args.prec, gt=args.gt_prec or 'self', weights='synthetic seed 0' + (' + separated fc_cls' if args.separated else ''),
                   labelled_frames=len(names), png_files=len(files), vpq=round(score['vpq'], 4),
                   pq_per_window={str(k): round(100 * score[k]['pq'], 4) for k in (1, 2, 3, 4)},
                   seconds=dict(model=round(dt, 3), postprocess_and_png=round(dpost, 3), eval=round(deval, 3)),
