@@ -1153,42 +1153,46 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
     const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
     const int nbt = d.cout_pad >> 5, kst = d.kpad >> 4;
     const size_t wplane = (size_t)d.nclass * nbt * kst * 512;
-    const elem_t* __restrict__ wfrag = reinterpret_cast<const elem_t*>(d.w_split) +
-        ((size_t)(cls * nbt + tile_n * (BN / 32) + wn * TN) * kst + 2 * (size_t)chunk0 * NTAP) * 512 + lane * 8;
+    // buffer-addressed loads as in the pipelined kernel: weights at a scalar byte offset + the lane's 16 bytes, activations at a
+    // 32-bit byte offset that lies beyond the buffer for halo positions outside the image / the channel range (-> zeros)
+    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(d.w_split, (unsigned)(wplane * NSB * sizeof(elem_t)));
+    const unsigned wbase = (unsigned)((((size_t)(cls * nbt + tile_n * (BN / 32) + wn * TN) * kst + 2 * (size_t)chunk0 * NTAP) * 512) * sizeof(elem_t));
+    const unsigned wlane = (unsigned)lane * 16u;
+    const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(d.in, (unsigned)((size_t)d.N * H * W * d.in_ld * sizeof(float)));
+    const unsigned ld4 = (unsigned)d.in_ld * 4u;
 
     f32x4 areg[NLD];
-    unsigned aok = 0;
     int achunk = chunk0;       // next chunk to load
     x8 bnext[2][NSB][TN];
     float amax = 0.f;
 
-    auto load_A = [&]() {
-        const int cic = achunk * BK + k4 * 4;
-        const bool kv = cic < cin_pad;
-        ++achunk;
-        aok = 0;
+    // byte offset of halo position r0 + 32 i (k-invariant), 0xFFFFFFF0 when it lies outside the image
+    unsigned hoff[NLD];
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            // the halo position is recomputed per chunk (a handful of VALU per 9 taps) instead of held in registers.
-            // branch-free: rows outside the image / channel range read element 0 and are zeroed when staged
-            const int hp = r0 + 32 * i;
-            const int hy = hp / HW, hx = hp - hy * HW;
-            const int iy = iy_org + hy, ix = ix_org + hx;
-            const bool ok = kv && hp < HROWS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            const int pix = ok ? (n * H + iy) * W + ix : 0;
-            areg[i] = *reinterpret_cast<const f32x4*>(d.in + ((size_t)pix * d.in_ld + d.in_coff + (ok ? cic : 0)));
-            aok |= (ok ? 1u : 0u) << i;
-        }
+    for (int i = 0; i < NLD; ++i) {
+        const int hp = r0 + 32 * i;
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const int iy = iy_org + hy, ix = ix_org + hx;
+        const bool ok = hp < HROWS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        hoff[i] = ok ? (unsigned)((n * H + iy) * W + ix) * ld4 + (unsigned)(d.in_coff + k4 * 4) * 4u : 0xFFFFFFF0u;
+    }
+
+    auto load_A = [&]() {
+        const bool kv = achunk * BK + k4 * 4 < cin_pad;
+        const unsigned coff = (unsigned)achunk * (BK * 4u);       // scalar
+        ++achunk;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            areg[i] = buffer_load16<f32x4>(arsrc, (kv && hoff[i] != 0xFFFFFFF0u) ? hoff[i] + coff : 0xFFFFFFF0u, 0u);
     };
     auto load_B = [&](int step, int m, int p) {
 #pragma unroll
         for (int b = 0; b < TN; ++b)
-            bnext[m][p][b] = *reinterpret_cast<const x8*>(wfrag + (size_t)p * wplane + ((size_t)b * kst + 2 * step + m) * 512);
+            bnext[m][p][b] = buffer_load16<x8>(wrsrc, wlane, wbase + (unsigned)(((size_t)p * wplane + ((size_t)b * kst + 2 * step + m) * 512) * sizeof(elem_t)));
     };
     auto store_A = [&](int i, int buf) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         x4 sp[NSA];
-        split_act<MODE>(((aok >> i) & 1u) ? areg[i] : z, sp, amax);
+        split_act<MODE>(areg[i], sp, amax);
         const int row = r0 + 32 * i;
 #pragma unroll
         for (int p = 0; p < NSA; ++p)
@@ -1354,48 +1358,52 @@ void conv_mfma_h8_kernel(const vps_conv_desc d, const int tiles_m, const int til
     const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;     // wm 0..3: output rows 2 wm, 2 wm + 1 of the patch
     const int nbt = d.cout_pad >> 5, kst = d.kpad >> 4;
     const size_t wplane = (size_t)d.nclass * nbt * kst * 512;
-    const elem_t* __restrict__ wblk = reinterpret_cast<const elem_t*>(d.w_split) +
-        ((size_t)(cls * nbt + tile_n * (BN / 32)) * kst + 2 * (size_t)chunk0 * NTAP) * 512;
+    // buffer-addressed loads (see the pipelined kernel): scalar weight offsets, zero-fill of the halo by an out-of-range offset
+    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(d.w_split, (unsigned)(wplane * NSB * sizeof(elem_t)));
+    const unsigned wbase = (unsigned)((((size_t)(cls * nbt + tile_n * (BN / 32)) * kst + 2 * (size_t)chunk0 * NTAP) * 512) * sizeof(elem_t));
+    const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(d.in, (unsigned)((size_t)d.N * H * W * d.in_ld * sizeof(float)));
+    const unsigned ld4 = (unsigned)d.in_ld * 4u;
 
     f32x4 areg[NLD];
-    unsigned aok = 0;
     int achunk = chunk0;       // next chunk to load
     x8 breg[NBL];
     float amax = 0.f;
 
-    auto load_A = [&]() {
-        const int cic = achunk * BK + k4 * 4;
-        const bool kv = cic < cin_pad;
-        ++achunk;
-        aok = 0;
+    // byte offset of halo position r0 + 64 i (k-invariant), 0xFFFFFFF0 when it lies outside the halo / the image
+    unsigned hoff[NLD];
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            // branch-free: rows outside the halo / image / channel range read element 0 and are zeroed when staged
-            const int hp = r0 + 64 * i;
-            const int hy = hp / HW, hx = hp - hy * HW;
-            const int iy = iy_org + hy, ix = ix_org + hx;
-            const bool ok = kv && hp < HROWS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            const int pix = ok ? (n * H + iy) * W + ix : 0;
-            areg[i] = *reinterpret_cast<const f32x4*>(d.in + ((size_t)pix * d.in_ld + d.in_coff + (ok ? cic : 0)));
-            aok |= (ok ? 1u : 0u) << i;
-        }
+    for (int i = 0; i < NLD; ++i) {
+        const int hp = r0 + 64 * i;
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const int iy = iy_org + hy, ix = ix_org + hx;
+        const bool ok = hp < HROWS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        hoff[i] = ok ? (unsigned)((n * H + iy) * W + ix) * ld4 + (unsigned)(d.in_coff + k4 * 4) * 4u : 0xFFFFFFF0u;
+    }
+
+    auto load_A = [&]() {
+        const bool kv = achunk * BK + k4 * 4 < cin_pad;
+        const unsigned coff = (unsigned)achunk * (BK * 4u);       // scalar
+        ++achunk;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            areg[i] = buffer_load16<f32x4>(arsrc, (kv && hoff[i] != 0xFFFFFFF0u) ? hoff[i] + coff : 0xFFFFFFF0u, 0u);
     };
     auto store_A = [&](int i, int buf) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         x4 sp[NSA];
-        split_act<MODE>(((aok >> i) & 1u) ? areg[i] : z, sp, amax);
+        split_act<MODE>(areg[i], sp, amax);
         const int row = r0 + 64 * i;
 #pragma unroll
         for (int p = 0; p < NSA; ++p)
             *reinterpret_cast<x4*>(&As[buf * ABUF + p * PLANE + row * LDS_LDH + (((k4 >> 1) ^ lds_swz(row)) << 3) + ((k4 & 1) << 2)]) = sp[p];
     };
-    // this thread's 16-byte chunks c = t + 512 j of fragment f = c / 64 = (plane * 2 + slab) * (BN/32) + column block
+    // this thread's 16-byte chunks c = t + 512 j of fragment f = c / 64 = (plane * 2 + slab) * (BN/32) + column block.
+    // The fragment index is wave-uniform for a given j (64 chunks per fragment, 64 lanes per wave): scalar offset + lane * 16
     auto load_B = [&](int step) {
 #pragma unroll
         for (int j = 0; j < NBL; ++j) {
-            const int c = t + 512 * j;
-            const int f = c >> 6, bcol = f % (BN / 32), pm = f / (BN / 32);
-            breg[j] = *reinterpret_cast<const x8*>(wblk + (size_t)(pm >> 1) * wplane + ((size_t)bcol * kst + 2 * step + (pm & 1)) * 512 + (c & 63) * 8);
+            const int f = __builtin_amdgcn_readfirstlane((t + 512 * j) >> 6), bcol = f % (BN / 32), pm = f / (BN / 32);
+            breg[j] = buffer_load16<x8>(wrsrc, (unsigned)lane * 16u,
+                                        wbase + (unsigned)(((size_t)(pm >> 1) * wplane + ((size_t)bcol * kst + 2 * step + (pm & 1)) * 512) * sizeof(elem_t)));
         }
     };
     auto store_B = [&](int buf) {
@@ -1579,11 +1587,13 @@ void conv_mfma_h8s2_kernel(const vps_conv_desc d, const int tiles_m, const int t
     const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
     const int nbt = d.cout_pad >> 5, kst = d.kpad >> 4;
     const size_t wplane = (size_t)nbt * kst * 512;
-    const elem_t* __restrict__ wblk = reinterpret_cast<const elem_t*>(d.w_split) +
-        ((size_t)(tile_n * (BN / 32)) * kst + 2 * (size_t)chunk0 * NTAP) * 512;
+    // buffer-addressed loads (see the pipelined kernel): scalar weight offsets, zero-fill of the patch by an out-of-range offset
+    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(d.w_split, (unsigned)(wplane * NSB * sizeof(elem_t)));
+    const unsigned wbase = (unsigned)((((size_t)(tile_n * (BN / 32)) * kst + 2 * (size_t)chunk0 * NTAP) * 512) * sizeof(elem_t));
+    const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(d.in, (unsigned)((size_t)d.N * H * W * d.in_ld * sizeof(float)));
+    const unsigned ld4 = (unsigned)d.in_ld * 4u;
 
     f32x4 areg[NLD];
-    unsigned aok = 0;
     int achunk = chunk0, aph = 0;      // next (chunk, phase) stage to load
     x8 breg[NBL];
     float amax = 0.f;
@@ -1594,23 +1604,20 @@ void conv_mfma_h8s2_kernel(const vps_conv_desc d, const int tiles_m, const int t
         const int rows = 8 + ((K - a + 1) >> 1) - 1, cols = 32 + ((K - b + 1) >> 1) - 1;
         const int cic = achunk * BK + k4 * 4;
         const bool kv = cic < cin_pad;
+        const unsigned coff = (unsigned)(d.in_coff + cic) * 4u;
         if (++aph == 4) { aph = 0; ++achunk; }
-        aok = 0;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int hp = r0 + 64 * i;
             const int hy = hp / HW, hx = hp - hy * HW;
             const int iy = iy_org + a + 2 * hy, ix = ix_org + b + 2 * hx;
             const bool ok = kv && hy < rows && hx < cols && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            const int pix = ok ? (n * H + iy) * W + ix : 0;
-            areg[i] = *reinterpret_cast<const f32x4*>(d.in + ((size_t)pix * d.in_ld + d.in_coff + (ok ? cic : 0)));
-            aok |= (ok ? 1u : 0u) << i;
+            areg[i] = buffer_load16<f32x4>(arsrc, ok ? (unsigned)((n * H + iy) * W + ix) * ld4 + coff : 0xFFFFFFF0u, 0u);
         }
     };
     auto store_A = [&](int i, int buf) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         x4 sp[NSA];
-        split_act<MODE>(((aok >> i) & 1u) ? areg[i] : z, sp, amax);
+        split_act<MODE>(areg[i], sp, amax);
         const int row = r0 + 64 * i;
 #pragma unroll
         for (int p = 0; p < NSA; ++p)
@@ -1620,9 +1627,9 @@ void conv_mfma_h8s2_kernel(const vps_conv_desc d, const int tiles_m, const int t
     auto load_B = [&](int wstep) {
 #pragma unroll
         for (int j = 0; j < NBL; ++j) {
-            const int c = t + 512 * j;
-            const int f = c >> 6, bcol = f % (BN / 32), pm = f / (BN / 32);
-            breg[j] = *reinterpret_cast<const x8*>(wblk + (size_t)(pm >> 1) * wplane + ((size_t)bcol * kst + 2 * wstep + (pm & 1)) * 512 + (c & 63) * 8);
+            const int f = __builtin_amdgcn_readfirstlane((t + 512 * j) >> 6), bcol = f % (BN / 32), pm = f / (BN / 32);
+            breg[j] = buffer_load16<x8>(wrsrc, (unsigned)lane * 16u,
+                                        wbase + (unsigned)(((size_t)(pm >> 1) * wplane + ((size_t)bcol * kst + 2 * wstep + (pm & 1)) * 512) * sizeof(elem_t)));
         }
     };
     auto store_B = [&](int buf) {

@@ -2,6 +2,7 @@
 // layout transposes, FlowNet2 input prep and the fused inter-stage tensor builder. All HBM-bound.
 // Reference (relative to /root/reference/mmdet/models/flow_modules unless noted) is cited per kernel.
 #include "common.h"
+#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -132,6 +133,147 @@ void correlation_kernel(const float* __restrict__ in1, int ld1, int coff1,
             const int dd = d0 + lane;
             if (dd < ND) out[(size_t)pix * out_ld + out_coff + dd] = vps_act(v[0] * invC, act, slope);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Correlation with ONE LANE PER OUTPUT PIXEL (round 3). The kernels above and below put the CHANNELS on the lanes, so every
+// output value needs a 64-lane reduction (as many shuffle / select instructions as multiply-adds). Here the channel loop is
+// sequential and a lane owns P neighbouring output pixels and all D displacements of one displacement row:
+//     acc[p][ti] += A[c][u + p] * B[c][u + p + ti]          (plane coordinates u: x = S2 * u + parity)
+// with both operands read from LDS tiles that were transposed when staged ([channel][plane position], lanes on consecutive
+// positions: conflict-free 8 / 16-byte reads), P + D - 1 reads of B for P * D multiply-adds - no cross-lane traffic at all.
+// Work decomposition: workgroup = (image, row y, column parity, 64 P positions, group of 4 displacement rows), wave w of it =
+// displacement row tj = 4 * group + w; the A tile (8 channels) is shared by the 4 waves, each wave stages its own B row tile.
+// Stride-2 displacements (FlowNetC) only ever pair pixels of equal column parity: each parity plane is a stride-1 problem.
+// Out-of-image samples are zeros: the loads are buffer loads whose offset lies beyond the tensor for them.
+// Arithmetic: fp32 multiply-adds in channel order, * 1/C at the end (the reference sums per 32-lane warp in another order:
+// agreement to ~1e-6 like the kernels above).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 corr_buffer_load16(const __amdgpu_buffer_rsrc_t r, const unsigned off) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+
+template <int S2, int R, int P>
+__global__ __launch_bounds__(256)
+void correlation_lds_kernel(const float* __restrict__ in1, int ld1, int coff1, const float* __restrict__ in2, int ld2, int coff2,
+                            float* __restrict__ out, int out_ld, int out_coff, int N, int H, int W, int C, int act, float slope) {
+    constexpr int D = 2 * R + 1;
+    constexpr int CC = 8;                 // channels per stage
+    constexpr int UW = 64 * P;            // plane positions of a workgroup
+    constexpr int BW = UW + 2 * R;        // B tile: positions u0 - R .. u0 + UW + R - 1
+    constexpr int BWP = (BW + 7) & ~3;    // row pitch (floats), 16-byte multiple, +1 quad of slack for the vector reads
+    constexpr int NBL = (BW * 2 + 63) / 64;   // f32x4 loads per lane and B stage
+    __shared__ __attribute__((aligned(16))) float As[CC * UW];
+    __shared__ __attribute__((aligned(16))) float Bs[4][CC * BWP];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int planeW = W / S2, segs = planeW / UW, groups = (D + 3) / 4;
+    int bid = blockIdx.x;
+    const int grp = bid % groups; bid /= groups;
+    const int useg = bid % segs; bid /= segs;
+    const int par = bid % S2; bid /= S2;
+    const int y = bid % H, n = bid / H;
+    const int u0 = useg * UW;
+    const int tjw = grp * 4 + wave;                  // this wave's displacement row index 0 .. D-1 (>= D: idle wave)
+    const bool active = tjw < D;
+    const int y2 = y + (tjw - R) * S2;
+    const bool rowok = active && (unsigned)y2 < (unsigned)H;
+
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in1), 0, (int)((size_t)N * H * W * ld1 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in2), 0, (int)((size_t)N * H * W * ld2 * 4), 0x00020000);
+    // A staging: 256 threads x one f32x4 = UW positions x 2 channel quads (P = 2) or two passes (P = 4)
+    constexpr int NAL = UW * 2 / 256;                // f32x4 loads per thread and A stage (1 or 2)
+    unsigned aoff[NAL];
+    int aj[NAL], aq[NAL];
+#pragma unroll
+    for (int i = 0; i < NAL; ++i) {
+        const int e = t + 256 * i;
+        aq[i] = e / UW; aj[i] = e - aq[i] * UW;
+        const int x = S2 * (u0 + aj[i]) + par;
+        aoff[i] = (unsigned)(((size_t)(n * H + y) * W + x) * ld1 + coff1 + 4 * aq[i]) * 4u;
+    }
+    // B staging (per wave): entry e = lane + 64 i -> (channel quad q, tile position j)
+    unsigned boff[NBL];
+    int bj[NBL], bq[NBL];
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+        const int e = lane + 64 * i;
+        bq[i] = e / BW; bj[i] = e - bq[i] * BW;
+        const int u = u0 - R + bj[i];
+        const bool ok = rowok && bq[i] < 2 && (unsigned)u < (unsigned)planeW;
+        const int x = S2 * u + par;
+        boff[i] = ok ? (unsigned)(((size_t)(n * H + (rowok ? y2 : 0)) * W + x) * ld2 + coff2 + 4 * bq[i]) * 4u : 0xFFFFFFF0u;
+    }
+
+    float acc[P][D];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int k = 0; k < D; ++k) acc[p][k] = 0.f;
+
+    float* __restrict__ bs = &Bs[wave][0];
+    for (int c0 = 0; c0 < C; c0 += CC) {
+        // ---- stage: global -> registers -> transposed LDS tiles
+        f32x4 av[NAL], bv[NBL];
+#pragma unroll
+        for (int i = 0; i < NAL; ++i) av[i] = corr_buffer_load16(r1, aoff[i] + (unsigned)c0 * 4u);
+#pragma unroll
+        for (int i = 0; i < NBL; ++i) bv[i] = corr_buffer_load16(r2, boff[i] == 0xFFFFFFF0u ? 0xFFFFFFF0u : boff[i] + (unsigned)c0 * 4u);
+        __syncthreads();                               // the previous stage's readers are done with both tiles
+#pragma unroll
+        for (int i = 0; i < NAL; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) As[(4 * aq[i] + e) * UW + aj[i]] = av[i][e];
+#pragma unroll
+        for (int i = 0; i < NBL; ++i)
+            if (bq[i] < 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bs[(4 * bq[i] + e) * BWP + bj[i]] = bv[i][e];
+            }
+        __syncthreads();
+        if (!active) continue;
+        // ---- compute: lane owns positions lane * P .. lane * P + P - 1
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            float a[P], b[P + D - 1];
+            if constexpr (P == 4) {
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(&As[c * UW + lane * 4]);
+                a[0] = t4[0]; a[1] = t4[1]; a[2] = t4[2]; a[3] = t4[3];
+#pragma unroll
+                for (int k = 0; k < (P + D - 1 + 3) / 4; ++k) {
+                    const f32x4 q4 = *reinterpret_cast<const f32x4*>(&bs[c * BWP + lane * 4 + 4 * k]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (4 * k + e < P + D - 1) b[4 * k + e] = q4[e];
+                }
+            } else {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 t2 = *reinterpret_cast<const f32x2*>(&As[c * UW + lane * 2]);
+                a[0] = t2[0]; a[1] = t2[1];
+#pragma unroll
+                for (int k = 0; k < (P + D - 1 + 1) / 2; ++k) {
+                    const f32x2 q2 = *reinterpret_cast<const f32x2*>(&bs[c * BWP + lane * 2 + 2 * k]);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        if (2 * k + e < P + D - 1) b[2 * k + e] = q2[e];
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc[p][k] = fmaf(a[p], b[p + k], acc[p][k]);
+        }
+    }
+    if (!active) return;
+    const float invC = 1.0f / (float)C;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int x = S2 * (u0 + lane * P + p) + par;
+        float* __restrict__ o = out + ((size_t)(n * H + y) * W + x) * out_ld + out_coff + tjw * D;
+#pragma unroll
+        for (int k = 0; k < D; ++k) o[k] = vps_act(acc[p][k] * invC, act, slope);
     }
 }
 
@@ -580,6 +722,21 @@ extern "C" int vps_correlation(const float* in1, int ld1, int coff1, const float
     hipLaunchKernelGGL((correlation4_kernel<S2, R, NC4>), dim3((unsigned)g4), dim3(256), 0, s, in1, ld1, coff1, in2, ld2, \
                        coff2, out, out_ld, out_coff, N, H, W, C, act, slope)
     long g4 = ((long)N * H * (W / 4) + 3) / 4; if (g4 > 65536) g4 = 65536;
+    // lane-per-pixel kernel (LDS-transposed tiles, no cross-lane reduction) when the row splits into whole 64 P position segments
+    static const bool lds_off = getenv("VPS_CORR_LDS") && getenv("VPS_CORR_LDS")[0] == '0';        // A/B switch
+    const bool small4g = (size_t)N * H * W * ld1 * 4 < 0xFFFFFFF0ull && (size_t)N * H * W * ld2 * 4 < 0xFFFFFFF0ull && (C & 7) == 0;
+    if (!lds_off && small4g && stride2 == 2 && r == 10 && W % 256 == 0) {
+        const long nb = (long)N * H * 2 * (W / 256) * 6;
+        hipLaunchKernelGGL((correlation_lds_kernel<2, 10, 2>), dim3((unsigned)nb), dim3(256), 0, s, in1, ld1, coff1, in2, ld2, coff2, out, out_ld,
+                           out_coff, N, H, W, C, act, slope);
+        return vps_launch_status();
+    }
+    if (!lds_off && small4g && stride2 == 1 && r == 4 && W % 256 == 0) {
+        const long nb = (long)N * H * (W / 256) * 3;
+        hipLaunchKernelGGL((correlation_lds_kernel<1, 4, 4>), dim3((unsigned)nb), dim3(256), 0, s, in1, ld1, coff1, in2, ld2, coff2, out, out_ld,
+                           out_coff, N, H, W, C, act, slope);
+        return vps_launch_status();
+    }
     if (stride2 == 2 && r == 10 && (W % 8) == 0 && C <= 256) { CORR4_LAUNCH(2, 10, 1); return vps_launch_status(); }
     if (stride2 == 1 && r == 4 && (W % 4) == 0 && C <= 256) { CORR4_LAUNCH(1, 4, 1); return vps_launch_status(); }
 #undef CORR4_LAUNCH

@@ -81,6 +81,7 @@ CONV_TRACE = None
 # the device-scope release / acquire around the ticket (buffer_wbl2 / buffer_inv: the partials of a tile come from blocks on
 # different XCDs, each with its own L2) writes back and invalidates a whole L2 per block. Kept as an option, OFF.
 SPLITK_LAST_BLOCK = os.environ.get('VPS_SPLITK_LAST_BLOCK', '0') == '1'
+SMALL_ON_MFMA = os.environ.get('VPS_SMALL_MFMA', '0') == '1'
 GN_REP = 32   # copies of the GroupNorm sums a conv epilogue spreads its atomics over (vps_conv_desc.gn_rep)
 
 
@@ -185,7 +186,11 @@ class PackedConv:
         w = weight.detach().float().cpu()
         self.prec = DEFAULT_PREC if prec is None else prec
         nout = w.shape[1] if transposed else w.shape[0]
-        self.small = nout <= 4 and not deform          # narrow outputs run on the exact-fp32 vector kernel in every mode
+        # narrow outputs (predict_flow, the 2-channel flow up-convolutions, 3-channel heads) run on the exact-fp32 vector kernel.
+        # VPS_SMALL_MFMA=1 (A/B switch): the 3x3 ones with >= 32 input channels go to the matrix cores like every other layer
+        # (cout padded to a 32-column tile)
+        nin = w.shape[0] if transposed else w.shape[1]
+        self.small = nout <= 4 and not deform and not (SMALL_ON_MFMA and not transposed and w.shape[2] == 3 and nin >= 32)
         if self.small:
             self.prec = hip.PREC_F32
         self.stride = stride
