@@ -139,33 +139,38 @@ void correlation_kernel(const float* __restrict__ in1, int ld1, int coff1,
 // ------------------------------------------------------------------------------------------------
 // Correlation with ONE LANE PER OUTPUT PIXEL (round 3). The kernels above and below put the CHANNELS on the lanes, so every
 // output value needs a 64-lane reduction (as many shuffle / select instructions as multiply-adds). Here the channel loop is
-// sequential and a lane owns P neighbouring output pixels and all D displacements of one displacement row:
+// sequential and a lane owns P = 2 neighbouring output pixels and all D displacements of one displacement row:
 //     acc[p][ti] += A[c][u + p] * B[c][u + p + ti]          (plane coordinates u: x = S2 * u + parity)
 // with both operands read from LDS tiles that were transposed when staged ([channel][plane position], lanes on consecutive
-// positions: conflict-free 8 / 16-byte reads), P + D - 1 reads of B for P * D multiply-adds - no cross-lane traffic at all.
-// Work decomposition: workgroup = (image, row y, column parity, 64 P positions, group of 4 displacement rows), wave w of it =
-// displacement row tj = 4 * group + w; the A tile (8 channels) is shared by the 4 waves, each wave stages its own B row tile.
+// positions: conflict-free 8-byte reads), P + D - 1 reads of B for P * D multiply-adds - no cross-lane traffic at all.
+// Work decomposition: workgroup = (image, row y, column parity, 128 plane positions, group of 4 displacement rows), wave w of
+// it = displacement row tj = 4 * group + w; the A tile is shared by the 4 waves, each wave stages its own B row tile.
 // Stride-2 displacements (FlowNetC) only ever pair pixels of equal column parity: each parity plane is a stride-1 problem.
+// A stage covers 32 channels = one whole 128-byte line per pixel (8 lanes x 16 bytes, coalesced; staging 8 channels at a time
+// fetched every line four times through a thrashing L1: 1.1 ms instead of 0.27 for the 81-channel case). The loads of stage
+// s + 1 are issued before the multiply-adds of stage s (registers -> LDS after the next barrier).
 // Out-of-image samples are zeros: the loads are buffer loads whose offset lies beyond the tensor for them.
 // Arithmetic: fp32 multiply-adds in channel order, * 1/C at the end (the reference sums per 32-lane warp in another order:
 // agreement to ~1e-6 like the kernels above).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ f32x4 corr_buffer_load16(const __amdgpu_buffer_rsrc_t r, const unsigned off) {
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
 }
 
-template <int S2, int R, int P>
+template <int S2, int R>
 __global__ __launch_bounds__(256)
 void correlation_lds_kernel(const float* __restrict__ in1, int ld1, int coff1, const float* __restrict__ in2, int ld2, int coff2,
                             float* __restrict__ out, int out_ld, int out_coff, int N, int H, int W, int C, int act, float slope) {
     constexpr int D = 2 * R + 1;
-    constexpr int CC = 8;                 // channels per stage
+    constexpr int P = 2;
+    constexpr int CC = 32;                // channels per stage: one 128-byte line per pixel
     constexpr int UW = 64 * P;            // plane positions of a workgroup
     constexpr int BW = UW + 2 * R;        // B tile: positions u0 - R .. u0 + UW + R - 1
-    constexpr int BWP = (BW + 7) & ~3;    // row pitch (floats), 16-byte multiple, +1 quad of slack for the vector reads
-    constexpr int NBL = (BW * 2 + 63) / 64;   // f32x4 loads per lane and B stage
-    __shared__ __attribute__((aligned(16))) float As[CC * UW];
+    constexpr int AWP = UW + 2;           // row pitches (floats): even (8-byte reads), = 2 mod 8 (transposing writes: 2-way conflicts)
+    constexpr int BWP = ((BW + 7) & ~7) + 2;
+    constexpr int NAL = UW * 8 / 256;         // f32x4 loads per thread and A stage
+    constexpr int NBL = (BW * 8 + 63) / 64;   // f32x4 loads per lane and B stage
+    __shared__ __attribute__((aligned(16))) float As[CC * AWP];
     __shared__ __attribute__((aligned(16))) float Bs[4][CC * BWP];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -183,28 +188,22 @@ void correlation_lds_kernel(const float* __restrict__ in1, int ld1, int coff1, c
 
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in1), 0, (int)((size_t)N * H * W * ld1 * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in2), 0, (int)((size_t)N * H * W * ld2 * 4), 0x00020000);
-    // A staging: 256 threads x one f32x4 = UW positions x 2 channel quads (P = 2) or two passes (P = 4)
-    constexpr int NAL = UW * 2 / 256;                // f32x4 loads per thread and A stage (1 or 2)
+    // entry e -> (plane position j = e / 8, channel quad q = e % 8): the 8 lanes of a pixel read its 128-byte line
     unsigned aoff[NAL];
-    int aj[NAL], aq[NAL];
 #pragma unroll
     for (int i = 0; i < NAL; ++i) {
-        const int e = t + 256 * i;
-        aq[i] = e / UW; aj[i] = e - aq[i] * UW;
-        const int x = S2 * (u0 + aj[i]) + par;
-        aoff[i] = (unsigned)(((size_t)(n * H + y) * W + x) * ld1 + coff1 + 4 * aq[i]) * 4u;
+        const int e = t + 256 * i, j = e >> 3, q = e & 7;
+        const int x = S2 * (u0 + j) + par;
+        aoff[i] = (unsigned)(((size_t)(n * H + y) * W + x) * ld1 + coff1 + 4 * q) * 4u;
     }
-    // B staging (per wave): entry e = lane + 64 i -> (channel quad q, tile position j)
     unsigned boff[NBL];
-    int bj[NBL], bq[NBL];
 #pragma unroll
     for (int i = 0; i < NBL; ++i) {
-        const int e = lane + 64 * i;
-        bq[i] = e / BW; bj[i] = e - bq[i] * BW;
-        const int u = u0 - R + bj[i];
-        const bool ok = rowok && bq[i] < 2 && (unsigned)u < (unsigned)planeW;
+        const int e = lane + 64 * i, j = e >> 3, q = e & 7;
+        const int u = u0 - R + j;
+        const bool ok = rowok && j < BW && (unsigned)u < (unsigned)planeW;
         const int x = S2 * u + par;
-        boff[i] = ok ? (unsigned)(((size_t)(n * H + (rowok ? y2 : 0)) * W + x) * ld2 + coff2 + 4 * bq[i]) * 4u : 0xFFFFFFF0u;
+        boff[i] = ok ? (unsigned)(((size_t)(n * H + (rowok ? y2 : 0)) * W + x) * ld2 + coff2 + 4 * q) * 4u : 0xFFFFFFF0u;
     }
 
     float acc[P][D];
@@ -214,56 +213,49 @@ void correlation_lds_kernel(const float* __restrict__ in1, int ld1, int coff1, c
         for (int k = 0; k < D; ++k) acc[p][k] = 0.f;
 
     float* __restrict__ bs = &Bs[wave][0];
-    for (int c0 = 0; c0 < C; c0 += CC) {
-        // ---- stage: global -> registers -> transposed LDS tiles
-        f32x4 av[NAL], bv[NBL];
+    f32x4 av[NAL], bv[NBL];
+    auto issue = [&](const int c0) {
 #pragma unroll
         for (int i = 0; i < NAL; ++i) av[i] = corr_buffer_load16(r1, aoff[i] + (unsigned)c0 * 4u);
 #pragma unroll
         for (int i = 0; i < NBL; ++i) bv[i] = corr_buffer_load16(r2, boff[i] == 0xFFFFFFF0u ? 0xFFFFFFF0u : boff[i] + (unsigned)c0 * 4u);
+    };
+    issue(0);
+    for (int c0 = 0; c0 < C; c0 += CC) {
         __syncthreads();                               // the previous stage's readers are done with both tiles
 #pragma unroll
-        for (int i = 0; i < NAL; ++i)
+        for (int i = 0; i < NAL; ++i) {
+            const int e = t + 256 * i, j = e >> 3, q = e & 7;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) As[(4 * aq[i] + e) * UW + aj[i]] = av[i][e];
+            for (int k = 0; k < 4; ++k) As[(4 * q + k) * AWP + j] = av[i][k];
+        }
 #pragma unroll
-        for (int i = 0; i < NBL; ++i)
-            if (bq[i] < 2) {
+        for (int i = 0; i < NBL; ++i) {
+            const int e = lane + 64 * i, j = e >> 3, q = e & 7;
+            if (j < BW) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bs[(4 * bq[i] + e) * BWP + bj[i]] = bv[i][e];
+                for (int k = 0; k < 4; ++k) bs[(4 * q + k) * BWP + j] = bv[i][k];
             }
+        }
         __syncthreads();
+        if (c0 + CC < C) issue(c0 + CC);               // in flight under this stage's multiply-adds
         if (!active) continue;
-        // ---- compute: lane owns positions lane * P .. lane * P + P - 1
-#pragma unroll
+        // ---- compute: lane owns positions lane * 2, lane * 2 + 1
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll 4
         for (int c = 0; c < CC; ++c) {
-            float a[P], b[P + D - 1];
-            if constexpr (P == 4) {
-                const f32x4 t4 = *reinterpret_cast<const f32x4*>(&As[c * UW + lane * 4]);
-                a[0] = t4[0]; a[1] = t4[1]; a[2] = t4[2]; a[3] = t4[3];
+            float b[P + D - 1 + 1];
+            const f32x2 a2 = *reinterpret_cast<const f32x2*>(&As[c * AWP + lane * 2]);
 #pragma unroll
-                for (int k = 0; k < (P + D - 1 + 3) / 4; ++k) {
-                    const f32x4 q4 = *reinterpret_cast<const f32x4*>(&bs[c * BWP + lane * 4 + 4 * k]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (4 * k + e < P + D - 1) b[4 * k + e] = q4[e];
-                }
-            } else {
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                const f32x2 t2 = *reinterpret_cast<const f32x2*>(&As[c * UW + lane * 2]);
-                a[0] = t2[0]; a[1] = t2[1];
-#pragma unroll
-                for (int k = 0; k < (P + D - 1 + 1) / 2; ++k) {
-                    const f32x2 q2 = *reinterpret_cast<const f32x2*>(&bs[c * BWP + lane * 2 + 2 * k]);
-#pragma unroll
-                    for (int e = 0; e < 2; ++e)
-                        if (2 * k + e < P + D - 1) b[2 * k + e] = q2[e];
-                }
+            for (int k = 0; k < (P + D - 1 + 1) / 2; ++k) {
+                const f32x2 q2 = *reinterpret_cast<const f32x2*>(&bs[c * BWP + lane * 2 + 2 * k]);
+                b[2 * k] = q2[0]; b[2 * k + 1] = q2[1];
             }
 #pragma unroll
-            for (int p = 0; p < P; ++p)
-#pragma unroll
-                for (int k = 0; k < D; ++k) acc[p][k] = fmaf(a[p], b[p + k], acc[p][k]);
+            for (int k = 0; k < D; ++k) {
+                acc[0][k] = fmaf(a2[0], b[k], acc[0][k]);
+                acc[1][k] = fmaf(a2[1], b[k + 1], acc[1][k]);
+            }
         }
     }
     if (!active) return;
@@ -724,16 +716,16 @@ extern "C" int vps_correlation(const float* in1, int ld1, int coff1, const float
     long g4 = ((long)N * H * (W / 4) + 3) / 4; if (g4 > 65536) g4 = 65536;
     // lane-per-pixel kernel (LDS-transposed tiles, no cross-lane reduction) when the row splits into whole 64 P position segments
     static const bool lds_off = getenv("VPS_CORR_LDS") && getenv("VPS_CORR_LDS")[0] == '0';        // A/B switch
-    const bool small4g = (size_t)N * H * W * ld1 * 4 < 0xFFFFFFF0ull && (size_t)N * H * W * ld2 * 4 < 0xFFFFFFF0ull && (C & 7) == 0;
+    const bool small4g = (size_t)N * H * W * ld1 * 4 < 0xFFFFFFF0ull && (size_t)N * H * W * ld2 * 4 < 0xFFFFFFF0ull && (C & 31) == 0;
     if (!lds_off && small4g && stride2 == 2 && r == 10 && W % 256 == 0) {
         const long nb = (long)N * H * 2 * (W / 256) * 6;
-        hipLaunchKernelGGL((correlation_lds_kernel<2, 10, 2>), dim3((unsigned)nb), dim3(256), 0, s, in1, ld1, coff1, in2, ld2, coff2, out, out_ld,
+        hipLaunchKernelGGL((correlation_lds_kernel<2, 10>), dim3((unsigned)nb), dim3(256), 0, s, in1, ld1, coff1, in2, ld2, coff2, out, out_ld,
                            out_coff, N, H, W, C, act, slope);
         return vps_launch_status();
     }
-    if (!lds_off && small4g && stride2 == 1 && r == 4 && W % 256 == 0) {
-        const long nb = (long)N * H * (W / 256) * 3;
-        hipLaunchKernelGGL((correlation_lds_kernel<1, 4, 4>), dim3((unsigned)nb), dim3(256), 0, s, in1, ld1, coff1, in2, ld2, coff2, out, out_ld,
+    if (!lds_off && small4g && stride2 == 1 && r == 4 && W % 128 == 0) {
+        const long nb = (long)N * H * (W / 128) * 3;
+        hipLaunchKernelGGL((correlation_lds_kernel<1, 4>), dim3((unsigned)nb), dim3(256), 0, s, in1, ld1, coff1, in2, ld2, coff2, out, out_ld,
                            out_coff, N, H, W, C, act, slope);
         return vps_launch_status();
     }

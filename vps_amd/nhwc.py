@@ -81,7 +81,7 @@ CONV_TRACE = None
 # the device-scope release / acquire around the ticket (buffer_wbl2 / buffer_inv: the partials of a tile come from blocks on
 # different XCDs, each with its own L2) writes back and invalidates a whole L2 per block. Kept as an option, OFF.
 SPLITK_LAST_BLOCK = os.environ.get('VPS_SPLITK_LAST_BLOCK', '0') == '1'
-SMALL_ON_MFMA = os.environ.get('VPS_SMALL_MFMA', '0') == '1'
+SMALL_ON_MFMA = os.environ.get('VPS_SMALL_MFMA', '1') != '0'      # 0: narrow-output layers always on the vector kernel (A/B runs)
 GN_REP = 32   # copies of the GroupNorm sums a conv epilogue spreads its atomics over (vps_conv_desc.gn_rep)
 
 
@@ -182,15 +182,20 @@ class PackedConv:
     """
 
     def __init__(self, weight, bias=None, bn=None, stride=1, padding=0, act=hip.ACT_NONE, slope=0.1,
-                 transposed=False, deform=False, device='cuda', prec=None):
+                 transposed=False, deform=False, device='cuda', prec=None, _twin=False):
         w = weight.detach().float().cpu()
         self.prec = DEFAULT_PREC if prec is None else prec
         nout = w.shape[1] if transposed else w.shape[0]
-        # narrow outputs (predict_flow, the 2-channel flow up-convolutions, 3-channel heads) run on the exact-fp32 vector kernel.
-        # VPS_SMALL_MFMA=1 (A/B switch): the 3x3 ones with >= 32 input channels go to the matrix cores like every other layer
-        # (cout padded to a 32-column tile)
+        # narrow outputs (predict_flow, the 2-channel flow up-convolutions, 3-channel heads) run on the exact-fp32 vector kernel in
+        # every mode - except where the matrix cores win although 30 of the 32 output columns of their tile are padding: 3x3 layers
+        # with >= 64 input channels on >= 100 000 pixels (measured per layer, profiles/r03_conv_table_small_on_mfma.txt: predict_flow2
+        # 194->2 @256x512 0.133 -> 0.080 ms per call; the low-resolution ones are faster on the vector kernel). Such a layer is
+        # packed both ways and `__call__` picks by the size of the map.
         nin = w.shape[0] if transposed else w.shape[1]
-        self.small = nout <= 4 and not deform and not (SMALL_ON_MFMA and not transposed and w.shape[2] == 3 and nin >= 32)
+        self.small = nout <= 4 and not deform and not _twin
+        self._mfma_twin = None
+        if self.small and SMALL_ON_MFMA and not transposed and w.shape[2] == 3 and nin >= 64 and (DEFAULT_PREC if prec is None else prec) != hip.PREC_F32:
+            self._mfma_twin = PackedConv(weight, bias, bn, stride, padding, act, slope, transposed, deform, device, prec, _twin=True)
         if self.small:
             self.prec = hip.PREC_F32
         self.stride = stride
@@ -365,6 +370,8 @@ class PackedConv:
         gn = (stats, G): float64 tensor [GN_REP, 2*G] of zeros that receives the GroupNorm sums of the output from the epilogue
         (vps_conv_desc.gn_stats; deformable layers of the split-operand modes). `self.gn_fused` tells whether the launch took
         them (it does not when the layer is split over K) - the caller then runs the statistics pass itself."""
+        if getattr(self, '_mfma_twin', None) is not None and x.N * x.H * x.W >= 100000:
+            return self._mfma_twin(x, out, ws, name, res, res_shift, offset, act, gn)
         assert x.C == self.cin or (x.C >= self.cin and x.C <= self.cin_pad), (x.C, self.cin)
         assert x.coff % 4 == 0 and x.ld % 4 == 0 and x.coff + self.cin_pad <= x.ld, (x.coff, x.ld, self.cin_pad)
         Ho, Wo = self.out_hw(x.H, x.W)
