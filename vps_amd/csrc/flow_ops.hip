@@ -723,7 +723,11 @@ extern "C" int vps_correlation(const float* in1, int ld1, int coff1, const float
                            out_coff, N, H, W, C, act, slope);
         return vps_launch_status();
     }
-    if (!lds_off && small4g && stride2 == 1 && r == 4 && W % 128 == 0) {
+    // the 81-channel (9 x 9) case stays on the channel-lane kernel below: with only 9 displacements per row the lane-per-pixel kernel
+    // reads 10 B values from LDS per 18 multiply-adds and is LDS-bandwidth bound (measured 409 us against 271 us); VPS_CORR_LDS=2
+    // forces it (A/B)
+    static const bool lds_all = getenv("VPS_CORR_LDS") && getenv("VPS_CORR_LDS")[0] == '2';
+    if (lds_all && small4g && stride2 == 1 && r == 4 && W % 128 == 0) {
         const long nb = (long)N * H * (W / 128) * 3;
         hipLaunchKernelGGL((correlation_lds_kernel<1, 4>), dim3((unsigned)nb), dim3(256), 0, s, in1, ld1, coff1, in2, ld2, coff2, out, out_ld,
                            out_coff, N, H, W, C, act, slope);
