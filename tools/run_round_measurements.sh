@@ -1,18 +1,25 @@
-mkdir -p gpurun_out; R=$PWD
-if [ -z "$SKIP_PYTEST" ]; then python -m pytest tests -m gpu -q --tb=short -rf -p no:cacheprovider > gpurun_out/pytest6.log 2>&1; tail -6 gpurun_out/pytest6.log; fi
-python bench.py --steps 20 --warmup 5 --conv-table gpurun_out/conv_table_r02_f16x3.txt > gpurun_out/bench6_default.json 2> gpurun_out/bench6.err; head -c 260 gpurun_out/bench6_default.json; echo
-python bench.py --model-config configs/viper/fusetrack_r101.py --height 1088 --width 1920 --prec bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/bench6_config5_bf16.json 2>> gpurun_out/bench6.err; head -c 260 gpurun_out/bench6_config5_bf16.json; echo
-python bench.py --model-config configs/viper/fusetrack_r101.py --height 1088 --width 1920 --prec f16x3 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/bench6_config5_f16x3.json 2>> gpurun_out/bench6.err; head -c 260 gpurun_out/bench6_config5_f16x3.json; echo
+# The judged measurement set of a round in one gpurun call (writes gpurun_out/; copy what is to be judged into profiles/).
+#   gpurun --timeout 2400 -- 'bash tools/run_round_measurements.sh'          SKIP_PYTEST=1 skips the GPU test suite
+mkdir -p gpurun_out; R=$PWD; T=${TAG:-r03}
+if [ -z "$SKIP_PYTEST" ]; then python -m pytest tests -m gpu -q --tb=short -rf -p no:cacheprovider > gpurun_out/${T}_pytest_gpu.log 2>&1; tail -6 gpurun_out/${T}_pytest_gpu.log; fi
+python bench.py --steps 20 --warmup 5 --conv-table gpurun_out/${T}_conv_table_f16x3.txt > gpurun_out/${T}_bench_default_f16x3.json 2> gpurun_out/${T}_bench.err; head -c 200 gpurun_out/${T}_bench_default_f16x3.json; echo
+python bench.py --model-config configs/viper/fusetrack_r101.py --height 1088 --width 1920 --prec f16x3 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/${T}_bench_config5_r101_1088x1920_f16x3.json 2>> gpurun_out/${T}_bench.err; head -c 200 gpurun_out/${T}_bench_config5_r101_1088x1920_f16x3.json; echo
+# VPQ of the benchmarked arithmetic against the exact-fp32 kernels, whole drop-in chain (tools/test_vpq.py + eval_vpq.py mirror), 1024x2048:
+# on the near-tied synthetic heads and on the well-separated fixture head
+python tools/run_vps_synthetic.py --height 1024 --width 2048 --videos 2 --frames 30 --prec f16x3 --gt-prec f32 --out gpurun_out/vps_near_tied > gpurun_out/${T}_vpq_f16x3_vs_f32_1024x2048_near_tied.json 2>> gpurun_out/${T}_bench.err
+python tools/run_vps_synthetic.py --height 1024 --width 2048 --videos 2 --frames 30 --prec f16x3 --gt-prec f32 --separated --out gpurun_out/vps_separated > gpurun_out/${T}_vpq_f16x3_vs_f32_1024x2048_separated.json 2>> gpurun_out/${T}_bench.err
+tail -n 1 gpurun_out/${T}_vpq_f16x3_vs_f32_1024x2048_near_tied.json | head -c 300; echo; tail -n 1 gpurun_out/${T}_vpq_f16x3_vs_f32_1024x2048_separated.json | head -c 300; echo
+rm -rf gpurun_out/vps_near_tied gpurun_out/vps_separated
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ss -o ss -- python $R/bench.py --steps 10 --warmup 3 --single-stream --no-cpu-baseline --no-extras > $R/gpurun_out/prof_ss.json 2> $R/gpurun_out/prof_ss.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -o pmc -- python $R/bench.py --steps 1 --warmup 1 --single-stream --no-cpu-baseline --no-extras --conv-table $R/gpurun_out/conv_table_pmc.txt > /dev/null 2> $R/gpurun_out/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -o pmc -- python $R/bench.py --steps 1 --warmup 1 --single-stream --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/pmc_write.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_mfma -o pmc -- python $R/bench.py --steps 1 --warmup 1 --single-stream --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/pmc_mfma.err
 cd $R
-python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 5 > gpurun_out/pmc_traffic_f16x3.json 2> gpurun_out/pmc_traffic.err
-python tools/pmc_mfma.py gpurun_out/pmc_mfma > gpurun_out/pmc_mfma_f16x3.json 2> gpurun_out/pmc_mfma_tool.err
-python tools/pmc_per_layer.py gpurun_out/conv_table_pmc.txt.ordered.json gpurun_out/pmc_fetch gpurun_out/pmc_write > gpurun_out/traffic_per_layer_f16x3.txt 2>> gpurun_out/pmc_traffic.err
-find gpurun_out/prof_ss -name "*kernel_stats.csv" | head -2; du -sh gpurun_out
+python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 5 > gpurun_out/${T}_pmc_traffic_f16x3.json 2> gpurun_out/pmc_traffic.err
+python tools/pmc_mfma.py gpurun_out/pmc_mfma > gpurun_out/${T}_pmc_mfma_busy_f16x3.json 2> gpurun_out/pmc_mfma_tool.err
+python tools/pmc_per_layer.py gpurun_out/conv_table_pmc.txt.ordered.json gpurun_out/pmc_fetch gpurun_out/pmc_write > gpurun_out/${T}_traffic_per_layer_f16x3.txt 2>> gpurun_out/pmc_traffic.err
+cp $(find gpurun_out/prof_ss -name "*kernel_stats.csv" | head -1) gpurun_out/${T}_fusetrack_kernel_stats_single_stream_f16x3.csv
 # keep the merged-back payload small: drop the raw per-dispatch traces
 find gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma gpurun_out/prof_ss -name "*kernel_trace.csv" -delete
 find gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma -name "*counter_collection.csv" -size +20M -delete
