@@ -866,7 +866,11 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
 // TAPMAJOR: k = tap * cin_pad + ci (small channel counts: the first layers) - the (tap, channel) of a staged group differs per
 // thread. Otherwise one k-step = one (32-channel chunk, tap), the same for all threads (chunk-major order; a 1x1 layer is its
 // one-tap case), and the step's part of the byte offset is scalar.
-template <int TM, int TN, int WAVES_M, int WAVES_N, int MODE, bool TAPMAJOR>
+// DEFORM (round 3): the deformable layers on the same pipeline. The four bilinear corners of a staged (row, tap) group are four
+// buffer loads issued one k-step ahead; they are blended with the corner weights of the per-block coefficient table when the row is
+// staged (between the MFMAs, like every other work item). Versus conv_mfma_bf16s_kernel (load | MFMAs | barrier | blend + stage |
+// barrier, weights through LDS): one barrier per k-step, staging interleaved with the matrix work, weights straight to registers.
+template <int TM, int TN, int WAVES_M, int WAVES_N, int MODE, bool TAPMAJOR, bool DEFORM = false>
 __global__ __launch_bounds__(256, 2)
 void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_m, const int tiles_n,
                             const int ksteps_per_split) {
@@ -881,6 +885,11 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
     constexpr int ABUF = NSA * BM * LDS_LDH;     // 16-bit elements of one activation buffer (all planes)
 
     __shared__ __attribute__((aligned(16))) elem_t As[2 * ABUF];
+    // DEFORM: corner weights (4 floats) and clamped corner coordinates (4 x u16) of every (tile row, tap), computed once per block
+    constexpr int DTAP = 9;
+    __shared__ __attribute__((aligned(16))) float cw[DEFORM ? BM * DTAP * 4 : 4];
+    __shared__ __attribute__((aligned(8))) unsigned short cc[DEFORM ? BM * DTAP * 4 : 4];
+    static_assert(!(DEFORM && TAPMAJOR), "deformable layers use the chunk-major order");
 
     const int t = threadIdx.x;
     int swz = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -949,19 +958,22 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
 
     // activation tiles in flight in registers: tile T waits in slot T & 1 from the step T-3 that requested it until step T-1
     // stages it (two full k-steps: a 3-product k-step is 24 MFMAs = 0.4 us, shorter than a trip to HBM)
-    f32x4 areg[2][4];
+    f32x4 areg[DEFORM ? 1 : 2][4];
+    f32x4 dcv[DEFORM ? 4 : 1][4];          // DEFORM: the four corner values of the staged rows of the tile in flight (ONE tile ahead)
+    float dcw[DEFORM ? 4 : 1][4];
     x8 bnext[2][NSB][TN];
     float amax = 0.f;
 
     // next activation tile -> registers of `slot` (sequential: every call advances the k state by one step)
     auto load_A = [&](const int slot) {
-        int kyc, kxc;
+        int kyc, kxc, chunk_of_step = 0;
         unsigned stepoff;      // byte offset = rowoff[i] (k-invariant, per thread) + the step's (tap, channel) part
         bool kv;
         if constexpr (!TAPMAJOR) {
             // scalar state: the step's offset is an SGPR, one vector add per staged row
             kyc = ky; kxc = kx;
             kv = chunk * BK + k4 * 4 < cin_pad;
+            chunk_of_step = chunk;
             stepoff = (unsigned)(kyc * W + kxc) * ld4 + (unsigned)chunk * (BK * 4u);
             if (++kx == KW) {
                 kx = 0;
@@ -977,12 +989,33 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
             stepoff = (unsigned)(kyc * W + kxc) * ld4 + (unsigned)(cic - k4 * 4) * 4u;
         }
         ++astep;
+        if constexpr (DEFORM) {
+            // table entry of (row, tap): four corner loads at clamped coordinates; the weights are zero where the reference zeroes the
+            // corner or skips the sample; beyond the channel range the offset lies outside the buffer (zeros)
+            const int tap = min(kyc * KW + kxc, DTAP - 1);
+            const unsigned choff = acoff + (unsigned)chunk_of_step * (BK * 4u);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            // out-of-image / out-of-range taps: offset beyond the buffer -> the load returns zeros (no branch, no select on the data)
-            const int iy = ri[i].iy0 + kyc, ix = ri[i].ix0 + kxc;
-            const bool ok = kv && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            areg[slot][i] = buffer_load16<f32x4>(arsrc, ok ? rowoff[i] + stepoff : 0xFFFFFFF0u, 0u);
+            for (int i = 0; i < 4; ++i) {
+                const int e = ((r0 + 32 * i) * DTAP + tap) * 4;
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(&cw[e]);
+                const vec4<unsigned short> c4 = *reinterpret_cast<const vec4<unsigned short>*>(&cc[e]);
+                dcw[i][0] = w4[0]; dcw[i][1] = w4[1]; dcw[i][2] = w4[2]; dcw[i][3] = w4[3];
+                const unsigned pb = (unsigned)ri[i].pixbase;
+                const unsigned o00 = (pb + (unsigned)c4[0] * W + c4[2]) * ld4 + choff, o01 = (pb + (unsigned)c4[0] * W + c4[3]) * ld4 + choff;
+                const unsigned o10 = (pb + (unsigned)c4[1] * W + c4[2]) * ld4 + choff, o11 = (pb + (unsigned)c4[1] * W + c4[3]) * ld4 + choff;
+                dcv[i][0] = buffer_load16<f32x4>(arsrc, kv ? o00 : 0xFFFFFFF0u, 0u);
+                dcv[i][1] = buffer_load16<f32x4>(arsrc, kv ? o01 : 0xFFFFFFF0u, 0u);
+                dcv[i][2] = buffer_load16<f32x4>(arsrc, kv ? o10 : 0xFFFFFFF0u, 0u);
+                dcv[i][3] = buffer_load16<f32x4>(arsrc, kv ? o11 : 0xFFFFFFF0u, 0u);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // out-of-image / out-of-range taps: offset beyond the buffer -> the load returns zeros (no branch, no select on the data)
+                const int iy = ri[i].iy0 + kyc, ix = ri[i].ix0 + kxc;
+                const bool ok = kv && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                areg[slot][i] = buffer_load16<f32x4>(arsrc, ok ? rowoff[i] + stepoff : 0xFFFFFFF0u, 0u);
+            }
         }
     };
 
@@ -996,7 +1029,8 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
     // split staged row i of `slot` and write it into activation buffer `buf`
     auto store_A = [&](int i, int buf, const int slot) {
         x4 sp[NSA];
-        split_act<MODE>(areg[slot][i], sp, amax);
+        if constexpr (DEFORM) split_act<MODE>(dcw[i][0] * dcv[i][0] + dcw[i][1] * dcv[i][1] + dcw[i][2] * dcv[i][2] + dcw[i][3] * dcv[i][3], sp, amax);
+        else split_act<MODE>(areg[slot][i], sp, amax);
         const int row = r0 + 32 * i;
 #pragma unroll
         for (int p = 0; p < NSA; ++p)
@@ -1025,6 +1059,36 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     // prologue: tile 0 staged in buffer 0, tiles 1 and 2 in flight in registers (slots 1, 0), weights of step 0 in flight
+    if constexpr (DEFORM) {
+        // deform_conv_cuda_kernel.cu:83-113,205-237: sample position = tap position + (dh, dw) of this output pixel; valid iff
+        // -1 < h < H and -1 < w < W; a corner outside the image contributes 0
+        for (int e = t; e < BM * DTAP; e += 256) {
+            const int row = e / DTAP, tap = e - row * DTAP;
+            const int m = tile_m * BM + row;
+            const bool act = m < M && tap < ntap;
+            const int mm = act ? m : 0;
+            const int qx = mm % d.Qw, tq = mm / d.Qw, qy = tq % d.Qh;
+            const int tky = tap / KW, tkx = tap - tky * KW;
+            const float* op = d.offset + (size_t)mm * d.off_ld + 2 * min(tap, ntap - 1);
+            const float h_im = (float)(qy * d.stride - pad_y + tky) + op[0];
+            const float w_im = (float)(qx * d.stride - pad_x + tkx) + op[1];
+            const bool inside = act && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int h_low = inside ? (int)hf : 0, w_low = inside ? (int)wf : 0;
+            const int h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = h_im - hf, lw = w_im - wf;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const bool hl = inside && h_low >= 0, hhv = inside && h_high <= H - 1;
+            const bool wl = w_low >= 0, whv = w_high <= W - 1;
+            const f32x4 w4 = {(hl && wl) ? hh * hw : 0.f, (hl && whv) ? hh * lw : 0.f, (hhv && wl) ? lh * hw : 0.f, (hhv && whv) ? lh * lw : 0.f};
+            *reinterpret_cast<f32x4*>(&cw[e * 4]) = w4;
+            vec4<unsigned short> c4;
+            c4[0] = (unsigned short)min(max(h_low, 0), H - 1); c4[1] = (unsigned short)min(max(h_high, 0), H - 1);
+            c4[2] = (unsigned short)min(max(w_low, 0), W - 1); c4[3] = (unsigned short)min(max(w_high, 0), W - 1);
+            *reinterpret_cast<vec4<unsigned short>*>(&cc[e * 4]) = c4;
+        }
+        __syncthreads();
+    }
     if (nsteps > 0) {
         load_A(0);
 #pragma unroll
@@ -1033,8 +1097,12 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
             for (int p = 0; p < NSB; ++p) load_B(0, m, p);
 #pragma unroll
         for (int i = 0; i < 4; ++i) store_A(i, 0, 0);
-        load_A(1);
-        load_A(0);
+        if constexpr (DEFORM) {
+            load_A(0);                 // ONE tile in flight: tile 1
+        } else {
+            load_A(1);
+            load_A(0);
+        }
     }
     __syncthreads();
 
@@ -1059,10 +1127,11 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
         __builtin_amdgcn_sched_barrier(0);
 
         auto work = [&](const int w) {
-            if (w < 2) store_A(w, cur ^ 1, cur ^ 1);                       // stage tile step+1 (its loads are one step old)
+            constexpr int slot = DEFORM ? 0 : (cur ^ 1);
+            if (w < 2) store_A(w, cur ^ 1, slot);                          // stage tile step+1 (its loads are one step old)
             else if (w == 2) read_A(1, cur);                      // fragments of the second slab
-            else if (w < 5) store_A(w - 1, cur ^ 1, cur ^ 1);
-            else if (w == 5) load_A(cur ^ 1);                     // tile step+3 -> the slot the stagings above just emptied
+            else if (w < 5) store_A(w - 1, cur ^ 1, slot);
+            else if (w == 5) load_A(slot);                        // tile step+3 (DEFORM: step+2) -> the slot the stagings above just emptied
             else load_B(bstep, (w - 6) / NSB, (w - 6) % NSB);       // weights of step+1 -> registers
         };
 
@@ -1096,7 +1165,7 @@ void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_
         if (step + 1 < nsteps) kstep(step + 1, std::integral_constant<int, 1>{});
     }
     report_range<MODE>(d, amax);
-    conv_epilogue<TM, TN, BN>(d, acc, M, tile_m, tile_n, cls, split, py, px, wm, wn, lane, (cls * tiles_m + tile_m) * tiles_n + tile_n);
+    conv_epilogue<TM, TN, BN, false, 4, DEFORM>(d, acc, M, tile_m, tile_n, cls, split, py, px, wm, wn, lane, (cls * tiles_m + tile_m) * tiles_n + tile_n);
 }
 
 // ================================================================================================
@@ -2051,6 +2120,10 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
         else { if (d.KH == 3) VPS_HALO_LAUNCH(VPS_PREC_BF16X6, 3); else VPS_HALO_LAUNCH(VPS_PREC_BF16X6, 2); }
 #undef VPS_HALO_LAUNCH
     } else {
+    // deformable layers: the pipelined kernel when the k order is chunk-major (every layer of the path), the two-barrier kernel
+    // otherwise; VPS_DCN_PIPE=0 forces the latter (A/B)
+    static const bool dcn_pipe_on = !(getenv("VPS_DCN_PIPE") && getenv("VPS_DCN_PIPE")[0] == '0');
+    const bool dcn_pipe = dcn_pipe_on && d.korder == 1 && ntap == 9 && d.H <= 65535 && d.W <= 65535;
     const bool tapmajor = d.korder == 0 && ntap > 1;      // small channel counts; a 1x1 layer is the one-tap case of the chunk-major order
 #define VPS_CONV_LAUNCH(KERNEL)                                                                              \
     hipLaunchKernelGGL((KERNEL), dim3((unsigned)nblk), dim3(256), 0, s, d, M, tiles_m, tiles_n, per_split)
@@ -2058,19 +2131,23 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
         if (d.offset) VPS_CONV_LAUNCH((conv_mfma_f32_kernel<TM, TN, WAVES_M, WAVES_N, true>));
         else VPS_CONV_LAUNCH((conv_mfma_f32_kernel<TM, TN, WAVES_M, WAVES_N, false>));
     } else if (d.prec == VPS_PREC_BF16) {
-        if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16, true>));
+        if (d.offset && dcn_pipe) VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16, false, true>));
+        else if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16, true>));
         else if (tapmajor) VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16, true>));
         else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16, false>));
     } else if (d.prec == VPS_PREC_BF16X3) {
-        if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X3, true>));
+        if (d.offset && dcn_pipe) VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X3, false, true>));
+        else if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X3, true>));
         else if (tapmajor) VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X3, true>));
         else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X3, false>));
     } else if (d.prec == VPS_PREC_F16X3) {
-        if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_F16X3, true>));
+        if (d.offset && dcn_pipe) VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_F16X3, false, true>));
+        else if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_F16X3, true>));
         else if (tapmajor) VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_F16X3, true>));
         else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_F16X3, false>));
     } else {
-        if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X6, true>));
+        if (d.offset && dcn_pipe) VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X6, false, true>));
+        else if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X6, true>));
         else if (tapmajor) VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X6, true>));
         else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X6, false>));
     }
