@@ -92,8 +92,8 @@ typedef struct vps_conv_desc {
     float* ws;
     /* split modes: 16-bit weight planes, no `w`. P planes: bf16 1, bf16x3 2, bf16x6 3 (plane p = bf16 RNE of the residual after p
      * terms), f16x3 3 (g0, g1, 2^-11*g0 of the per-channel pre-scaled weight; the scale's inverse is folded into `scale`).
-     *   with `offset` (deformable):  [P][nclass][cout_pad][kpad]
-     *   otherwise, MFMA-fragment order (weights go straight to registers, one coalesced 1 KB load per fragment):
+     *   with `offset` (deformable) AND korder 0:  [P][nclass][cout_pad][kpad] (two-barrier kernel, weights through LDS)
+     *   otherwise - deformable layers in the chunk-major order included - MFMA-fragment order (weights go straight to registers, one coalesced 1 KB load per fragment):
      *                               [P][nclass][cout_pad/32][kpad/16][lane 0..63][8], lane = 32*((k/8)%2) + cout%32 */
     int32_t prec;       /* VPS_PREC_* */
     const void* w_split;

@@ -25,7 +25,7 @@ BOUND = {hip.PREC_F16X3: 3 * 2.0 ** -22, hip.PREC_BF16X6: 2.0 ** -22, hip.PREC_B
 def unpack_planes(pc):
     """w_split -> float64 [plane][class][cout_pad][tap][cin_pad] in natural order (undoes fragment order and k order)"""
     ws = pc.w_split
-    if not pc.deform:
+    if not (pc.deform and pc.korder == 0):
         P, C, OB, KB, two, thirty2, eight = ws.shape
         assert (two, thirty2, eight) == (2, 32, 8)
         ws = ws.permute(0, 1, 2, 5, 3, 4, 6).reshape(P, C, OB * 32, KB * 16)

@@ -2120,10 +2120,9 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
         else { if (d.KH == 3) VPS_HALO_LAUNCH(VPS_PREC_BF16X6, 3); else VPS_HALO_LAUNCH(VPS_PREC_BF16X6, 2); }
 #undef VPS_HALO_LAUNCH
     } else {
-    // deformable layers: the pipelined kernel when the k order is chunk-major (every layer of the path), the two-barrier kernel
-    // otherwise; VPS_DCN_PIPE=0 forces the latter (A/B)
-    static const bool dcn_pipe_on = !(getenv("VPS_DCN_PIPE") && getenv("VPS_DCN_PIPE")[0] == '0');
-    const bool dcn_pipe = dcn_pipe_on && d.korder == 1 && ntap == 9 && d.H <= 65535 && d.W <= 65535;
+    // deformable layers: the pipelined kernel when the k order is chunk-major (every layer of the path; weights in fragment order),
+    // the two-barrier kernel for the tap-major order (row-major weights: vps_hip.h)
+    const bool dcn_pipe = d.korder == 1;
     const bool tapmajor = d.korder == 0 && ntap > 1;      // small channel counts; a 1x1 layer is the one-tap case of the chunk-major order
 #define VPS_CONV_LAUNCH(KERNEL)                                                                              \
     hipLaunchKernelGGL((KERNEL), dim3((unsigned)nblk), dim3(256), 0, s, d, M, tiles_m, tiles_n, per_split)

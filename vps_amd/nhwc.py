@@ -326,8 +326,9 @@ class PackedConv:
                 planes.append(h)
                 r = r - h.float()
         ws = torch.stack(planes, 0)                     # [planes][class][cout_pad][kpad]
-        if not self.deform:
-            # MFMA-fragment order for the direct-to-register weight path (conv_mfma_bf16d_kernel):
+        if not (self.deform and self.korder == 0):
+            # MFMA-fragment order for the direct-to-register weight path (every kernel but the two-barrier deformable one, which
+            # only takes the tap-major deformable layers - none on the path):
             # [plane][class][cout_pad/32][kpad/16][lane = 32*(k/8 % 2) + cout % 32][8 consecutive k]
             P, C, O, K = ws.shape
             ws = ws.view(P, C, O // 32, 32, K // 16, 2, 8).permute(0, 1, 2, 4, 5, 3, 6)
