@@ -4,6 +4,14 @@ mkdir -p gpurun_out; R=$PWD; T=${TAG:-r03}
 if [ -z "$SKIP_PYTEST" ]; then python -m pytest tests -m gpu -q --tb=short -rf -p no:cacheprovider > gpurun_out/${T}_pytest_gpu.log 2>&1; tail -6 gpurun_out/${T}_pytest_gpu.log; fi
 python bench.py --steps 20 --warmup 5 --conv-table gpurun_out/${T}_conv_table_f16x3.txt > gpurun_out/${T}_bench_default_f16x3.json 2> gpurun_out/${T}_bench.err; head -c 200 gpurun_out/${T}_bench_default_f16x3.json; echo
 python bench.py --model-config configs/viper/fusetrack_r101.py --height 1088 --width 1920 --prec f16x3 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/${T}_bench_config5_r101_1088x1920_f16x3.json 2>> gpurun_out/${T}_bench.err; head -c 200 gpurun_out/${T}_bench_config5_r101_1088x1920_f16x3.json; echo
+# the 2-rank clip pipeline, functionally: two processes on the ONE GPU of this box over gloo (NOT RCCL, no scaling number): the
+# streamed records / maps / hand-off with the real DetectorBackend; its clip30 id_checksum must equal the 1-rank run's
+VPS_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/${T}_bench_2rank_gloo_one_gpu.json 2>> gpurun_out/${T}_bench.err
+python - <<PY
+import json
+a=json.loads(open('gpurun_out/${T}_bench_default_f16x3.json').read().strip().splitlines()[-1]); b=json.loads(open('gpurun_out/${T}_bench_2rank_gloo_one_gpu.json').read().strip().splitlines()[-1])
+print('clip30 id_checksum 1 rank', a['clip30']['id_checksum'], '2 ranks', b['clip30']['id_checksum'], 'EQUAL' if a['clip30']['id_checksum']==b['clip30']['id_checksum'] else 'DIFFERENT')
+PY
 # VPQ of the benchmarked arithmetic against the exact-fp32 kernels, whole drop-in chain (tools/test_vpq.py + eval_vpq.py mirror), 1024x2048:
 # on the near-tied synthetic heads and on the well-separated fixture head
 python tools/run_vps_synthetic.py --height 1024 --width 2048 --videos 2 --frames 30 --prec f16x3 --gt-prec f32 --out gpurun_out/vps_near_tied > gpurun_out/${T}_vpq_f16x3_vs_f32_1024x2048_near_tied.json 2>> gpurun_out/${T}_bench.err
