@@ -86,7 +86,7 @@ class ClipShardRunner:
         for key, dt in zip(self.VEC_KEYS, (torch.int64, torch.float32, torch.int64)):
             rec[key] = buf[o:o + k].to(dt); o += cap
         for key, w, dt in lay:
-            v = buf[o:o + K * w].to(dt)
+            v = buf[o:o + K * w].to(dt, copy=True)        # own allocation: the kernels need 16-byte aligned operands
             rec[key] = v.reshape(K, w) if (w > 1 or key == 'det_bboxes') else v.reshape(K); o += cap * w
         rec['fcn_outputs'], rec['panoptic_outputs'] = maps[1][None], maps[0][None]
         return rec
