@@ -269,6 +269,44 @@ def test_clip_shard_backend_and_handoff_feature(setup):
     assert np.array_equal(out[2]['panoptic_det_obj_ids'].cpu().numpy(), seq[1]['panoptic_det_obj_ids'])
 
 
+def test_streamed_records_of_another_rank_replay_to_the_sequential_ids(setup):
+    """what rank r > 0 does in vps_amd/clip_shard.py, in one process: every frame is computed with deferred tracking, its detection
+    record + maps are packed into the fixed-layout tensors that travel to rank 0, unpacked there and assigned in clip order
+    (`track_assign`) — ids, maps and per-instance vectors must equal the inline sequential run"""
+    from vps_amd.clip_shard import ClipShardRunner, DetectorBackend
+    m, fr, dev = setup['model'], setup['frames'], setup['dev']
+    H, W, n = setup['H'], setup['W'], setup['n']
+    m._cache = None; m._pf = None; m.reset_tracker()
+    seq = []
+    for t in range(n):
+        out = m(return_loss=False, rescale=True, img=[fr[t].to(dev)], img_meta=[[synth.img_meta(H, W, 10000 + t + 1)]],
+                ref_img=[fr[t - 1 if t else 0].to(dev)])
+        seq.append({k: v.cpu().numpy().copy() for k, v in out[2].items()})
+    be = DetectorBackend(m, H, W, prefetch=False)
+    be.inline_ids = False                                  # a rank that does not own the head of the clip
+    runner = ClipShardRunner(be, 0, 1, None, dev)
+    cap, lay, nrec = runner._layout()
+    m._cache = None; m._pf = None; m.reset_tracker()
+    frd = [f.to(dev) for f in fr]
+    wire = []
+    for t in range(n):
+        rec = be.process(frd[t], frd[t - 1 if t else 0], None, 10000 + t + 1, t == 0)
+        buf = runner._pack(rec, torch.zeros(nrec, dtype=torch.float32, device=dev))
+        maps = torch.stack([rec['panoptic_outputs'][0], rec['fcn_outputs'][0]]).to(torch.uint8).contiguous()
+        wire.append((buf.clone(), maps.clone()))
+    m.reset_tracker()                                      # "rank 0": only the tracker state matters from here on
+    for t, (buf, maps) in enumerate(wire):
+        rec = runner._unpack(buf, maps, t)
+        out = be.finalize(rec, be.assign(rec, t == 0))
+        assert np.array_equal(np.asarray(out['panoptic_det_obj_ids']), seq[t]['panoptic_det_obj_ids']), t
+        assert np.array_equal(out['panoptic_cls_inds'].cpu().numpy(), seq[t]['panoptic_cls_inds']), t
+        assert np.array_equal(out['panoptic_det_labels'].cpu().numpy(), seq[t]['panoptic_det_labels']), t
+        assert np.array_equal(out['panoptic_cls_prob'].cpu().numpy(), seq[t]['panoptic_cls_prob']), t
+        assert np.array_equal(out['panoptic_outputs'].cpu().numpy(), seq[t]['panoptic_outputs']), t
+        assert np.array_equal(out['fcn_outputs'].cpu().numpy(), seq[t]['fcn_outputs']), t
+    m._cache = None; m.reset_tracker()
+
+
 @pytest.mark.parametrize('prec_name', ['bf16x3'])
 def test_split_bf16_arithmetic_end_to_end(setup, runs, prec_name):
     """the split-bf16 matrix-core modes on the whole path: bf16x6 (fp32-grade) must reproduce ids/classes exactly; bf16x3
