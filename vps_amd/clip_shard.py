@@ -91,6 +91,16 @@ class ClipShardRunner:
         rec['fcn_outputs'], rec['panoptic_outputs'] = maps[1][None], maps[0][None]
         return rec
 
+    def _post(self, ops):
+        """batch_isend_irecv. RCCL sends are ordered behind the current stream by the backend. The gloo backend (functional runs of
+        the multi-rank path on one box, CPU tests) hands the raw pointer of a device tensor to the transport, whose host thread reads
+        it whenever it gets to it - NOT stream-ordered (measured: the 134 MB hand-off arrived partly stale at 1024x2048 while the
+        128x256 run was bitwise right): the producing stream is drained before a send is posted."""
+        dist = self.dist
+        if dist.get_backend() == 'gloo' and any(op.op is dist.isend and op.tensor.is_cuda for op in ops):
+            torch.cuda.current_stream(ops[0].tensor.device).synchronize()
+        return dist.batch_isend_irecv(ops)
+
     def run(self, load_frame, nframes, video_id=1):
         """load_frame(t) -> normalised frame tensor [1,3,H,W] on this rank's device (data loading is not the sharded path).
         Returns on rank 0 the list of per-frame outputs for the WHOLE clip (frame order), elsewhere []."""
@@ -123,7 +133,7 @@ class ClipShardRunner:
             if rank > 0:
                 recv_buf = be.ref_feature_buffer(load_frame(s))
                 ops.append(dist.P2POp(dist.irecv, recv_buf, rank - 1))
-            reqs = dist.batch_isend_irecv(ops) if ops else []
+            reqs = self._post(ops) if ops else []
         # 2) rank 0 posts the receives of every other rank's records + maps, in clip order (per peer the order of its sends)
         inbox = {}
         if world > 1 and rank == 0:
@@ -134,7 +144,7 @@ class ClipShardRunner:
                 for t in range(*parts[r]):
                     buf = torch.zeros(n, dtype=torch.float32, device=dev)
                     maps = torch.empty(2, Hm, Wm, dtype=torch.uint8, device=dev)
-                    inbox[t] = (buf, maps, dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, r), dist.P2POp(dist.irecv, maps, r)]))
+                    inbox[t] = (buf, maps, self._post([dist.P2POp(dist.irecv, buf, r), dist.P2POp(dist.irecv, maps, r)]))
         # 3) this rank's frames
         outs, sent = [], []
         prev = None
@@ -161,7 +171,7 @@ class ClipShardRunner:
                 cap, lay, n = self._layout()
                 buf = self._pack(rec, torch.zeros(n, dtype=torch.float32, device=rec[self.track_keys[0]].device))
                 maps = torch.stack([torch.as_tensor(rec['panoptic_outputs'])[0], torch.as_tensor(rec['fcn_outputs'])[0]]).to(torch.uint8).contiguous()
-                sent.append((buf, maps, dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, 0), dist.P2POp(dist.isend, maps, 0)])))
+                sent.append((buf, maps, self._post([dist.P2POp(dist.isend, buf, 0), dist.P2POp(dist.isend, maps, 0)])))
             prev = img
             memo.pop(t - 1, None)            # frame t-1 is no longer needed (frame t stays: it is frame t+1's reference)
         for rq in reqs:
