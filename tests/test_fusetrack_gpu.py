@@ -252,8 +252,8 @@ def test_clip_shard_backend_and_handoff_feature(setup):
         m._cache = None; m._pf = None; m.reset_tracker()
         outs = ClipShardRunner(DetectorBackend(m, H, W, prefetch=prefetch), 0, 1, None, dev).run(lambda t: frd[t], n)
         for t in range(n):
-            # the pipelined schedule (next frame's FlowNet2 / ResNet / FPN enqueued behind this frame's semantic head) is bitwise
-            # the sequential one
+            # the pipelined schedule (next frame's FlowNet2 / ResNet / FPN on the prefetch stream beside this frame's neck and
+            # heads, in a ring of three workspaces) is bitwise the sequential one
             assert np.array_equal(np.asarray(outs[t]['panoptic_det_obj_ids']), seq[t]['panoptic_det_obj_ids']), (prefetch, t)
             assert np.array_equal(outs[t]['panoptic_outputs'].cpu().numpy(), seq[t]['panoptic_outputs']), (prefetch, t)
             assert np.array_equal(outs[t]['fcn_outputs'].cpu().numpy(), seq[t]['fcn_outputs']), (prefetch, t)

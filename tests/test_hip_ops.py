@@ -362,6 +362,32 @@ def test_bfp_gather_scatter(dev):
         _cmp(o.to_nchw(), r, rtol=1e-6, atol=1e-6, what='scatter %d' % i)
 
 
+@pytest.mark.parametrize('C,H,W,coff', [(256, 16, 24, 0), (256, 9, 7, 64), (64, 5, 33, 4)])
+def test_tcea_temporal_and_modulate(dev, C, H, W, coff):
+    """utils/tcea_modules.py:56-66 (per-frame correlation with the centre embedding -> sigmoid -> scale the frame) and :76-77
+    (fea * sigmoid(att) * 2 + att_add) as the two kernels of necks._TCEAFusion, kernel level. The frames come in as channel
+    windows of wider buffers, as the neck passes them (bsf is a window of the LiteFlowNet input buffer)."""
+    emb = _rand(1, 2 * C, H, W, seed=1, scale=0.2)
+    emb_ref = _rand(1, C, H, W, seed=2, scale=0.2)
+    f0, f1 = _rand(1, C, H, W, seed=3), _rand(1, C, H, W, seed=4)
+    cor = [torch.sigmoid((emb[:, i * C:(i + 1) * C] * emb_ref).sum(1, keepdim=True)) for i in range(2)]
+    ref = torch.cat([f0 * cor[0], f1 * cor[1]], 1)
+    ws = nhwc.Workspace(dev)
+    wide = ws.fmap('wide', 1, H, W, C + coff + 12)
+    wide.window(coff, C).t[..., coff:coff + C] = nhwc.from_nchw(f0.to(dev)).t
+    out = nhwc.tcea_temporal(nhwc.from_nchw(emb.to(dev)), nhwc.from_nchw(emb_ref.to(dev)), wide.window(coff, C),
+                             nhwc.from_nchw(f1.to(dev)), ws.fmap('al', 1, H, W, 2 * C))
+    _cmp(out.to_nchw(), ref, rtol=1e-5, atol=1e-6, what='tcea temporal')
+    # the sigmoid saturates cleanly (|logit| up to ~C * 25): no NaN, exact 0 / 1 limits like torch
+    big = nhwc.tcea_temporal(nhwc.from_nchw((emb * 50).to(dev)), nhwc.from_nchw((emb_ref * 50).to(dev)), wide.window(coff, C),
+                             nhwc.from_nchw(f1.to(dev)), ws.fmap('al2', 1, H, W, 2 * C))
+    cor = [torch.sigmoid((emb[:, i * C:(i + 1) * C] * 50 * (emb_ref * 50)).sum(1, keepdim=True)) for i in range(2)]
+    _cmp(big.to_nchw(), torch.cat([f0 * cor[0], f1 * cor[1]], 1), rtol=2e-3, atol=1e-6, what='tcea temporal saturated')   # a logit of magnitude ~1e3 carries ~1e-4 of summation-order noise
+    fea, att, add = _rand(1, C, H, W, seed=5), _rand(1, C, H, W, seed=6, scale=3.0), _rand(1, C, H, W, seed=7)
+    o = nhwc.tcea_modulate(nhwc.from_nchw(fea.to(dev)), nhwc.from_nchw(att.to(dev)), nhwc.from_nchw(add.to(dev)), ws.fmap('mod', 1, H, W, C))
+    _cmp(o.to_nchw(), fea * torch.sigmoid(att) * 2 + add, rtol=1e-6, atol=1e-6, what='tcea modulate')
+
+
 @pytest.mark.parametrize('C', [256, 128])
 def test_groupnorm_relu(dev, C):
     x = _rand(1, C, 20, 28, seed=1, scale=2.0) + 0.5

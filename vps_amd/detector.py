@@ -109,8 +109,11 @@ class PanopticFuseTrack(HipModule):
         self.verify_ref_frame = True       # check that ref_img IS the previous call's img before reusing its features
         self.int64_outputs = False         # True: panoptic/semantic maps as int64 like the reference (uint8 values otherwise)
         self.profile = None                # set to {} to collect per-stage hip events (stages then run on one stream)
-        self.overlap_streams = True        # independent branches of the frame on two HIP streams (see simple_test)
+        self.overlap_streams = True        # independent branches of the frame on two HIP streams, + a prefetch stream (see simple_test)
         self._side = None
+        self._pre = None                   # prefetch stream + its ring of workspaces (clip pipelines)
+        self._ring = None
+        self._slot = 0
         self._ws = None
         self._flip = 0
         self._cache = None
@@ -224,10 +227,10 @@ class PanopticFuseTrack(HipModule):
         ref_feature / defer_tracking (clip_shard.py): gathered pre-neck feature of the previous frame received from the
         neighbouring GPU, and postponing the sequential id assignment to the clip-level replay.
         prefetch (clip pipelines): (next_img, next_ref_img), the device tensors the NEXT call will be made with. Their
-        FlowNet2 + ResNet/FPN/gather — which depend on the images alone — are enqueued on the side stream behind this frame's
-        semantic head, so the GPU has ~20 ms of independent work while the host walks through this frame's detection branch
-        (MaskROI / tracker / MaskRemoval round trips). The next call picks the results up (matched by tensor identity);
-        outputs are bitwise those of the unpipelined schedule."""
+        FlowNet2 + ResNet/FPN/gather — which depend on the images alone — are enqueued on a third (prefetch) stream, into a ring
+        of private workspaces, BEFORE this frame's neck: they run beside this frame's neck, semantic head and detection heads
+        and keep the GPU fed while the host waits for this frame's two small reads. The next call picks the results up (matched
+        by tensor identity); outputs are bitwise those of the unpipelined schedule."""
         assert proposals is None
         if not img.is_cuda:
             raise hip.VpsHipError('PanopticFuseTrack runs on the device only (no CPU path)')
@@ -271,17 +274,39 @@ class PanopticFuseTrack(HipModule):
             self._mark('backbone_fpn')
         else:
             pf, self._pf = self._pf, None
+            if side is not None and prefetch is not None:
+                # The NEXT frame's image-only stages (FlowNet2, ResNet + FPN + gather) go to a third stream before anything of THIS
+                # frame is enqueued, so they run beside this frame's neck and heads, not behind its semantic head: the prefetch
+                # stream is then busy back to back (it is the longest chain, ~16 ms of the frame's ~23 ms of kernel time) and the
+                # main / side streams fill the CUs its low-resolution layers leave idle. Its buffers come from a ring of three
+                # private workspaces: slot (t+1) % 3 was last written for frame t-2, whose flow / levels were read by neck(t-2)
+                # and whose gathered feature was last read by neck(t-1) as ref_bsf — both enqueued on the main stream in earlier
+                # calls, which the wait below orders this stream behind (the main stream is drained at this point anyway: the
+                # previous call ended with its end-of-frame read). The images may have been produced on the main stream too.
+                if self._pre is None or self._pre.device != dev:
+                    self._pre = torch.cuda.Stream(device=dev)
+                    self._ring = [nhwc.Workspace(dev) for _ in range(3)]
+                self._pre.wait_stream(main)
+                self._slot = (self._slot + 1) % 3
+                rws = self._ring[self._slot]
+                nimg, nref = prefetch
+                with torch.cuda.stream(self._pre):
+                    nflow = self.flownet2.run(nimg, nref, self._mean_t, self._std_t, rws)
+                    nlevels, ncat = self._backbone_fpn_gather(nimg, rws)
+                    ev = torch.cuda.Event()
+                    ev.record(self._pre)
+                self._pf = dict(img=nimg, ref=nref, version=(nimg._version, nref._version), event=ev, flow=nflow, levels=nlevels, cat=ncat)
             if pf is not None and side is not None and pf['img'] is img and pf['ref'] is ref_img and pf['version'] == (img._version, ref_img._version):
-                # (1)+(2) were enqueued on the side stream during the previous call (prefetch)
+                # (1)+(2) were enqueued on the prefetch stream during the previous call
                 main.wait_event(pf['event'])
                 flow, levels, cat = pf['flow'], pf['levels'], pf['cat']
                 self._mark('flownet2')
             else:
                 if pf is not None:
-                    # an unused prefetch (the caller announced other tensors than it now passes): the side stream may still be
-                    # writing 'img_nhwc' / 'bb.*' / 'fpn.*' / 'fn2.*' / its 'neck.cat' buffer — the same workspace names this
-                    # frame is about to write — so the main stream orders itself behind it first, and that
-                    # 'neck.cat' buffer is the one to overwrite, not the previous frame's
+                    # an unused prefetch (the caller announced other tensors than it now passes): the prefetch stream may still be
+                    # reading those tensors, which the caller is now free to rewrite on the main stream — so the main stream orders
+                    # itself behind it. Its results sit in a ring workspace nobody reads; the A/B alternation of the
+                    # main workspace's 'neck.cat' buffer is put back in step (the prefetch's gather flipped it).
                     if main is not None:
                         main.wait_event(pf['event'])
                     else:
@@ -328,16 +353,6 @@ class PanopticFuseTrack(HipModule):
                 fcn_score = self.panopticFPN.run(x[0:self.panopticFPN.num_levels], ws)
                 sem_done = torch.cuda.Event()
                 sem_done.record(side)
-                if prefetch is not None and self.with_fusion:
-                    # the next frame's image-only stages, behind the semantic head on the side stream. Their buffers ('fn2.*',
-                    # 'img_nhwc', 'bb.*', 'fpn.*', the OTHER 'neck.cat' buffer) were last read by this frame's flow resize /
-                    # neck, which the main stream enqueued before the side stream's wait above; nothing after the neck reads them.
-                    nimg, nref = prefetch
-                    nflow = self.flownet2.run(nimg, nref, self._mean_t, self._std_t, ws)
-                    nlevels, ncat = self._backbone_fpn_gather(nimg, ws)
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    self._pf = dict(img=nimg, ref=nref, version=(nimg._version, nref._version), event=ev, flow=nflow, levels=nlevels, cat=ncat)
         else:
             fcn_score = self.panopticFPN.run(x[0:self.panopticFPN.num_levels], ws)
         if inject is not None and 'fcn_score' in inject:

@@ -130,8 +130,8 @@ class FMap:
 class Workspace:
     """Named persistent device buffers (one per activation of the frame graph), reused across frames: the allocator is never on
     the critical path and pad lanes stay zero. Reuse is safe under the detector's stream discipline, which is an INVARIANT of
-    every caller (vps_amd/detector.py): a frame runs on two streams (and, in clip mode, the next frame's image-only stages
-    behind the side stream); branches that run concurrently use DISJOINT buffer names, a stream is joined (wait_stream /
+    every caller (vps_amd/detector.py): a frame runs on two streams (in clip mode the next frame's image-only stages run on
+    a third stream, in a ring of three workspaces of their own); branches that run concurrently use DISJOINT buffer names, a stream is joined (wait_stream /
     wait_event) before the other reads what it wrote and before the next frame rewrites it, and buffers are never freed, so no
     allocation made on one stream is recycled under another. tests/test_fullsize_gpu.py compares the two-stream schedule with
     the one-stream schedule bitwise; tests/test_fusetrack_gpu.py does the same for the pipelined schedule."""
