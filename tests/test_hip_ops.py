@@ -68,6 +68,15 @@ CONV_CASES = [
     # VPS_S2_HALO=1 in the environment the experimental phase-split 8-wave halo kernel (f16x3 / bf16x3)
     (64, 128, 5, 2, 2, 512, 512, 'leaky', False, False),
     (128, 256, 3, 2, 1, 500, 516, 'relu', True, True),   # overhanging patches, two column tiles, residual + BN epilogue
+    (64, 64, 3, 2, 1, 500, 1030, 'leaky', False, False), # the 64-column variant of the phase-split kernel (FlowNetSD / Fusion conv1), overhanging patches
+    # narrow outputs at sizes where a workgroup walks several runs (grid-stride loop, folding reduction over 64 / 16 / 4 lanes)
+    (194, 2, 3, 1, 1, 64, 131, 'none', False, False),
+    (64, 2, 3, 1, 1, 40, 57, 'leaky', False, False),
+    (16, 2, 3, 1, 1, 130, 258, 'none', False, False),
+    # 5..16 output channels on >= 256 patches of 8x32: the 16x16x32 kernel in f16x3 (overhanging patches, ragged channel chunk;
+    # 10 channels: scalar stores and the channel guard; residual + BN epilogue)
+    (82, 16, 3, 1, 1, 130, 520, 'leaky', False, False),
+    (64, 10, 3, 1, 1, 136, 520, 'relu', True, True),
 ]
 
 
@@ -130,7 +139,9 @@ def test_conv_writes_into_concat_window_and_reads_padded_window(dev):
                                                 # whole 8x16 patches per parity class: halo-staged kernel
                                                 (386, 64, 4, 1, 16, 32), (162, 16, 4, 1, 8, 48), (128, 160, 4, 1, 24, 16),
                                                 # 4 parity classes x 128 tiles of 8x32: the 8-wave halo kernel on a transposed conv
-                                                (96, 128, 4, 1, 128, 256)])
+                                                (96, 128, 4, 1, 128, 256),
+                                                # 16 output channels, 4 classes x 153 patches of 8x32: the 16x16x32 kernel (f16x3)
+                                                (162, 16, 4, 1, 130, 260)])
 def test_conv_transpose_matches_torch_cpu(dev, cin, cout, k, pad, H, W, prec, tol):
     x = _rand(2 if k == 2 else 1, cin, H, W, seed=1)
     w = _rand(cin, cout, k, k, seed=2, scale=(1.0 / (cin * k)) ** 0.5)

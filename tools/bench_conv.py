@@ -31,6 +31,10 @@ SHAPES = [  # name, cin, cout, k, stride, pad, H, W, transposed, deform
     ('flownet deconv2 386->64 4x4 @128x256', 386, 64, 4, 2, 1, 128, 256, True, False),
     ('flownet predict_flow2 194->2 3x3 @256x512', 194, 2, 3, 1, 1, 256, 512, False, False),
     ('fusion deconv0 162->16 4x4 @512x1024', 162, 16, 4, 2, 1, 512, 1024, True, False),
+    ('fusion interconv0 82->16 3x3 @1024x2048', 82, 16, 3, 1, 1, 1024, 2048, False, False),
+    ('fusion conv1 64->64 3x3s2 @1024x2048', 64, 64, 3, 2, 1, 1024, 2048, False, False),
+    ('flownet predict_flow3 386->2 3x3 @128x256', 386, 2, 3, 1, 1, 128, 256, False, False),
+    ('fusion predict_flow0 16->2 3x3 @1024x2048', 16, 2, 3, 1, 1, 1024, 2048, False, False),
     ('upsnet dcn 256->256 3x3 @256x512', 256, 256, 3, 1, 1, 256, 512, False, True),
     ('upsnet dcn 128->128 3x3 @256x512', 128, 128, 3, 1, 1, 256, 512, False, True),
     ('bbox fc 12544->1024 M=1000', 12544, 1024, 1, 1, 0, 1, 1000, False, False),

@@ -1610,10 +1610,11 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int MODE, int K>
+template <int MODE, int K, int BN = 128>
 __global__ __launch_bounds__(512, 2)
 void conv_mfma_h8s2_kernel(const vps_conv_desc d, const int tiles_m, const int tiles_n, const int chunks_per_split) {
-    constexpr int TM = 2, TN = 2, WAVES_N = 2, BN = 128;
+    static_assert(BN == 128 || BN == 64, "two column waves of 64 or 32 columns");
+    constexpr int TM = 2, TN = BN / 64, WAVES_N = 2;
     constexpr int NTAP = K * K;
     constexpr int J0 = s2_taps_1d(K, 0);                // taps per axis of the even phase (the larger one)
     constexpr int HW = 32 + J0 - 1, HH = 8 + J0 - 1;    // sub-image patch of an 8 x 32 output patch: 10 x 34 (K = 5), 9 x 33 (K = 3)
@@ -1627,9 +1628,9 @@ void conv_mfma_h8s2_kernel(const vps_conv_desc d, const int tiles_m, const int t
     constexpr int PLANE = NLD * 64 * LDS_LDH;
     constexpr int ABUF = NSA * PLANE;
     constexpr int NFRAG = NSB * 2 * (BN / 32);
-    constexpr int BBUF = NFRAG * 512;
-    static_assert((NFRAG * 64) % 512 == 0, "whole 16-byte chunks per thread");
-    constexpr int NBL = NFRAG * 64 / 512;
+    constexpr int NBL = (NFRAG * 64 + 511) / 512;       // 16-byte weight chunks per thread
+    constexpr bool WHOLE = (NFRAG * 64) % 512 == 0;
+    constexpr int BBUF = NBL * 512 * 8;                 // whole rounds of the 512 threads (>= NFRAG * 512)
     static_assert(2 * (ABUF + BBUF) * 2 <= 160 * 1024, "LDS budget of the CU");
 
     __shared__ __attribute__((aligned(16))) elem_t As[2 * ABUF];
@@ -1696,14 +1697,18 @@ void conv_mfma_h8s2_kernel(const vps_conv_desc d, const int tiles_m, const int t
     auto load_B = [&](int wstep) {
 #pragma unroll
         for (int j = 0; j < NBL; ++j) {
-            const int f = __builtin_amdgcn_readfirstlane((t + 512 * j) >> 6), bcol = f % (BN / 32), pm = f / (BN / 32);
+            // no branch in here (it would split the interleaved MFMA stream): when the fragments are not a whole number of rounds
+            // (64 columns, 3 weight planes) the surplus waves re-load the last fragment into the padding of the buffer
+            const int fr = __builtin_amdgcn_readfirstlane((t + 512 * j) >> 6), f = WHOLE ? fr : min(fr, NFRAG - 1);
+            const int bcol = f % (BN / 32), pm = f / (BN / 32);
             breg[j] = buffer_load16<x8>(wrsrc, (unsigned)lane * 16u,
                                         wbase + (unsigned)(((size_t)(pm >> 1) * wplane + ((size_t)bcol * kst + 2 * wstep + (pm & 1)) * 512) * sizeof(elem_t)));
         }
     };
     auto store_B = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < NBL; ++j) *reinterpret_cast<x8*>(&Bs[buf * BBUF + (t + 512 * j) * 8]) = breg[j];
+        for (int j = 0; j < NBL; ++j)
+            *reinterpret_cast<x8*>(&Bs[buf * BBUF + (t + 512 * j) * 8]) = breg[j];
     };
 
     int hbase[TM];
@@ -1805,6 +1810,209 @@ void conv_mfma_h8s2_kernel(const vps_conv_desc d, const int tiles_m, const int t
 }
 
 // ================================================================================================
+// Narrow-output layers (5 <= cout <= 16: the full-resolution FlowNetFusion / FlowNetSD interconv and deconv layers) on the
+// 16x16x32 MFMA shape. A 32-column tile of the 32x32x16 shape spends half of every MFMA and of every weight fragment on zero
+// columns; here the WEIGHT fragment (16 output channels x 32 k) is the A operand and 16 consecutive pixels of a patch row
+// x one whole 32-channel chunk are the B operand, so one MFMA is one (tap, chunk) of 16 pixels with no padding, and the
+// accumulator (col = lane & 15 = pixel, rows 4 (lane >> 4) + r = 4 consecutive channels) is stored as one float4 per lane.
+// Structure of conv_mfma_h8_kernel: 8 waves, an 8 x 32 output patch per block (wave w = patch row w, two 16-pixel groups), the
+// halo tile of the patch staged once per 32-channel chunk (split into the planes of the arithmetic), but the weights of a WHOLE
+// chunk (KH*KW taps x NSB planes x 1 KB) are staged per chunk: barriers per chunk, not per tap (a tap is only 6 MFMAs of 16 cycles
+// per wave). A chunk of this kernel is short (54 MFMAs = 0.9k cycles against ~2k cycles of HBM latency) and a patch has only 3..6
+// chunks, so the latency is hidden by a SECOND BLOCK on the CU rather than by a deeper software pipeline: ONE activation and ONE
+// weight buffer in LDS (76 KB), the next chunk in flight in registers while this one is multiplied, <= 128 VGPRs (the
+// double-buffered first version kept one block per CU and ran at the memory latency: 0.43 ms for 82 -> 16 @1024x2048). The 16-byte chunk index of an LDS row is XOR-ed with (row >> 1) & 3: the 16 lanes of a
+// k-group read 16 consecutive rows, 8 of them cover the 8 distinct 16-byte slots of 128 bytes.
+// The weight fragments come from the SAME packed layout as every other kernel ([plane][32-column block][16-k step][lane][8]):
+// lane l of the 16x16x32 A fragment (channel l & 15, k-group g = l >> 4) is lane (l & 15) + 32 (g & 1) of step 2 s + (g >> 1).
+// ================================================================================================
+__device__ __forceinline__ int lds_swz16(int row) { return (row >> 1) & 3; }
+
+template <int MODE, int KH, int KW>
+__global__ __launch_bounds__(512, 4)
+void conv_mfma_n16_kernel(const vps_conv_desc d, const int tiles_m) {
+    constexpr int NTAP = KH * KW;
+    constexpr int HW = 32 + KW - 1, HH = 8 + KH - 1;   // halo tile of an 8 x 32 patch
+    constexpr int HROWS = HH * HW;
+    constexpr int NLD = (HROWS + 63) / 64;              // staged rows per thread
+    typedef Split<MODE> SM;
+    typedef typename SM::elem elem_t;
+    typedef vec8<elem_t> x8;
+    typedef vec4<elem_t> x4;
+    constexpr int NSA = SM::NSA, NSB = SM::NSB, NT = SM::NT;
+    constexpr int PLANE = NLD * 64 * LDS_LDH;
+    constexpr int ABUF = NSA * PLANE;
+    constexpr int NWF = NTAP * NSB;                     // 1 KB weight fragments of one chunk
+    constexpr int WBUF = NWF * 512;
+    constexpr int NBL = (NWF * 64 + 511) / 512;         // 16-byte weight chunks per thread and chunk
+    static_assert((ABUF + WBUF) * 2 <= 80 * 1024, "two blocks per CU");
+
+    __shared__ __attribute__((aligned(16))) elem_t As[ABUF];
+    __shared__ __attribute__((aligned(16))) elem_t Ws[WBUF];
+
+    const int t = threadIdx.x;
+    int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+    int tile_n, tile_m, cls, split;
+    decode_tile(d, swz, 1, tiles_m, tile_n, tile_m, cls, split);
+
+    const int py = cls / d.os_x, px = cls - py * d.os_x;
+    const int H = d.H, W = d.W, cin_pad = d.cin_pad;
+    const int tiles_x = (d.Qw + 31) >> 5, tiles_y = (d.Qh + 7) >> 3;
+    const int tx = tile_m % tiles_x, tq = tile_m / tiles_x;
+    const int ty = tq % tiles_y, n = tq / tiles_y;
+    const int iy_org = ty * 8 - d.pad_y[py], ix_org = tx * 32 - d.pad_x[px];
+
+    const int k4 = t & 7;
+    const int r0 = t >> 3;
+    const int nchunks = d.kpad / (BK * NTAP);
+
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // patch row
+    const int nbt = d.cout_pad >> 5, kst = d.kpad >> 4;
+    const size_t wplane = (size_t)d.nclass * nbt * kst * 512;
+    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(d.w_split, (unsigned)(wplane * NSB * sizeof(elem_t)));
+    const unsigned wbase = (unsigned)(((size_t)(cls * nbt) * kst * 512) * sizeof(elem_t));
+    // source of this lane's 16 bytes inside the two 32x16 fragments of a 32-k step
+    const unsigned wlane = (unsigned)((((lane >> 5) & 1) * 512 + ((lane & 15) + 32 * ((lane >> 4) & 1)) * 8) * sizeof(elem_t));
+    const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(d.in, (unsigned)((size_t)d.N * H * W * d.in_ld * sizeof(float)));
+    const unsigned ld4 = (unsigned)d.in_ld * 4u;
+
+    f32x4 areg[NLD];
+    x8 wreg[NBL];
+    int achunk = 0;
+    float amax = 0.f;
+
+    unsigned hoff[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int hp = r0 + 64 * i;
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const int iy = iy_org + hy, ix = ix_org + hx;
+        const bool ok = hp < HROWS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        hoff[i] = ok ? (unsigned)((n * H + iy) * W + ix) * ld4 + (unsigned)(d.in_coff + k4 * 4) * 4u : 0xFFFFFFF0u;
+    }
+    auto load_A = [&]() {
+        const bool kv = achunk * BK + k4 * 4 < cin_pad;
+        const unsigned coff = (unsigned)achunk * (BK * 4u);
+        ++achunk;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            areg[i] = buffer_load16<f32x4>(arsrc, (kv && hoff[i] != 0xFFFFFFF0u) ? hoff[i] + coff : 0xFFFFFFF0u, 0u);
+    };
+    auto store_A = [&](int i) {
+        x4 sp[NSA];
+        split_act<MODE>(areg[i], sp, amax);
+        const int row = r0 + 64 * i;
+#pragma unroll
+        for (int p = 0; p < NSA; ++p)
+            *reinterpret_cast<x4*>(&As[p * PLANE + row * LDS_LDH + (((k4 >> 1) ^ lds_swz16(row)) << 3) + ((k4 & 1) << 2)]) = sp[p];
+    };
+    // fragment f = tap * NSB + plane of the chunk: wave-uniform per j
+    auto load_W = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < NBL; ++j) {
+            const int f = __builtin_amdgcn_readfirstlane((t + 512 * j) >> 6);
+            if (f < NWF) {
+                const int tap = f / NSB, pl = f - tap * NSB;
+                wreg[j] = buffer_load16<x8>(wrsrc, wlane, wbase + (unsigned)(((size_t)pl * wplane + (size_t)(2 * (chunk * NTAP + tap)) * 512) * sizeof(elem_t)));
+            }
+        }
+    };
+    auto store_W = [&](int j) {
+        if (__builtin_amdgcn_readfirstlane((t + 512 * j) >> 6) < NWF) *reinterpret_cast<x8*>(&Ws[(t + 512 * j) * 8]) = wreg[j];
+    };
+
+    // B operand: pixel x = 16 h + (lane & 15) of patch row `wave`, k-group lane >> 4 = 16-byte chunk of the LDS row
+    const int hbase = wave * HW + (lane & 15);
+    const int kg = lane >> 4;
+    f32x4 acc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // LDS element offsets of this lane's activation fragments, per (tap, pixel group): loop-invariant (the swizzle depends on the row)
+    int aoff[NTAP][2];
+#pragma unroll
+    for (int tp = 0; tp < NTAP; ++tp)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int hrow = hbase + 16 * h + (tp / KW) * HW + (tp % KW);
+            aoff[tp][h] = hrow * LDS_LDH + ((kg ^ lds_swz16(hrow)) << 3);
+        }
+
+    load_A();
+    load_W(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        // the chunk in the registers -> LDS (the previous chunk's fragment reads are behind the barrier that ended its loop body)
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) store_A(i);
+#pragma unroll
+        for (int j = 0; j < NBL; ++j) store_W(j);
+        if (chunk + 1 < nchunks) {                               // next chunk in flight while this one is multiplied
+            load_A();
+            load_W(chunk + 1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tp = 0; tp < NTAP; ++tp) {
+            x8 wf[NSB], af[2][NSA];
+#pragma unroll
+            for (int p = 0; p < NSB; ++p) wf[p] = *reinterpret_cast<const x8*>(&Ws[(tp * NSB + p) * 512 + lane * 8]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int p = 0; p < NSA; ++p) af[h][p] = *reinterpret_cast<const x8*>(&As[aoff[tp][h] + p * PLANE]);
+#pragma unroll
+            for (int q = 0; q < NT; ++q)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if constexpr (MODE == VPS_PREC_F16X3) acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[SM::PB[q]], af[h][SM::PA[q]], acc[h], 0, 0, 0);
+                    else acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[SM::PB[q]], af[h][SM::PA[q]], acc[h], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    report_range<MODE>(d, amax);
+
+    // epilogue: lane = pixel (lane & 15) of the group, output channels 4 (lane >> 4) .. + 3
+    const int co = 4 * kg;
+    const int qy = ty * 8 + wave;
+    const bool v4 = !((d.out_ld | d.out_coff | d.cout) & 3) && !((uintptr_t)d.out & 15);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (co + e < d.cout) {
+            if (d.scale) sc[e] = d.scale[co + e];
+            if (d.shift) sh[e] = d.shift[co + e];
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int qx = tx * 32 + 16 * h + (lane & 15);
+        if (qy < d.Qh && qx < d.Qw && co < d.cout) {
+            const int oy = qy * d.os_y + py, ox = qx * d.os_x + px;
+            const size_t opix = ((size_t)n * d.Ho + oy) * d.Wo + ox;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = acc[h][e] * sc[e] + sh[e];
+            if (d.res) {
+                const int rs = d.res_shift;
+                const float* rp = d.res + (((size_t)n * (d.Ho >> rs) + (oy >> rs)) * (d.Wo >> rs) + (ox >> rs)) * d.res_ld + d.res_coff + co;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (co + e < d.cout) o[e] += rp[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = vps_act(o[e], d.act, d.slope);
+            float* op = d.out + opix * d.out_ld + d.out_coff + co;
+            if (v4) *reinterpret_cast<f32x4*>(op) = o;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (co + e < d.cout) op[e] = o[e];
+            }
+        }
+    }
+}
+
+// ================================================================================================
 // Narrow-output convolution (cout <= 4: the FlowNet predict_flow / upsampled_flow layers, 2 channels). A 32-column MFMA
 // tile would waste 94 % of the matrix pipe and still stage the whole activation tile through LDS; these layers are
 // pure activation streaming, so they run on the vector ALU in exact fp32: G lanes (G = pow2 >= cin_pad/4, <= 64) share
@@ -1877,16 +2085,21 @@ void conv_small_kernel(const vps_conv_desc d, const int M, const int G, const in
 // Narrow-output 3x3 stride-1 convolution (the predict_flow layers): same arithmetic as conv_small_kernel, organised for the
 // memory pipe. The CO x kpad weights sit in LDS (loaded once per workgroup); every G-lane group walks a horizontal run of
 // RUN output pixels whose RUN+2 input columns (float4 channel slices of 3 rows) are all requested up front, so each
-// activation is loaded 3.75 times instead of 9 and a run costs one memory latency instead of 9 per pixel (the layer is
-// pure activation streaming: latency and load count are the cost); loads are branch-free (clamped address, value zeroed
-// afterwards).
+// activation is loaded 4.5 times instead of 9 and a run costs one memory latency instead of 9 per pixel (the layer is
+// pure activation streaming: latency and load count are the cost). Round 3: 4 waves per SIMD instead of 2 (256-thread blocks,
+// 110 VGPRs: one weight read per tap and output channel shared by the RUN pixels instead of weights held in registers),
+// buffer-addressed loads (out-of-image taps / idle lanes masked by the offset: 18 selects per run instead of 72), an fmaf
+// chain straight into the accumulator (288 instead of 360 VALU per run) and a folding butterfly for the G-lane reduction of the
+// 8 accumulators (7 + log2(G/8) shuffles instead of 8 log2 G).
 template <int CO, int RUN>
-__global__ __launch_bounds__(512)
+__global__ __launch_bounds__(256, 4)
 void conv_small3x3_kernel(const vps_conv_desc d, const int G, const int logG, const int runs_per_row, const long total_runs) {
     extern __shared__ __attribute__((aligned(16))) float wlds[];   // [CO][kpad]
+    constexpr int NV = RUN * CO;                                   // accumulators per lane: 8
+    static_assert(NV == 8, "the butterfly below folds 8 values over 3 lane bits");
     const int t = threadIdx.x;
     const int kpad = d.kpad;
-    for (int i = t * 4; i < CO * kpad; i += 512 * 4) {
+    for (int i = t * 4; i < CO * kpad; i += 256 * 4) {
         const int co = i / kpad, k = i - co * kpad;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(&wlds[i]) = co < d.cout_pad ? *reinterpret_cast<const f32x4*>(d.w + (size_t)co * kpad + k) : z;
@@ -1896,10 +2109,12 @@ void conv_small3x3_kernel(const vps_conv_desc d, const int G, const int logG, co
     const int lane = t & 63;
     const int sub = lane & (G - 1);
     const int ppw = 64 >> logG;
-    const long group = ((long)blockIdx.x * 8 + (t >> 6)) * ppw + (lane >> logG);
-    const long ngroups = (long)gridDim.x * 8 * ppw;
+    const long group = ((long)blockIdx.x * 4 + (t >> 6)) * ppw + (lane >> logG);
+    const long ngroups = (long)gridDim.x * 4 * ppw;
     const int H = d.H, W = d.W, cin_pad = d.cin_pad, c4n = cin_pad >> 2;
     const int nslot = (c4n + G - 1) >> logG;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(d.in, (unsigned)((size_t)d.N * H * W * d.in_ld * sizeof(float)));
+    const unsigned ld4 = (unsigned)d.in_ld * 4u;
 
     for (long run = group; run - (lane >> logG) < total_runs; run += ngroups) {   // whole wavefronts iterate together (shuffles below)
         const bool rv = run < total_runs;
@@ -1917,76 +2132,84 @@ void conv_small3x3_kernel(const vps_conv_desc d, const int G, const int logG, co
             const int c4 = sub + (slot << logG);
             const bool cv = rv && c4 < c4n;
             const int ci = cv ? 4 * c4 : 0;
-            // weight offsets of this channel slice: tap stride in k
             const int kbase = d.korder == 0 ? ci : ((ci >> 5) * 9) * 32 + (ci & 31);
             const int kstep = d.korder == 0 ? cin_pad : 32;
-            const float* __restrict__ rowp[3];
-            bool rowok[3];
+            const unsigned coff = (unsigned)(d.in_coff + ci) * 4u;
+            // all RUN+2 columns of the 3 rows are requested before the first value is used; out-of-image taps, channel pads and
+            // idle lanes are masked by the ADDRESS (an offset beyond the buffer reads zeros): one select per load, none per value
+            f32x4 col[RUN + 2][3];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int iy = y + ky - 1;
-                rowok[ky] = cv && (unsigned)iy < (unsigned)H;
-                rowp[ky] = d.in + ((size_t)(n * H + (rowok[ky] ? iy : 0)) * W) * d.in_ld + d.in_coff + ci;
-            }
-            // all RUN+2 columns of the run are requested before the first value is touched (a select right behind each load
-            // would put an s_waitcnt vmcnt(0) behind each load: 30 serial memory latencies per run); masks are applied in
-            // place once the data is there
-            f32x4 col[RUN + 2][3];
+                const bool rok = cv && (unsigned)iy < (unsigned)H;
+                const unsigned rowoff = (unsigned)((n * H + iy) * W) * ld4 + coff;
 #pragma unroll
-            for (int j = 0; j < RUN + 2; ++j) {
-                const int x = x0 - 1 + j;
-                const size_t xo = (size_t)((unsigned)x < (unsigned)W ? x : 0) * d.in_ld;
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) col[j][ky] = *reinterpret_cast<const f32x4*>(rowp[ky] + xo);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < RUN + 2; ++j) {
-                const bool xok = (unsigned)(x0 - 1 + j) < (unsigned)W;
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    col[j][ky] = (xok && rowok[ky]) ? col[j][ky] : z;
+                for (int j = 0; j < RUN + 2; ++j) {
+                    const int x = x0 - 1 + j;
+                    const bool ok = rok && (unsigned)x < (unsigned)W;
+                    col[j][ky] = buffer_load16<f32x4>(rsrc, ok ? rowoff + (unsigned)x * ld4 : 0xFFFFFFF0u, 0u);
                 }
             }
+            // one weight read per (tap, output channel), used by the RUN pixels of the run
 #pragma unroll
-            for (int xi = 0; xi < RUN; ++xi) {
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int k = kbase + (ky * 3 + kx) * kstep;
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const f32x4 a = col[xi + kx][ky];
-                        const int k = kbase + (ky * 3 + kx) * kstep;
+                    for (int c = 0; c < CO; ++c) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(&wlds[c * kpad + k]);
 #pragma unroll
-                        for (int c = 0; c < CO; ++c) {
-                            const f32x4 wv = *reinterpret_cast<const f32x4*>(&wlds[c * kpad + k]);
-                            acc[xi][c] += a[0] * wv[0] + a[1] * wv[1] + a[2] * wv[2] + a[3] * wv[3];
+                        for (int xi = 0; xi < RUN; ++xi) {
+                            const f32x4 a = col[xi + kx][ky];
+                            acc[xi][c] = __builtin_fmaf(a[3], wv[3], __builtin_fmaf(a[2], wv[2], __builtin_fmaf(a[1], wv[1], __builtin_fmaf(a[0], wv[0], acc[xi][c]))));
                         }
                     }
-            }
+                }
         }
+        // reduction over the G lanes of the group
+        float v[NV];
 #pragma unroll
         for (int xi = 0; xi < RUN; ++xi)
 #pragma unroll
-            for (int c = 0; c < CO; ++c)
-                for (int off = G >> 1; off >= 1; off >>= 1) acc[xi][c] += __shfl_xor(acc[xi][c], off, 64);
-        if (rv && sub == 0) {
+            for (int c = 0; c < CO; ++c) v[xi * CO + c] = acc[xi][c];
+        int mine = 0;                      // index of the value this lane ends up holding (G >= 8)
+        if (G >= 8) {
+            // folding butterfly: over lane bits 0..2 every exchange halves the number of values a lane carries (8 -> 4 -> 2 -> 1:
+            // 7 shuffles instead of 24), then plain exchanges of the single value over the remaining bits
 #pragma unroll
-            for (int xi = 0; xi < RUN; ++xi) {
-                const int x = x0 + xi;
-                if (x >= W) break;
-                const size_t opix = ((size_t)n * d.Ho + y) * d.Wo + x;
-                const int rs = d.res_shift;
-                const size_t rpix = ((size_t)n * (d.Ho >> rs) + (y >> rs)) * (d.Wo >> rs) + (x >> rs);
+            for (int s = 0; s < 3; ++s) {
+                const int off = 1 << s, half = (NV >> 1) >> s;
+                const bool up = lane & off;
 #pragma unroll
-                for (int c = 0; c < CO; ++c) {
-                    if (c < d.cout) {
-                        float v = acc[xi][c] * (d.scale ? d.scale[c] : 1.f) + (d.shift ? d.shift[c] : 0.f);
-                        if (d.res) v += d.res[rpix * d.res_ld + d.res_coff + c];
-                        d.out[opix * d.out_ld + d.out_coff + c] = vps_act(v, d.act, d.slope);
-                    }
+                for (int i = 0; i < half; ++i) {
+                    const float send = up ? v[i] : v[i + half];
+                    const float keep = up ? v[i + half] : v[i];
+                    v[i] = keep + __shfl_xor(send, off, 64);
                 }
+                mine += up ? half : 0;
             }
+            for (int off = 8; off < G; off <<= 1) v[0] += __shfl_xor(v[0], off, 64);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                for (int off = G >> 1; off >= 1; off >>= 1) v[i] += __shfl_xor(v[i], off, 64);
+        }
+        const int rs = d.res_shift;
+        auto put = [&](const int xi, const int c, const float a) {
+            const int x = x0 + xi;
+            if (x < W && c < d.cout) {
+                const size_t opix = ((size_t)n * d.Ho + y) * d.Wo + x;
+                float o = a * (d.scale ? d.scale[c] : 1.f) + (d.shift ? d.shift[c] : 0.f);
+                if (d.res) o += d.res[(((size_t)n * (d.Ho >> rs) + (y >> rs)) * (d.Wo >> rs) + (x >> rs)) * d.res_ld + d.res_coff + c];
+                d.out[opix * d.out_ld + d.out_coff + c] = vps_act(o, d.act, d.slope);
+            }
+        };
+        if (G >= 8) {
+            if (rv && sub < 8) put(mine / CO, mine % CO, v[0]);
+        } else if (rv && sub == 0) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) put(i / CO, i % CO, v[i]);
         }
     }
 }
@@ -2085,15 +2308,23 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
                     tiles2d8 * 256 * 2 <= (long)M * 3 && tiles2d8 * tiles_n * d.nclass * d.ksplit >= 256;
     // stride-2 3x3 / 5x5 layers on the phase-split 8-wave halo kernel (VPS_S2_HALO=0 in the environment switches it off: A/B runs)
     static const bool s2_enabled = !(getenv("VPS_S2_HALO") && getenv("VPS_S2_HALO")[0] == '0');
-    const bool h8s2 = s2_enabled && BN == 128 && (d.prec == VPS_PREC_F16X3 || d.prec == VPS_PREC_BF16X3 || d.prec == VPS_PREC_BF16) && !d.offset &&
+    const bool h8s2 = s2_enabled && (BN == 128 || BN == 64) && (d.prec == VPS_PREC_F16X3 || d.prec == VPS_PREC_BF16X3 || d.prec == VPS_PREC_BF16) && !d.offset &&
                       d.stride == 2 && d.nclass == 1 && d.korder == 1 && d.KH == d.KW && (d.KH == 3 || d.KH == 5) &&
                       d.pad_y[0] == d.KH / 2 && d.pad_x[0] == d.KW / 2 && tiles2d8 * 256 * 2 <= (long)M * 3 &&
                       tiles2d8 * tiles_n * d.ksplit >= 256 && (d.ksplit == 1 || (ksteps % d.ksplit == 0 && per_split % ntap == 0));
-    if (h8s2) {
+    // 5..16 output channels, stride-1 3x3 / 2x2-class layers with enough 8 x 32 patches: the 16x16x32 kernel (VPS_N16=0 switches it off)
+    static const bool n16_enabled = !(getenv("VPS_N16") && getenv("VPS_N16")[0] == '0');
+    const bool n16 = n16_enabled && BN == 32 && d.prec == VPS_PREC_F16X3 && halo && d.cout > 4 && d.cout <= 16 && d.cout_pad == 32 && d.ksplit == 1 &&
+                     !d.gn_stats && tiles2d8 * 256 * 2 <= (long)M * 3 && tiles2d8 * d.nclass >= 256;
+    if (n16) {
+        const long nblk8 = tiles2d8 * d.nclass;
+        if (d.KH == 3) hipLaunchKernelGGL((conv_mfma_n16_kernel<VPS_PREC_F16X3, 3, 3>), dim3((unsigned)nblk8), dim3(512), 0, s, d, (int)tiles2d8);
+        else hipLaunchKernelGGL((conv_mfma_n16_kernel<VPS_PREC_F16X3, 2, 2>), dim3((unsigned)nblk8), dim3(512), 0, s, d, (int)tiles2d8);
+    } else if (h8s2) {
         const int tiles_m8 = (int)tiles2d8;
         const long nblk8 = (long)tiles_m8 * tiles_n * d.ksplit;
 #define VPS_H8S2_LAUNCH(MODE, K)                                                                                                 \
-    hipLaunchKernelGGL((conv_mfma_h8s2_kernel<MODE, K>), dim3((unsigned)nblk8), dim3(512), 0, s, d, tiles_m8, tiles_n, per_split / ntap)
+    hipLaunchKernelGGL((conv_mfma_h8s2_kernel<MODE, K, (BN == 64 ? 64 : 128)>), dim3((unsigned)nblk8), dim3(512), 0, s, d, tiles_m8, tiles_n, per_split / ntap)
         if (d.prec == VPS_PREC_BF16) { if (d.KH == 3) VPS_H8S2_LAUNCH(VPS_PREC_BF16, 3); else VPS_H8S2_LAUNCH(VPS_PREC_BF16, 5); }
         else if (d.prec == VPS_PREC_BF16X3) { if (d.KH == 3) VPS_H8S2_LAUNCH(VPS_PREC_BF16X3, 3); else VPS_H8S2_LAUNCH(VPS_PREC_BF16X3, 5); }
         else { if (d.KH == 3) VPS_H8S2_LAUNCH(VPS_PREC_F16X3, 3); else VPS_H8S2_LAUNCH(VPS_PREC_F16X3, 5); }
@@ -2197,22 +2428,22 @@ extern "C" int vps_conv2d(const vps_conv_desc* dp, void* stream) {
         while (G < 64 && G < (d.cin_pad >> 2)) { G <<= 1; ++logG; }
         const size_t wbytes = (size_t)(d.cout <= 2 ? 2 : 4) * d.kpad * sizeof(float);
         if (d.KH == 3 && d.KW == 3 && d.stride == 1 && d.nclass == 1 && d.pad_y[0] == 1 && d.pad_x[0] == 1 && d.Ho == d.H && d.Wo == d.W &&
-            wbytes <= 150 * 1024 && (d.cout <= 2 || d.cout_pad >= 4)) {
+            wbytes <= 150 * 1024 && (d.cout <= 2 || d.cout_pad >= 4) && (size_t)d.N * d.H * d.W * d.in_ld * sizeof(float) < 0xFFFFFFF0ull) {
             constexpr int RUN = 4;
             const int run = d.cout <= 2 ? RUN : RUN / 2;
             const int runs_per_row = (d.W + run - 1) / run;
             const long total_runs = (long)d.N * d.H * runs_per_row;
             const int ppw = 64 >> logG;
-            long blocks = (total_runs + 8 * ppw - 1) / (8 * ppw);
-            if (blocks > 1024) blocks = 1024;
+            long blocks = (total_runs + 4 * ppw - 1) / (4 * ppw);
+            if (blocks > 1024) blocks = 1024;             // 4 blocks of 4 waves per CU: one resident round, the weights are staged once per block
             static bool attr_set = false;
             if (!attr_set) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small3x3_kernel<2, RUN>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small3x3_kernel<4, RUN / 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
                 attr_set = true;
             }
-            if (d.cout <= 2) hipLaunchKernelGGL((conv_small3x3_kernel<2, RUN>), dim3((unsigned)blocks), dim3(512), wbytes, s, d, G, logG, runs_per_row, total_runs);
-            else hipLaunchKernelGGL((conv_small3x3_kernel<4, RUN / 2>), dim3((unsigned)blocks), dim3(512), wbytes, s, d, G, logG, runs_per_row, total_runs);
+            if (d.cout <= 2) hipLaunchKernelGGL((conv_small3x3_kernel<2, RUN>), dim3((unsigned)blocks), dim3(256), wbytes, s, d, G, logG, runs_per_row, total_runs);
+            else hipLaunchKernelGGL((conv_small3x3_kernel<4, RUN / 2>), dim3((unsigned)blocks), dim3(256), wbytes, s, d, G, logG, runs_per_row, total_runs);
             return vps_launch_status();
         }
         const long total = (long)d.nclass * M;
