@@ -81,7 +81,9 @@ CONV_TRACE = None
 # the device-scope release / acquire around the ticket (buffer_wbl2 / buffer_inv: the partials of a tile come from blocks on
 # different XCDs, each with its own L2) writes back and invalidates a whole L2 per block. Kept as an option, OFF.
 SPLITK_LAST_BLOCK = os.environ.get('VPS_SPLITK_LAST_BLOCK', '0') == '1'
-SMALL_ON_MFMA = os.environ.get('VPS_SMALL_MFMA', '1') != '0'      # 0: narrow-output layers always on the vector kernel (A/B runs)
+# 1: the 3x3 narrow-output layers with >= 64 input channels on large maps run on the MFMA tile kernel (a second packed copy). It won
+# against the first vector kernel (predict_flow2 0.133 -> 0.080 ms); the round-3 vector kernel does 0.059 ms in exact fp32: default off.
+SMALL_ON_MFMA = os.environ.get('VPS_SMALL_MFMA', '0') != '0'
 GN_REP = 32   # copies of the GroupNorm sums a conv epilogue spreads its atomics over (vps_conv_desc.gn_rep)
 
 
