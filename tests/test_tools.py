@@ -88,4 +88,7 @@ def test_check_isa_reports_resources_and_mix():
     h8 = mix['void conv_mfma_h8_kernel<4, 3, 3>']
     assert h8['mfma'] == 216 and h8['barrier'] == 9                       # 9 taps x (2 slabs x 3 products x 2 x 2 fragments), one barrier per tap
     assert h8['valu'] / h8['mfma'] < 5 and h8['lds_read'] / h8['mfma'] < 2        # the issue budget of DESIGN.md 3.1
-    assert mix['void conv_mfma_h8s2_kernel<4, 5>']['mfma'] == 600         # 25 taps of the phase-split 5x5 stride-2 kernel
+    assert mix['void conv_mfma_h8s2_kernel<4, 5, 128>']['mfma'] == 600    # 25 taps of the phase-split 5x5 stride-2 kernel
+    assert mix['void conv_mfma_h8s2_kernel<4, 3, 64>']['mfma'] == 108     # the 64-column instance: one column fragment per wave
+    n16 = mix['void conv_mfma_n16_kernel<4, 3, 3>']
+    assert n16['mfma'] == 54 and n16['barrier'] == 2                      # 9 taps x 3 products x 2 pixel groups of 16x16x32, two barriers per chunk
