@@ -463,12 +463,13 @@ def main():
                        'detections_per_frame': round(ndet / max(total_frames, 1), 1),
                        'parallelism': ('clip-shard x%d (contiguous shards of %d frames), 1 p2p feature hand-off per shard boundary, tracker replay '
                                        'on rank 0 + result gather inside the timed region' % (world, args.steps)) if use_runner else 'single GPU',
-                       'pipelining': 'two HIP streams per frame; the next frame of the clip (FlowNet2 + ResNet/FPN, image-only stages) is enqueued behind '
-                                     'the current frame\'s semantic head' if (use_runner and not args.no_prefetch and not args.single_stream) else 'two HIP streams per frame' if not args.single_stream else 'one stream',
+                       'pipelining': 'two HIP streams per frame + a third for the next frame of the clip (FlowNet2 + ResNet/FPN, image-only stages, ring of '
+                                     'three workspaces), enqueued before the current frame\'s neck' if (use_runner and not args.no_prefetch and not args.single_stream) else 'two HIP streams per frame' if not args.single_stream else 'one stream',
+                       'workspace_GB': round(sum(w.nbytes() for w in [getattr(model, '_ws', None)] + list(getattr(model, '_ring', None) or []) if w is not None) / 1e9, 2),
                        'timed_region': 'inputs resident in HBM; excludes the H2D of the two 25 MB frames and the D2H of the two uint8 maps that '
                                        'tools/test_vpq.py:46-56 pays (~0.4 ms per frame over PCIe 5 x16 when not overlapped)'},
             'roofline': roof, 'stage_ms': stages,
-            'stage_ms_note': 'instrumented extra frame on ONE stream; the timed frames overlap FlowNet2 with backbone+FPN and the semantic head with the detection heads on two streams',
+            'stage_ms_note': 'instrumented extra frame on ONE stream; the timed frames overlap the semantic head with the detection heads on two streams and the next frame\'s FlowNet2 + backbone + FPN on a third',
         }
         if os.environ.get('VPS_S2_HALO', '1')[0] == '0':
             line['config']['experimental'] = 'VPS_S2_HALO=0: the phase-split stride-2 halo kernel switched off (A/B run, not the default configuration)'
