@@ -80,6 +80,7 @@ CONV_TRACE = None
 # split do it (vps_conv_desc.tile_counter): measured 31.2 instead of 42.2 frames/s (profiles/r03_bench_splitk_last_block_ab.json) -
 # the device-scope release / acquire around the ticket (buffer_wbl2 / buffer_inv: the partials of a tile come from blocks on
 # different XCDs, each with its own L2) writes back and invalidates a whole L2 per block. Kept as an option, OFF.
+SPLITK_TARGET_BLOCKS = int(os.environ.get('VPS_SPLITK_TARGET', '512'))     # blocks a split launch aims at (two per CU)
 SPLITK_LAST_BLOCK = os.environ.get('VPS_SPLITK_LAST_BLOCK', '0') == '1'
 # 1: the 3x3 narrow-output layers with >= 64 input channels on large maps run on the MFMA tile kernel (a second packed copy). It won
 # against the first vector kernel (predict_flow2 0.133 -> 0.080 ms); the round-3 vector kernel does 0.059 ms in exact fp32: default off.
@@ -430,7 +431,7 @@ class PackedConv:
         ksteps = self.kpad // 32
         ksplit = 1
         if tiles < 256 and ksteps >= 8 and not getattr(self, 'small', False):
-            ksplit = max(1, min((512 + tiles - 1) // tiles, ksteps // 4, 32))
+            ksplit = max(1, min((SPLITK_TARGET_BLOCKS + tiles - 1) // tiles, ksteps // 4, 32))
             ntap = self.KH * self.KW
             halo = (self.prec != hip.PREC_F32 and not self.deform and self.stride == 1 and self.korder == 1 and self.KH == self.KW
                     and self.KH in (2, 3) and x.N * ((d.Qh + 7) // 8) * ((d.Qw + 15) // 16) * 256 <= 3 * M)
