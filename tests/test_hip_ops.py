@@ -77,6 +77,8 @@ CONV_CASES = [
     # 10 channels: scalar stores and the channel guard; residual + BN epilogue)
     (82, 16, 3, 1, 1, 130, 520, 'leaky', False, False),
     (64, 10, 3, 1, 1, 136, 520, 'relu', True, True),
+    # 64 output channels on a map with >= 256 patches of 8x32 (where a 64-column 8-wave instance was tried and dropped): overhanging patches, residual
+    (96, 64, 3, 1, 1, 130, 520, 'relu', True, True),
 ]
 
 
@@ -141,7 +143,9 @@ def test_conv_writes_into_concat_window_and_reads_padded_window(dev):
                                                 # 4 parity classes x 128 tiles of 8x32: the 8-wave halo kernel on a transposed conv
                                                 (96, 128, 4, 1, 128, 256),
                                                 # 16 output channels, 4 classes x 153 patches of 8x32: the 16x16x32 kernel (f16x3)
-                                                (162, 16, 4, 1, 130, 260)])
+                                                (162, 16, 4, 1, 130, 260),
+                                                # 64 output channels, 4 classes x 72 patches of 8x32 (4-wave halo kernel, ragged width)
+                                                (96, 64, 4, 1, 64, 260)])
 def test_conv_transpose_matches_torch_cpu(dev, cin, cout, k, pad, H, W, prec, tol):
     x = _rand(2 if k == 2 else 1, cin, H, W, seed=1)
     w = _rand(cin, cout, k, k, seed=2, scale=(1.0 / (cin * k)) ** 0.5)
