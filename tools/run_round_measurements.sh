@@ -23,12 +23,16 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ss -o
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -o pmc -- python $R/bench.py --steps 1 --warmup 1 --single-stream --no-cpu-baseline --no-extras --conv-table $R/gpurun_out/conv_table_pmc.txt > /dev/null 2> $R/gpurun_out/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -o pmc -- python $R/bench.py --steps 1 --warmup 1 --single-stream --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/pmc_write.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_mfma -o pmc -- python $R/bench.py --steps 1 --warmup 1 --single-stream --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/pmc_mfma.err
+# occupancy of the timed frames (three streams): union and sum of the kernel intervals per frame interval
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/trace.err
 cd $R
+python tools/trace_gaps.py gpurun_out/trace --out gpurun_out/${T}_frame_occupancy_traced.json
+python tools/bench_input_pipeline.py --frames 64 --workers 1 2 4 8 16 32 > gpurun_out/${T}_input_pipeline_decode_upload_prep.json 2>> gpurun_out/${T}_bench.err
 python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 5 > gpurun_out/${T}_pmc_traffic_f16x3.json 2> gpurun_out/pmc_traffic.err
 python tools/pmc_mfma.py gpurun_out/pmc_mfma > gpurun_out/${T}_pmc_mfma_busy_f16x3.json 2> gpurun_out/pmc_mfma_tool.err
 python tools/pmc_per_layer.py gpurun_out/conv_table_pmc.txt.ordered.json gpurun_out/pmc_fetch gpurun_out/pmc_write > gpurun_out/${T}_traffic_per_layer_f16x3.txt 2>> gpurun_out/pmc_traffic.err
 cp $(find gpurun_out/prof_ss -name "*kernel_stats.csv" | head -1) gpurun_out/${T}_fusetrack_kernel_stats_single_stream_f16x3.csv
 # keep the merged-back payload small: drop the raw per-dispatch traces
-find gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma gpurun_out/prof_ss -name "*kernel_trace.csv" -delete
+find gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma gpurun_out/prof_ss gpurun_out/trace -name "*kernel_trace.csv" -delete
 find gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma -name "*counter_collection.csv" -size +20M -delete
 du -sh gpurun_out
