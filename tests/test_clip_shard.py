@@ -1,4 +1,4 @@
-"""CPU / gloo, world_size 2: the clip-sharding protocol of vps_amd/clip_shard.py (frame partition, ONE point-to-point
+"""CPU / gloo, world_size 2 (oracle-backed detector) and world_size 8 / 4 (cheap chained backend): the clip-sharding protocol of vps_amd/clip_shard.py (frame partition, ONE point-to-point
 hand-off of the gathered pre-neck feature per shard boundary, fixed-layout detection records streamed to rank 0, which assigns
 the track ids frame by frame in clip order) gives exactly the
 outputs of the sequential single-process run. The compute backend injected here is oracle-backed (tests may use the
@@ -208,3 +208,106 @@ def test_clip_shorter_than_world_does_not_deadlock():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The protocol itself at the node size the benchmark is quoted on (8 ranks, the 30-frame clip of BASELINE config 4, shards
+# 4,4,4,4,4,4,3,3) with a cheap deterministic backend: every record depends on the frame, on its reference frame AND on the
+# feature handed over from the previous rank, and the id assignment depends on the whole history in clip order — a lost, swapped
+# or stale hand-off / record / map, or an assignment out of clip order, changes the result.
+class ChainBackend:
+    max_det = 16
+    Hm, Wm = 8, 16
+
+    def __init__(self):
+        self.state = 7          # order-dependent tracker state
+
+    def record_layout(self):
+        return [('det_bboxes', 4, torch.float32), ('det_labels', 1, torch.int64), ('cls_prob', 1, torch.float32), ('emb', 8, torch.float32)]
+
+    def map_shape(self):
+        return self.Hm, self.Wm
+
+    def ref_feature(self, img):
+        return (img.reshape(1, 3, -1)[:, :, :16].clone() * 0.5 + 1.0).contiguous()
+
+    def ref_feature_buffer(self, img):
+        return torch.empty(1, 3, 16)
+
+    def process(self, img, ref_img, ref_feature, iid, is_first):
+        ref = ref_feature if ref_feature is not None else self.ref_feature(ref_img)
+        t = iid % 10000 - 1
+        K = 2 + t % 5
+        base = float(img.sum()) + 3.0 * float(ref.sum())
+        g = torch.Generator().manual_seed(int(abs(base) * 1000) % (2 ** 31))
+        bb = torch.rand(K, 4, generator=g)
+        keep = np.arange(0, K, 2)
+        return dict(det_bboxes=bb, det_labels=torch.arange(K) % 3, cls_prob=torch.rand(K, generator=g), emb=torch.rand(K, 8, generator=g),
+                    keep_inds=keep, fcn_outputs=torch.full((1, self.Hm, self.Wm), t % 250, dtype=torch.uint8),
+                    panoptic_outputs=(torch.arange(self.Hm * self.Wm).reshape(1, self.Hm, self.Wm) % (K + 1)).to(torch.uint8),
+                    panoptic_cls_inds=torch.arange(keep.size) + 11, panoptic_cls_prob=torch.rand(keep.size, generator=g),
+                    panoptic_det_labels=torch.arange(keep.size) % 3)
+
+    def assign(self, rec, is_first):
+        if is_first:
+            self.state = 7
+        K = rec['det_bboxes'].shape[0]
+        ids = []
+        for i in range(K):
+            self.state = (self.state * 31 + int(float(rec['emb'][i].sum() + rec['det_bboxes'][i].sum()) * 4096) + int(rec['det_labels'][i])) % 1000003
+            ids.append(self.state % 97)
+        return np.asarray(ids)
+
+    def finalize(self, rec, ids):
+        return dict(t=rec['t'], panoptic_det_obj_ids=np.asarray(ids)[np.asarray(rec['keep_inds'])],
+                    cls=torch.as_tensor(rec['panoptic_cls_inds']).numpy().copy(), prob=torch.as_tensor(rec['panoptic_cls_prob']).numpy().copy(),
+                    pan=torch.as_tensor(rec['panoptic_outputs']).numpy().copy(), sem=torch.as_tensor(rec['fcn_outputs']).numpy().copy())
+
+
+def _chain_frames(n):
+    g = torch.Generator().manual_seed(5)
+    return [torch.rand(1, 3, 8, 16, generator=g) for _ in range(n)]
+
+
+def _worker_chain(rank, world, port, q, nframes):
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    frames = _chain_frames(nframes)
+    loads = []
+    outs = ClipShardRunner(ChainBackend(), rank, world, dist).run(lambda t: (loads.append(t), frames[t])[1], nframes)
+    s, e = partition(nframes, world)[rank]
+    # every frame of the shard (and the reference of its first frame) is loaded exactly once
+    assert sorted(loads) == list(range(max(s - 1, 0), e)) if e > s else loads == [], (rank, loads)
+    if rank == 0:
+        q.put(outs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('world,nframes', [(8, 30), (4, 6)])
+def test_node_size_protocol_equals_sequential(world, nframes):
+    frames = _chain_frames(nframes)
+    be = ChainBackend()
+    seq = []
+    for t in range(nframes):
+        rec = be.process(frames[t], frames[t - 1 if t else 0], None, 10000 + t + 1, t == 0)
+        rec['t'] = t
+        seq.append(be.finalize(rec, be.assign(rec, t == 0)))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_chain, args=(r, world, port, q, nframes)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = q.get(timeout=500)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert [o['t'] for o in outs] == list(range(nframes))
+    for a, b in zip(outs, seq):
+        for k in ('panoptic_det_obj_ids', 'cls', 'pan', 'sem'):
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), (a['t'], k, a[k], b[k])
+        assert np.allclose(a['prob'], b['prob'], rtol=0, atol=0)
