@@ -134,14 +134,20 @@ class ClipShardRunner:
                 recv_buf = be.ref_feature_buffer(load_frame(s))
                 ops.append(dist.P2POp(dist.irecv, recv_buf, rank - 1))
             reqs = self._post(ops) if ops else []
-        # 2) rank 0 posts the receives of every other rank's records + maps, in clip order (per peer the order of its sends)
+        # 2) rank 0 posts the receives of every other rank's records + maps: per peer in the order of its sends (frame order), and
+        # across peers by position in the shard, not peer by peer — the ranks finish their j-th frames at about the same time, and on
+        # RCCL the point-to-point operations of a rank run in posting order on one communicator stream: posted peer by peer, the
+        # sends of ranks 2..N-1 would spin (on a few CUs of their GPU) until rank 1's whole shard had arrived
         inbox = {}
         if world > 1 and rank == 0:
             cap, lay, n = self._layout()
             dev = self.device if self.device is not None else load_frame(0).device
             Hm, Wm = be.map_shape()
-            for r in range(1, world):
-                for t in range(*parts[r]):
+            for j in range(max(b - a for a, b in parts)):
+                for r in range(1, world):
+                    t = parts[r][0] + j
+                    if t >= parts[r][1]:
+                        continue
                     buf = torch.zeros(n, dtype=torch.float32, device=dev)
                     maps = torch.empty(2, Hm, Wm, dtype=torch.uint8, device=dev)
                     inbox[t] = (buf, maps, self._post([dist.P2POp(dist.irecv, buf, r), dist.P2POp(dist.irecv, maps, r)]))
