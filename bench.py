@@ -481,7 +481,7 @@ def main():
             line['clip30'] = clip30
         if other is not None:
             line['other_arithmetic'] = other
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU leg is reported at N = 1 only (it takes about a minute of host time)
             line['cpu_baseline'] = cpu_baseline(args.seed)
         print(json.dumps(line))
     if world > 1:
