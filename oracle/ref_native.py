@@ -125,7 +125,11 @@ def nms_mmdet(dets, thr):
     if dets.shape[0] == 0:
         return dets, dets.new_zeros(0, dtype=torch.long)
     n = dets.shape[0]
-    order = torch.sort(dets[:, 4], descending=True, stable=True)[1]     # scores.sort(0, descending=True)
+    # nms_wrapper.py: `scores.sort(0, descending=True)` — torch's default sort is NOT stable, so the reference's order among EXACTLY
+    # equal scores is whatever its sort implementation produces (unspecified). This harness, the oracle (oracle/ops.py:nms_mmdet)
+    # and the product (vps_amd/heads.py, operators.py) all pin the stable order; the 'ties' case of test_ref_native_gpu.py therefore
+    # checks the compiled kernel's suppression logic on tied SCORES under that one order, not the reference's tie order.
+    order = torch.sort(dets[:, 4], descending=True, stable=True)[1]
     boxes_sorted = dets.index_select(0, order).contiguous()
     keep = np.zeros(n, dtype=np.int64)
     num = ctypes.c_int()
