@@ -129,3 +129,30 @@ def test_packed_transposed_conv_classes_reproduce_conv_transpose(prec):
             y[:, :, py::2, px::2] = acc
     rel = float(((y - ref).abs() / den).max())
     assert rel <= BOUND[prec], rel
+
+
+def test_n16_weight_fragment_gather_from_the_common_packed_layout():
+    """conv_mfma_n16_kernel (16x16x32 MFMA, 5..16 output channels) takes its A operand — 16 output channels x 32 k — from the SAME
+    packed buffer as every other kernel: lane l of the fragment of 32-k step s reads the 16 bytes of lane (l & 15) + 32 (g & 1) of
+    16-k step 2s + (g >> 1), g = l >> 4 (csrc/conv_mfma.hip: load_W / `wlane`). Mirror that address arithmetic on the host and check
+    that the lane then holds W[channel l & 15][k = 32 s + 8 g .. + 7], the operand layout of v_mfma_f32_16x16x32_f16, for every plane
+    and k step of a chunk-major 3x3 layer and of a transposed layer's parity classes."""
+    g = torch.Generator().manual_seed(3)
+    for transposed in (False, True):
+        w = torch.randn((82, 16, 4, 4) if transposed else (16, 82, 3, 3), generator=g)
+        pc = nhwc.PackedConv(w, None, None, stride=2 if transposed else 1, padding=1, transposed=transposed, device='cpu', prec=hip.PREC_F16X3)
+        assert pc.korder == 1 and pc.cout_pad == 32
+        ws = pc.w_split                                        # [plane][class][cout_pad/32][kpad/16][2][32][8]
+        P, C, OB, KB = ws.shape[:4]
+        flat = ws.reshape(P, C, OB, KB, 512)                   # one 1 KB fragment of the 32x32x16 shape = 512 elements, lane-major
+        nat = ws.permute(0, 1, 2, 5, 3, 4, 6).reshape(P, C, OB * 32, KB * 16)     # natural [cout][k]
+        lanes = torch.arange(64)
+        grp = lanes >> 4
+        src_lane = (lanes & 15) + 32 * (grp & 1)
+        for s in range(KB // 2):
+            for p in range(P):
+                for c in range(C):
+                    frag = torch.stack([flat[p, c, 0, 2 * s + int(grp[l] >> 1), int(src_lane[l]) * 8:int(src_lane[l]) * 8 + 8] for l in range(64)])   # [64 lanes][8]
+                    want = torch.stack([nat[p, c, int(l & 15), 32 * s + 8 * int(grp[l]):32 * s + 8 * int(grp[l]) + 8] for l in lanes])
+                    assert torch.equal(frag, want), (transposed, s, p, c)
+        assert float(nat[:, :, 16:].abs().max()) == 0.0       # channels 16..31 of the padded block are zero: one 16-row block suffices
