@@ -319,6 +319,16 @@ int vps_panoptic_combine_dev(const float* fcn_score, int score_ld, int Hs, int W
  * Device-resident detection post-processing (csrc/head_ops.hip): the order-defining HOST code of the reference's heads as
  * single-workgroup kernels, so that a frame needs ONE mid-frame D2H (the detection list) and one at its end (kept list + ids).
  * -------------------------------------------------------------------------------------------- */
+/* ref: models/anchor_heads/rpn_head.py:62-91 (sigmoid objectness, `scores.topk(nms_pre)`, gathers) + core/anchor/anchor_generator.py:55-72
+ * (grid anchors) + core/bbox/transforms.py:34-68 (delta2bbox, means 0, clipped to the image): ONE launch for all levels, one
+ * workgroup per level. cls[l] / reg[l]: NHWC maps [H_l][W_l][ld] of level l (device pointers in host arrays; channels [0, A) /
+ * [0, 4A) used), base_anchors: device [nlv][A][4] (the rounded base anchors of gen_base_anchors), strides / stds [4]: host arrays.
+ * boxes [nlv][nms_pre][5]: the min(H_l*W_l*A, nms_pre) best positions of level l in DESCENDING score order (equal scores: ascending
+ * position), rows beyond that count zeroed. nlv <= 8, nms_pre <= 8192. */
+int vps_rpn_select(const float* const* cls, const int32_t* cls_ld, const float* const* reg, const int32_t* reg_ld,
+                   const int32_t* Hs, const int32_t* Ws, const float* strides, int nlv, int A, const float* base_anchors,
+                   int nms_pre, const float* stds, float img_h, float img_w, float* boxes, void* stream);
+
 /* ref: models/anchor_heads/rpn_head.py:94-104 (`mlvl_proposals` cat, `[:nms_post]` per level, top `max_num` by score).
  * boxes [nlv][nmax][5] per level in descending score order, keep [nlv][nmax] / nkeep [nlv] as written by vps_nms_batched.
  * out [max_num][5] (rows >= n_out[0] zeroed), n_out[0] = min(max_num, sum_l min(nkeep[l], nms_post)). nlv*nms_post <= 8192. */

@@ -520,6 +520,54 @@ def test_delta2bbox_overlaps_softmax(dev):
         _cmp(o, fn(x, dim=1), rtol=1e-5, atol=1e-6, what='softmax')
 
 
+@pytest.mark.parametrize('quant', [0.0, 0.5, 1e9], ids=['continuous', 'ties', 'constant'])
+def test_rpn_select_matches_topk_gather_decode(dev, quant):
+    """vps_rpn_select (one launch: sigmoid, top nms_pre per level, gathers, delta2bbox) against the chain it replaces
+    (rpn_head.py:62-91): torch sigmoid / stable descending sort on the device + gen anchors + vps_delta2bbox. Levels: one
+    below nms_pre (kept whole), one above the 8192-key sort buffer (radix select), one in between; logits quantised to force
+    exactly tied scores (ascending position among equals, also across the threshold) and a constant map (every score tied)."""
+    from ctypes import c_float, c_int32, c_void_p
+    from vps_amd import heads as HD
+    lib = hip.load()
+    A, nms_pre = 3, 1000
+    shapes = [(96, 160), (40, 72), (16, 18)]
+    strides = [4., 8., 16.]
+    nlv = len(shapes)
+    base = torch.stack([HD.gen_base_anchors(int(s), (8, 16, 32), (0.5, 1.0, 2.0)) for s in strides]).to(dev).contiguous()
+    cls_t, reg_t = [], []
+    for li, (H, W) in enumerate(shapes):
+        c = _rand(H, W, 4, seed=10 + li, scale=2.0)
+        if quant >= 1e9:
+            c = torch.zeros_like(c) + 0.25
+        elif quant > 0:
+            c = torch.round(c / quant) * quant
+        cls_t.append(c.to(dev).contiguous()); reg_t.append(_rand(H, W, 12, seed=20 + li, scale=0.3).to(dev).contiguous())
+    boxes = torch.full((nlv, nms_pre, 5), -1.0, device=dev)
+    cp = (c_void_p * nlv)(*[c.data_ptr() for c in cls_t]); cl = (c_int32 * nlv)(*[4] * nlv)
+    rp = (c_void_p * nlv)(*[r.data_ptr() for r in reg_t]); rl = (c_int32 * nlv)(*[12] * nlv)
+    Hs = (c_int32 * nlv)(*[h for h, _ in shapes]); Ws = (c_int32 * nlv)(*[w for _, w in shapes])
+    st = (c_float * nlv)(*strides); stds = (c_float * 4)(1., 1., 1., 1.)
+    hip.check(lib.vps_rpn_select(cp, cl, rp, rl, Hs, Ws, st, nlv, A, hip.ptr(base), nms_pre, stds, 384., 640., hip.ptr(boxes),
+                                 hip.stream_ptr()), 'vps_rpn_select')
+    torch.cuda.synchronize()
+    for li, (H, W) in enumerate(shapes):
+        scores = cls_t[li][..., :A].reshape(-1).sigmoid()
+        deltas = reg_t[li][..., :4 * A].reshape(-1, 4)
+        sx = torch.arange(0, W, dtype=torch.float32) * strides[li]; sy = torch.arange(0, H, dtype=torch.float32) * strides[li]
+        xx = sx.repeat(H); yy = sy.view(-1, 1).repeat(1, W).view(-1)
+        anchors = (base[li].cpu()[None] + torch.stack([xx, yy, xx, yy], -1)[:, None, :]).view(-1, 4).to(dev)
+        sc, order = torch.sort(scores, descending=True, stable=True)
+        n = min(scores.numel(), nms_pre)
+        order = order[:n]
+        d_, a_, s_ = deltas[order].contiguous(), anchors[order].contiguous(), sc[:n].contiguous()
+        ref = torch.zeros(nms_pre, 5, device=dev)
+        hip.check(lib.vps_delta2bbox(hip.ptr(a_), hip.ptr(d_), hip.ptr(s_), hip.ptr(ref), n, 1., 1., 1., 1., 384., 640., hip.stream_ptr()), 'd2b')
+        torch.cuda.synchronize()
+        got = boxes[li].cpu(); ref = ref.cpu()
+        assert torch.equal(got[:, 4], ref[:, 4]), 'level %d: scores / selection differ (first at %s)' % (li, torch.nonzero(got[:, 4] != ref[:, 4])[:3].flatten().tolist())
+        assert torch.equal(got, ref), 'level %d: decoded boxes differ, max %.3e' % (li, float((got - ref).abs().max()))
+
+
 # ------------------------------------------------------------------------------------------------ reference-named operator API
 def test_reference_named_operator_wrappers(dev):
     """vps_amd/operators.py: the reference's operator classes (NCHW signatures) backed by the C-ABI"""

@@ -47,6 +47,8 @@ class ClipShardRunner:
     receives up front) — and assembles the outputs. No object collectives, no pickling, no barrier between "compute" and
     "replay": the only serial work is the tracker step itself (two small kernels per frame)."""
 
+    recv_window = 3        # positions per peer whose receives rank 0 keeps posted
+
     def __init__(self, backend, rank=0, world=1, dist=None, device=None, track_keys=('det_bboxes', 'det_labels', 'cls_prob', 'emb')):
         self.backend, self.rank, self.world, self.dist = backend, rank, world, dist
         self.device = device
@@ -88,7 +90,7 @@ class ClipShardRunner:
         for key, w, dt in lay:
             v = buf[o:o + K * w].to(dt, copy=True)        # own allocation: the kernels need 16-byte aligned operands
             rec[key] = v.reshape(K, w) if (w > 1 or key == 'det_bboxes') else v.reshape(K); o += cap * w
-        rec['fcn_outputs'], rec['panoptic_outputs'] = maps[1][None], maps[0][None]
+        rec['fcn_outputs'], rec['panoptic_outputs'] = maps[1][None].clone(), maps[0][None].clone()     # `maps` is recycled by the runner
         return rec
 
     def _post(self, ops):
@@ -138,19 +140,30 @@ class ClipShardRunner:
         # across peers by position in the shard, not peer by peer — the ranks finish their j-th frames at about the same time, and on
         # RCCL the point-to-point operations of a rank run in posting order on one communicator stream: posted peer by peer, the
         # sends of ranks 2..N-1 would spin (on a few CUs of their GPU) until rank 1's whole shard had arrived
-        inbox = {}
+        # Only a WINDOW of positions is posted at a time (`recv_window` per peer, buffers recycled as step 4 consumes them): a long
+        # video would otherwise pin ~5 MB per remote frame on rank 0 and queue O(clip) receive kernels on the communicator stream
+        # (ADVICE r3). A peer's sends complete in order, so its position j + window is posted when its position j has been consumed.
+        inbox, pool = {}, []
+        post_recv = None
         if world > 1 and rank == 0:
             cap, lay, n = self._layout()
             dev = self.device if self.device is not None else load_frame(0).device
             Hm, Wm = be.map_shape()
-            for j in range(max(b - a for a, b in parts)):
-                for r in range(1, world):
-                    t = parts[r][0] + j
-                    if t >= parts[r][1]:
-                        continue
+
+            def post_recv(r, j):
+                t = parts[r][0] + j
+                if t >= parts[r][1]:
+                    return
+                if pool:
+                    buf, maps = pool.pop()
+                    buf.zero_()
+                else:
                     buf = torch.zeros(n, dtype=torch.float32, device=dev)
                     maps = torch.empty(2, Hm, Wm, dtype=torch.uint8, device=dev)
-                    inbox[t] = (buf, maps, self._post([dist.P2POp(dist.irecv, buf, r), dist.P2POp(dist.irecv, maps, r)]))
+                inbox[t] = (buf, maps, self._post([dist.P2POp(dist.irecv, buf, r), dist.P2POp(dist.irecv, maps, r)]))
+            for j in range(min(self.recv_window, max(b - a for a, b in parts))):
+                for r in range(1, world):
+                    post_recv(r, j)
         # 3) this rank's frames
         outs, sent = [], []
         prev = None
@@ -184,12 +197,16 @@ class ClipShardRunner:
             rq.wait()
         # 4) rank 0: the other shards' frames in clip order, each as soon as its record has arrived
         if rank == 0:
-            for t in sorted(inbox):
-                buf, maps, rq = inbox[t]
-                for q in rq:
-                    q.wait()
-                rec = self._unpack(buf, maps, t)
-                outs.append(be.finalize(rec, be.assign(rec, t == 0)))
+            for r in range(1, world):
+                for j in range(parts[r][1] - parts[r][0]):
+                    t = parts[r][0] + j
+                    buf, maps, rq = inbox.pop(t)
+                    for q in rq:
+                        q.wait()
+                    rec = self._unpack(buf, maps, t)       # copies everything it keeps: the buffers go back to the pool
+                    outs.append(be.finalize(rec, be.assign(rec, t == 0)))
+                    pool.append((buf, maps))
+                    post_recv(r, j + self.recv_window)
             return outs
         for buf, maps, rq in sent:
             for q in rq:
@@ -219,7 +236,20 @@ class DetectorBackend:
         return self.H, self.W
 
     def ref_feature(self, img):
-        return self.det.gathered_feature(img)
+        """gathered pre-neck feature of the shard's last frame, for the hand-off to the next rank. f16x3: the ResNet + FPN pass behind
+        it reports its fp16 range like every frame does, but no end-of-frame read follows before the send - so the report is read
+        here (one 4-byte D2H ahead of the isend): an overflowed layer is switched to bf16x6 and the feature is computed again, the
+        receiver never sees an fp16-overflowed `ref_bsf`"""
+        from . import hip, nhwc
+        for _ in range(4):
+            feat = self.det.gathered_feature(img)
+            if nhwc.DEFAULT_PREC != hip.PREC_F16X3 and nhwc._F16_NEXT[0] <= 1:
+                return feat
+            if int(nhwc.f16_status(img.device).amax().item()) == 0:
+                return feat
+            nhwc.f16_fallback(img.device)
+            self.det._handoff = None
+        raise hip.VpsHipError('f16x3: the hand-off feature still overflows the fp16 range after three rounds of per-layer bf16x6 fallback')
 
     def ref_feature_buffer(self, img):
         C = self.det.extra_neck.in_channels

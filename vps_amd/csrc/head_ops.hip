@@ -86,6 +86,174 @@ void rpn_collect_kernel(const float* __restrict__ boxes, const int* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// RPN, per level (rpn_head.py:62-91 + core/bbox/transforms.py:34-68): objectness = sigmoid(rpn_cls) over the (h, w, anchor)
+// positions, the nms_pre best by score (torch.topk; a level with <= nms_pre positions keeps all of them and nms() sorts them:
+// the same descending list), their anchors + deltas -> delta2bbox -> [count][5] boxes in descending score order. ONE workgroup
+// per level (grid = levels), everything a host loop of torch kernels did before (sigmoid, topk, three gathers, decode):
+//   1. radix select of the count-th largest key (key = bits of the fp32 score, all positive: unsigned order = float order) on
+//      4096 / 1024 / 1024-bin LDS histograms, stopping as soon as everything at or above the threshold bin fits the sort buffer;
+//   2. those candidates -> 64-bit keys (score bits | ~index) -> bitonic sort, descending: equal scores in ascending index order
+//      (what a stable descending sort gives; the reference's own order among exactly equal scores is torch.topk's, unspecified);
+//   3. the first `count` are decoded (anchor = rounded base anchor + stride * (x, y), generated on the fly).
+// The score map is read 2 (typical) .. 4 times by one CU: it is <= 2 MB and stays in the XCD's L2.
+// ------------------------------------------------------------------------------------------------
+struct RpnLevels {
+    const float* cls[8];
+    const float* reg[8];
+    int cls_ld[8], reg_ld[8], H[8], W[8];
+    float stride[8];
+};
+
+__device__ __forceinline__ unsigned rpn_key(const float* __restrict__ cls, const int ld, const int A, const int i) {
+    const int pos = i / A, a = i - pos * A;
+    const float x = cls[(size_t)pos * ld + a];
+    const float s = 1.f / (1.f + expf(-x));          // at::sigmoid on the device: 1 / (1 + exp(-x)) in fp32
+    return __float_as_uint(s);
+}
+
+__global__ __launch_bounds__(1024)
+void rpn_select_kernel(const RpnLevels L, const int A, const float* __restrict__ base_anchors, const int nms_pre, const float sx,
+                       const float sy, const float sw, const float sh, const float img_h, const float img_w, const float max_ratio,
+                       float* __restrict__ boxes) {
+    __shared__ u64 keys[SORT_CAP];
+    __shared__ int hist[4096];
+    __shared__ int scan[1024];
+    __shared__ int sh_bin, sh_above, sh_cnt;
+    const int l = blockIdx.x, t = threadIdx.x;
+    const float* __restrict__ cls = L.cls[l];
+    const int ld = L.cls_ld[l], n = L.H[l] * L.W[l] * A;
+    const int count = min(n, nms_pre);
+    float* __restrict__ out = boxes + (size_t)l * nms_pre * 5;
+
+    // ---- 1. threshold: keys whose bits above `shift` equal `prefix` are still undecided; `above` keys are known to be larger
+    unsigned prefix = 0;
+    int shift = 20, nbits = 12, above = 0;
+    bool exact = false;          // the threshold key is known exactly (shift == 0 reached)
+    if (n > SORT_CAP || n > count) {
+        for (;;) {
+            const int nbin = 1 << nbits;
+            for (int b = t; b < nbin; b += 1024) hist[b] = 0;
+            __syncthreads();
+            const int hs = shift + nbits;                  // bits >= hs are decided
+            for (int i = t; i < n; i += 1024) {
+                const unsigned k = rpn_key(cls, ld, A, i);
+                if (hs >= 32 || (k >> hs) == (prefix >> hs)) atomicAdd(&hist[(k >> shift) & (nbin - 1)], 1);
+            }
+            __syncthreads();
+            // bins from the top: thread t owns bins [nbin - 1 - 4t - 3, nbin - 1 - 4t] (nbin / 1024 of them: 4 or 1)
+            const int per = nbin >> 10;
+            int own = 0;
+            for (int e = 0; e < per; ++e) own += hist[nbin - 1 - (t * per + e)];
+            scan[t] = own;
+            __syncthreads();
+            for (int off = 1; off < 1024; off <<= 1) {
+                const int v = t >= off ? scan[t - off] : 0;
+                __syncthreads();
+                scan[t] += v;
+                __syncthreads();
+            }
+            const int need = count - above;                // rank of the threshold among the undecided keys, from the top (>= 1)
+            const int incl = scan[t], excl = incl - own;
+            if (excl < need && need <= incl) {             // the threshold bin is one of this thread's
+                int c = excl;
+                for (int e = 0; e < per; ++e) {
+                    const int b = nbin - 1 - (t * per + e);
+                    if (c + hist[b] >= need) { sh_bin = b; sh_above = c; sh_cnt = hist[b]; break; }
+                    c += hist[b];
+                }
+            }
+            __syncthreads();
+            const int bin = sh_bin, pop = sh_cnt;
+            above += sh_above;
+            prefix |= (unsigned)bin << shift;
+            __syncthreads();
+            if (shift == 0) { exact = true; break; }
+            if (above + pop <= SORT_CAP) break;            // everything from this bin upwards fits the sort buffer
+            shift -= 10; nbits = 10;
+        }
+    } else {
+        shift = 32;                                        // every key is a candidate
+    }
+
+    // ---- 2. candidates: keys >= the lower bound of the threshold bin. With an exact threshold shared by more keys than there is
+    // room for (degenerate score maps), the ties are taken in ascending index order (an ordered block scan, 1024 positions a round)
+    __syncthreads();
+    if (t == 0) sh_cnt = 0;
+    __syncthreads();
+    const unsigned lo = shift >= 32 ? 0u : (prefix >> shift) << shift;
+    int room_eq = SORT_CAP;                                // ties that still fit
+    if (exact) room_eq = count - above;
+    for (int i = t; i < n; i += 1024) {
+        const unsigned k = rpn_key(cls, ld, A, i);
+        if (exact ? k > lo : k >= lo) {
+            const int slot = atomicAdd(&sh_cnt, 1);
+            keys[slot] = ((u64)k << 32) | (u64)(0xFFFFFFFFu - (unsigned)i);
+        }
+    }
+    __syncthreads();
+    if (exact) {
+        int taken = 0;                                     // uniform across the block
+        const int base0 = sh_cnt;
+        for (int c0 = 0; c0 < n && taken < room_eq; c0 += 1024) {
+            const int i = c0 + t;
+            const unsigned k = i < n ? rpn_key(cls, ld, A, i) : 0u;
+            const int f = (i < n && k == lo) ? 1 : 0;
+            scan[t] = f;
+            __syncthreads();
+            for (int off = 1; off < 1024; off <<= 1) {
+                const int v = t >= off ? scan[t - off] : 0;
+                __syncthreads();
+                scan[t] += v;
+                __syncthreads();
+            }
+            const int rank = taken + scan[t] - f;          // this tie's position among all ties, in index order
+            if (f && rank < room_eq) keys[base0 + rank] = ((u64)k << 32) | (u64)(0xFFFFFFFFu - (unsigned)i);
+            taken += scan[1023];
+            __syncthreads();
+        }
+        if (t == 0) sh_cnt = base0 + min(taken, room_eq);
+        __syncthreads();
+    }
+    const int m = sh_cnt;                                  // count <= m <= SORT_CAP
+    const int n2 = next_pow2(m);
+    for (int i = m + t; i < n2; i += 1024) keys[i] = 0;
+    __syncthreads();
+    bitonic_sort_desc<1024>(keys, n2);
+
+    // ---- 3. decode (delta2bbox, means 0; the arithmetic of delta2bbox_kernel in det_ops.hip)
+    const float* __restrict__ reg = L.reg[l];
+    const int rld = L.reg_ld[l], W = L.W[l];
+    const float stride = L.stride[l];
+    for (int i = t; i < nms_pre; i += 1024) {
+        float o[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (i < count) {
+            const u64 key = keys[i];
+            const int idx = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+            const int pos = idx / A, a = idx - pos * A;
+            const int y = pos / W, x = pos - y * W;
+            const float* ba = base_anchors + ((size_t)l * A + a) * 4;
+            const float fx = (float)x * stride, fy = (float)y * stride;
+            const float a0 = ba[0] + fx, a1 = ba[1] + fy, a2 = ba[2] + fx, a3 = ba[3] + fy;
+            const float* d = reg + (size_t)pos * rld + 4 * a;
+            const float dx = d[0] * sx, dy = d[1] * sy;
+            float dw = d[2] * sw, dh = d[3] * sh;
+            dw = fminf(fmaxf(dw, -max_ratio), max_ratio);
+            dh = fminf(fmaxf(dh, -max_ratio), max_ratio);
+            const float px = (a0 + a2) * 0.5f, py = (a1 + a3) * 0.5f;
+            const float pw = a2 - a0 + 1.0f, ph = a3 - a1 + 1.0f;
+            const float gw = pw * expf(dw), gh = ph * expf(dh);
+            const float gx = __fadd_rn(px, __fmul_rn(pw, dx)), gy = __fadd_rn(py, __fmul_rn(ph, dy));
+            float x1 = gx - gw * 0.5f + 0.5f, y1 = gy - gh * 0.5f + 0.5f;
+            float x2 = gx + gw * 0.5f - 0.5f, y2 = gy + gh * 0.5f - 0.5f;
+            o[0] = fminf(fmaxf(x1, 0.f), img_w - 1.f); o[1] = fminf(fmaxf(y1, 0.f), img_h - 1.f);
+            o[2] = fminf(fmaxf(x2, 0.f), img_w - 1.f); o[3] = fminf(fmaxf(y2, 0.f), img_h - 1.f);
+            o[4] = __uint_as_float((unsigned)(key >> 32));
+        }
+        for (int e = 0; e < 5; ++e) out[(size_t)i * 5 + e] = o[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // MaskROI, first half (mask_roi.py:43-95 with class_agnostic=True, clip_boxes=True, bbox_class_agnostic=False):
 // candidate q = roi*(nc-1) + (cls-1); those with prob > thr are sorted by descending score (gpu_nms.pyx:23-38:
 // `order = scores.argsort()[::-1]`; equal scores: the larger q first = a stable ascending sort reversed) and their refined,
@@ -321,6 +489,22 @@ extern "C" int vps_rpn_collect(const float* boxes, const int32_t* keep, const in
     if (!boxes || !keep || !nkeep || !out || !n_out) return VPS_EARG(1);
     if (nlv < 1 || nlv > 8 || nmax < 1 || nms_post < 1 || max_num < 1 || (long)nlv * min(nms_post, nmax) > SORT_CAP) return VPS_EARG(2);
     hipLaunchKernelGGL(rpn_collect_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, boxes, keep, nkeep, nlv, nmax, nms_post, max_num, out, n_out);
+    return vps_launch_status();
+}
+
+extern "C" int vps_rpn_select(const float* const* cls, const int32_t* cls_ld, const float* const* reg, const int32_t* reg_ld,
+                              const int32_t* Hs, const int32_t* Ws, const float* strides, int nlv, int A, const float* base_anchors,
+                              int nms_pre, const float* stds, float img_h, float img_w, float* boxes, void* stream) {
+    if (!cls || !cls_ld || !reg || !reg_ld || !Hs || !Ws || !strides || !base_anchors || !stds || !boxes) return VPS_EARG(1);
+    if (nlv < 1 || nlv > 8 || A < 1 || nms_pre < 1 || nms_pre > SORT_CAP) return VPS_EARG(2);
+    RpnLevels L;
+    for (int l = 0; l < nlv; ++l) {
+        if (!cls[l] || !reg[l] || Hs[l] < 1 || Ws[l] < 1 || cls_ld[l] < A || reg_ld[l] < 4 * A || (long)Hs[l] * Ws[l] * A > 0x7fffffffL) return VPS_EARG(3);
+        L.cls[l] = cls[l]; L.reg[l] = reg[l]; L.cls_ld[l] = cls_ld[l]; L.reg_ld[l] = reg_ld[l]; L.H[l] = Hs[l]; L.W[l] = Ws[l]; L.stride[l] = strides[l];
+    }
+    const float max_ratio = (float)fabs(log(16.0 / 1000.0));
+    hipLaunchKernelGGL(rpn_select_kernel, dim3(nlv), dim3(1024), 0, (hipStream_t)stream, L, A, base_anchors, nms_pre, stds[0], stds[1], stds[2],
+                       stds[3], img_h, img_w, max_ratio, boxes);
     return vps_launch_status();
 }
 

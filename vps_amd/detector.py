@@ -188,7 +188,13 @@ class PanopticFuseTrack(HipModule):
         beyond the fp16 range (|x| > 65504; reported per layer through vps_conv_desc.status, read with the frame's end-of-frame
         read) is switched to bf16x6 for good and the frame is computed again from the state it started in — no exception, no
         wrong result; `nhwc.F16_FALLBACKS` counts the switched layers."""
+        if img.is_cuda:
+            self.ensure_packed(img.device)      # a lazily packed model registers its f16x3 layers here: `guard` must see them (ADVICE r3)
         guard = nhwc._F16_NEXT[0] > 1 and img.is_cuda
+        if self._mem_n is None:
+            # an exception between the tracker kernels and the end-of-frame read of an earlier call left the host's view of the memory
+            # size unset: the device word is authoritative
+            self._mem_n = int(self._mem_count.item()) if self._mem_count is not None else 0
         for attempt in range(4):
             snap = self._tracker_snapshot() if guard and self.with_track and not defer_tracking else None
             out = self._simple_test_once(img, img_meta, proposals, rescale, ref_img, inject, ref_feature, defer_tracking,
@@ -292,7 +298,7 @@ class PanopticFuseTrack(HipModule):
                 nimg, nref = prefetch
                 with torch.cuda.stream(self._pre):
                     nflow = self.flownet2.run(nimg, nref, self._mean_t, self._std_t, rws)
-                    nlevels, ncat = self._backbone_fpn_gather(nimg, rws)
+                    nlevels, ncat = self._backbone_fpn_gather(nimg, rws, ring=True)
                     ev = torch.cuda.Event()
                     ev.record(self._pre)
                 self._pf = dict(img=nimg, ref=nref, version=(nimg._version, nref._version), event=ev, flow=nflow, levels=nlevels, cat=ncat)
@@ -305,13 +311,12 @@ class PanopticFuseTrack(HipModule):
                 if pf is not None:
                     # an unused prefetch (the caller announced other tensors than it now passes): the prefetch stream may still be
                     # reading those tensors, which the caller is now free to rewrite on the main stream — so the main stream orders
-                    # itself behind it. Its results sit in a ring workspace nobody reads; the A/B alternation of the
-                    # main workspace's 'neck.cat' buffer is put back in step (the prefetch's gather flipped it).
+                    # itself behind it. Its results sit in a ring workspace nobody reads (ring slots have ONE gathered-
+                    # feature buffer each and leave the A/B alternation of the main workspace alone).
                     if main is not None:
                         main.wait_event(pf['event'])
                     else:
                         pf['event'].synchronize()
-                    self._flip ^= 1
                 # (1) flow ---------------------------------------------------------------------------------------------
                 if side is not None:
                     side.wait_stream(main)
@@ -457,10 +462,15 @@ class PanopticFuseTrack(HipModule):
         p = self._probe(ref_img)
         return p.shape == probe.shape and bool(torch.equal(p, probe))
 
-    def _backbone_fpn_gather(self, img, ws):
-        """ResNet + FPN + gather of one frame into the frame-alternating 'neck.cat' buffer -> (levels, cat)"""
-        self._flip ^= 1
-        tag = 'AB'[self._flip]
+    def _backbone_fpn_gather(self, img, ws, ring=False):
+        """ResNet + FPN + gather of one frame -> (levels, cat). In the main workspace the gathered feature alternates between the
+        'neck.catA' / 'neck.catB' buffers (frame t's is frame t+1's `ref_bsf`); a slot of the prefetch ring is rewritten every third
+        frame only and has ONE buffer (the A/B pair there was 0.4 GB of dead memory at 1024x2048: ADVICE r3)"""
+        if ring:
+            tag = 'R'
+        else:
+            self._flip ^= 1
+            tag = 'AB'[self._flip]
         pre = self._handoff
         if pre is not None and pre['img'] is img and pre['version'] == img._version:
             # clip sharding: this frame's ResNet+FPN+gather already ran for the hand-off to the next GPU (gathered_feature)

@@ -152,29 +152,38 @@ class RPNHead(HipModule):
         A = self.num_anchors
         nlv = len(levels)
         nms_pre = cfg.nms_pre
-        boxes = ws.get(tag + 'boxes', (nlv, nms_pre, 5), zero=True)
-        counts = []
+        # vps_rpn_collect walks every level's keep list in score order and cuts it at nms_post: equal to the reference (which cuts the
+        # nms() output of a level that was not top-k'ed in ascending anchor order) only when the cut never bites, and its LDS sort
+        # holds 8192 candidates: the shipped configs (1000 / 1000 / 1000) satisfy both
+        if not (cfg.nms_post >= nms_pre > 0 and nlv * min(cfg.nms_post, nms_pre) <= 8192):
+            raise hip.VpsHipError('RPNHead: test_cfg.rpn needs nms_post >= nms_pre > 0 and levels * nms_pre <= 8192 (got nms_pre=%d nms_post=%d, %d levels)'
+                                  % (nms_pre, cfg.nms_post, nlv))
+        boxes = ws.get(tag + 'boxes', (nlv, nms_pre, 5), zero=False)
+        cls_l, reg_l, counts = [], [], []
         for li, x in enumerate(levels):
             t = self._conv(x, ws=ws, name='%sconv%d' % (tag, li))
-            cls = self._cls(t, ws=ws, name='%scls%d' % (tag, li))
-            reg = self._reg(t, ws=ws, name='%sreg%d' % (tag, li))
-            scores = cls.t[..., :A].reshape(-1).sigmoid()
-            deltas = reg.t[..., :4 * A].reshape(-1, 4)
-            anchors = self._anchors(li, x.H, x.W, dev)
-            if nms_pre > 0 and scores.shape[0] > nms_pre:
-                scores, topk = scores.topk(nms_pre)
-                deltas = deltas[topk, :]; anchors = anchors[topk, :]
-            else:
-                # the reference hands unsorted boxes to nms(), which sorts them by score internally
-                scores, order = torch.sort(scores, descending=True, stable=True)
-                deltas = deltas[order, :]; anchors = anchors[order, :]
-            n = scores.shape[0]
-            deltas = deltas.contiguous(); anchors = anchors.contiguous(); scores = scores.contiguous()
-            hip.check(lib.vps_delta2bbox(hip.ptr(anchors), hip.ptr(deltas), hip.ptr(scores), hip.ptr(boxes[li]), n,
-                                         self.target_stds[0], self.target_stds[1], self.target_stds[2], self.target_stds[3],
-                                         float(img_shape[0]), float(img_shape[1]), hip.stream_ptr()), 'vps_delta2bbox')
-            counts.append(n)
-            self._keepalive = (deltas, anchors, scores)
+            cls_l.append(self._cls(t, ws=ws, name='%scls%d' % (tag, li)))
+            reg_l.append(self._reg(t, ws=ws, name='%sreg%d' % (tag, li)))
+            counts.append(min(x.H * x.W * A, nms_pre))
+        # rpn_head.py:62-91 for all levels in ONE launch (sigmoid, top nms_pre by score, gathers, delta2bbox): vps_rpn_select.
+        # Base anchors as the reference rounds them (anchor_generator.py:28-53), once per device
+        key = str(dev)
+        if self._anchor_cache.get('base') is None or self._anchor_cache['base'][0] != key:
+            base = torch.stack([gen_base_anchors(self.anchor_base_sizes[li], self.anchor_scales, self.anchor_ratios) for li in range(nlv)])
+            self._anchor_cache['base'] = (key, base.to(dev).contiguous())
+        base_d = self._anchor_cache['base'][1]
+        assert base_d.shape == (nlv, A, 4)
+        from ctypes import c_float, c_int32, c_void_p
+        cp = (c_void_p * nlv)(*[c.t.data_ptr() for c in cls_l]); cl = (c_int32 * nlv)(*[c.ld for c in cls_l])
+        rp = (c_void_p * nlv)(*[r.t.data_ptr() for r in reg_l]); rl = (c_int32 * nlv)(*[r.ld for r in reg_l])
+        for c, r in zip(cls_l, reg_l):
+            assert c.coff == 0 and r.coff == 0
+        Hs = (c_int32 * nlv)(*[x.H for x in levels]); Ws = (c_int32 * nlv)(*[x.W for x in levels])
+        st = (c_float * nlv)(*[float(v) for v in self.anchor_strides[:nlv]])
+        stds = (c_float * 4)(*[float(v) for v in self.target_stds])
+        assert all(float(v) == 0.0 for v in self.target_means)
+        hip.check(lib.vps_rpn_select(cp, cl, rp, rl, Hs, Ws, st, nlv, A, hip.ptr(base_d), nms_pre, stds, float(img_shape[0]), float(img_shape[1]),
+                                     hip.ptr(boxes), hip.stream_ptr()), 'vps_rpn_select')
         assert cfg.min_bbox_size == 0 and not cfg.nms_across_levels
         cb = (nms_pre + 63) // 64
         ck = (tuple(counts), str(dev))
