@@ -211,6 +211,7 @@ def main():
     ap.add_argument('--conv-table', default=None, help='write the per-layer-shape conv timing table of one frame here')
     ap.add_argument('--no-prefetch', action='store_true', help='do not enqueue the next frame behind the current one (A/B of the clip pipelining)')
     ap.add_argument('--single-stream', action='store_true', help='run every frame on one stream (for kernel traces whose durations add up)')
+    ap.add_argument('--png-workers', type=int, default=6, help='decode threads of the `from_png` leg (frames read from PNG files through vps_amd.pipeline.ClipFeeder)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -367,6 +368,82 @@ def main():
                           'the instance vectors after every frame; 1 mid-frame + 1 end-of-frame host read inside the detector')
         reset()
 
+    # ---- untimed: the same clip pipeline fed from PNG FILES: vps_amd.pipeline.ClipFeeder decodes with a pool of host
+    # threads ahead of the detector, uploads the uint8 frame through pinned memory and normalises / pads on the device -----------------
+    from_png = None
+    if rank == 0 and not args.no_extras and use_runner and world == 1:
+        import shutil
+        import tempfile
+        from PIL import Image
+        from vps_amd.pipeline import ClipFeeder, DeviceImagePrep
+        tmpd = tempfile.mkdtemp(prefix='vps_bench_png_')
+        try:
+            names = []
+            for i in range(8):
+                fr = synth.synth_frame(Hh, Ww, seed=i % 4, shift=(2 * i, i), noise=2.0).astype(np.uint8)       # BGR, camera-like noise
+                fn = os.path.join(tmpd, 'f%02d_city_newImg8bit.png' % i)
+                Image.fromarray(np.ascontiguousarray(fr[:, :, ::-1])).save(fn, compress_level=6)
+                names.append(fn)
+            prep = DeviceImagePrep(**cfg.img_norm_cfg, size_divisor=32, img_scale=(max(Hh, Ww), min(Hh, Ww)), device=dev)
+            nfr = 24
+            reset()
+            runner.run(ClipFeeder([names[t % 8] for t in range(4)], prep, workers=args.png_workers), 4, video_id=8)
+            reset()
+            feeder = ClipFeeder([names[t % 8] for t in range(nfr)], prep, workers=args.png_workers)
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            runner.run(feeder, nfr, video_id=9)
+            torch.cuda.synchronize()
+            c1 = time.perf_counter() - c0
+            feeder.close()
+            from_png = dict(frames=nfr, decode_processes=args.png_workers, frames_per_s=round(nfr / c1, 3), ms_per_frame=round(1e3 * c1 / nfr, 3),
+                            png_MB_per_frame=round(sum(os.path.getsize(f) for f in names) / 8e6, 2), decodes=feeder.decodes,
+                            note='ClipShardRunner.run(ClipFeeder(files, DeviceImagePrep)): PNG decode in %d host processes (every file once), 6 MB pinned upload, '
+                                 'Normalize + Pad + ImageToTensor on the device; the reference decodes and normalises both images of every pair on 2 workers' % args.png_workers)
+        finally:
+            shutil.rmtree(tmpd, ignore_errors=True)
+        reset()
+
+    # ---- untimed: inputs of the multi-GPU cost model (vps_amd.clip_shard.predict_clip_time) measured on this GPU, and its prediction for
+    # 2 / 4 / 8 GPUs - no RCCL run exists from this build (one GPU per box), so the first real one has something to be judged against
+    scaling_model = None
+    if rank == 0 and not args.no_extras and use_runner and world == 1:
+        from vps_amd.clip_shard import predict_clip_time
+
+        def timed(fn, n):
+            ts = []
+            for _ in range(n):
+                torch.cuda.synchronize()
+                c0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - c0)
+            return float(np.median(ts))
+        reset()
+        t_first = timed(lambda: (reset(), runner.run(load_frame, 1, video_id=11)), 3)          # a frame with nothing to hide its image-only stages behind
+        t_hand = timed(lambda: model.gathered_feature(load_frame(3)), 5)
+        model._handoff = None
+        reset()
+        plain_step(0, 12); plain_step(1, 12)
+        rec = dict(model._track_record)
+        t_assign = timed(lambda: model.track_assign(rec, False), 5)
+        reset()
+        feat_mb = 4.0 * (Hh // 4) * (Ww // 4) * model.extra_neck.in_channels / 1e6
+        t_xfer = feat_mb * 1e6 / 48e9                  # ASSUMED: one xGMI link at ~48 GB/s effective for a single p2p stream (153 GB/s raw)
+        t_frame = dt / total_frames
+        pred = {}
+        for nn in (1, 2, 4, 8):
+            c = predict_clip_time(30, nn, t_frame, t_first, t_hand, t_xfer, t_assign)
+            w = predict_clip_time(args.steps * nn, nn, t_frame, t_first, t_hand, t_xfer, t_assign)
+            pred[str(nn)] = dict(clip30_frames_per_s=round(c['frames_per_s'], 1), clip30_critical=c['critical'],
+                                 bench_weak_frames_per_s=round(w['frames_per_s'], 1))
+        scaling_model = dict(inputs_ms=dict(frame_steady=round(1e3 * t_frame, 3), frame_without_prefetch_partner=round(1e3 * t_first, 3),
+                                            handoff_resnet_fpn_gather=round(1e3 * t_hand, 3), handoff_transfer_assumed=round(1e3 * t_xfer, 3),
+                                            tracker_step_replay=round(1e3 * t_assign, 3)),
+                             handoff_MB=round(feat_mb, 1), predicted=pred,
+                             note='critical-path model of ClipShardRunner (vps_amd/clip_shard.py:predict_clip_time), NOT a measurement: no multi-GPU run exists '
+                                  'from this build. transfer time assumes ~48 GB/s for one point-to-point stream over one xGMI link')
+
     # ---- instrumented extra frame (outside the timed region): per-stage and per-conv-launch HIP events, ONE stream ---------------
     roof, stages, hbm = None, None, None
     if rank == 0:
@@ -475,6 +552,10 @@ def main():
             line['config']['experimental'] = 'VPS_S2_HALO=0: the phase-split stride-2 halo kernel switched off (A/B run, not the default configuration)'
         if plain is not None:
             line['test_vpq_loop'] = plain
+        if from_png is not None:
+            line['from_png'] = from_png
+        if scaling_model is not None:
+            line['scaling_model'] = scaling_model
         line['config']['host_reads_per_frame'] = '2 (the detection list after MaskROI: 8 KB; kept list + track ids + range report at the end: 2 KB)'
         line['f16_fallbacks'] = int(nhwc.F16_FALLBACKS[0])        # layers switched from f16x3 to bf16x6 by the fp16 range report (0 here)
         if clip30 is not None:

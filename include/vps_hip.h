@@ -320,14 +320,15 @@ int vps_panoptic_combine_dev(const float* fcn_score, int score_ld, int Hs, int W
  * single-workgroup kernels, so that a frame needs ONE mid-frame D2H (the detection list) and one at its end (kept list + ids).
  * -------------------------------------------------------------------------------------------- */
 /* ref: models/anchor_heads/rpn_head.py:62-91 (sigmoid objectness, `scores.topk(nms_pre)`, gathers) + core/anchor/anchor_generator.py:55-72
- * (grid anchors) + core/bbox/transforms.py:34-68 (delta2bbox, means 0, clipped to the image): ONE launch for all levels, one
- * workgroup per level. cls[l] / reg[l]: NHWC maps [H_l][W_l][ld] of level l (device pointers in host arrays; channels [0, A) /
- * [0, 4A) used), base_anchors: device [nlv][A][4] (the rounded base anchors of gen_base_anchors), strides / stds [4]: host arrays.
- * boxes [nlv][nms_pre][5]: the min(H_l*W_l*A, nms_pre) best positions of level l in DESCENDING score order (equal scores: ascending
- * position), rows beyond that count zeroed. nlv <= 8, nms_pre <= 8192. */
+ * (grid anchors) + core/bbox/transforms.py:34-68 (delta2bbox, means 0, clipped to the image) for ALL levels: one chip-wide scoring
+ * launch + one select / sort / decode launch with one workgroup per level. cls[l] / reg[l]: NHWC maps [H_l][W_l][ld] of level l
+ * (device pointers in host arrays; channels [0, A) / [0, 4A) used), base_anchors: device [nlv][A][4] (the rounded base anchors of
+ * gen_base_anchors), strides / stds [4]: host arrays. Scratch: keys [sum_l H_l*W_l*A] uint32, hist [nlv * 4096] int32 ZERO on entry
+ * (the launch leaves it zero). boxes [nlv][nms_pre][5]: the min(H_l*W_l*A, nms_pre) best positions of level l in DESCENDING score
+ * order (equal scores: ascending position), rows beyond that count zeroed. nlv <= 8, nms_pre <= 8192. */
 int vps_rpn_select(const float* const* cls, const int32_t* cls_ld, const float* const* reg, const int32_t* reg_ld,
                    const int32_t* Hs, const int32_t* Ws, const float* strides, int nlv, int A, const float* base_anchors,
-                   int nms_pre, const float* stds, float img_h, float img_w, float* boxes, void* stream);
+                   int nms_pre, const float* stds, float img_h, float img_w, uint32_t* keys, int32_t* hist, float* boxes, void* stream);
 
 /* ref: models/anchor_heads/rpn_head.py:94-104 (`mlvl_proposals` cat, `[:nms_post]` per level, top `max_num` by score).
  * boxes [nlv][nmax][5] per level in descending score order, keep [nlv][nmax] / nkeep [nlv] as written by vps_nms_batched.

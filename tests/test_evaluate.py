@@ -176,3 +176,38 @@ def test_eval_vpq_command_line_on_the_device(dev, tmp_path):
     exp = _expected_vpq(sets)
     for k in exp:
         assert abs(got[k] - exp[k]) < 1e-9, (k, got[k], exp[k])
+
+
+def test_pq_average_viper_variant_excludes_mobilebarrier():
+    """tools/dataset/viper.py:64-90 (PQStat.pq_average with `if label == 11: continue`) against vps_amd's `exclude=`: the REAL
+    class, imported under the golden generator's shims when /root/reference is there, else the restated expectation"""
+    import os
+    from vps_amd import evaluate as ev
+    from vps_amd.postprocess import DATASETS
+    cats = {c: {'isthing': 1 if c >= 13 else 0} for c in range(23)}
+    stat = ev.PQStat()
+    rng = np.random.default_rng(3)
+    vals = {}
+    for c in (2, 5, 11, 13, 17, 22):
+        tp, fp, fn = int(rng.integers(1, 9)), int(rng.integers(0, 5)), int(rng.integers(0, 5))
+        iou = float(rng.uniform(0.5, 1.0)) * tp
+        stat[c].tp, stat[c].fp, stat[c].fn, stat[c].iou = tp, fp, fn, iou
+        vals[c] = (tp, fp, fn, iou)
+    got, per = stat.pq_average(cats, None, exclude=DATASETS['viper']['pq_exclude'])
+    assert 11 not in per and got['n'] == 5
+    want = np.mean([vals[c][3] / (vals[c][0] + 0.5 * vals[c][1] + 0.5 * vals[c][2]) for c in (2, 5, 13, 17, 22)])
+    assert abs(got['pq'] - want) < 1e-12
+    full, _ = stat.pq_average(cats, None)
+    assert full['n'] == 6
+    if os.path.isdir('/root/reference/tools/dataset'):
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+        import make_unify_golden as mg
+        mg.load_reference_function('tools.dataset.viper', 23, 11)
+        ref_mod = sys.modules['tools.dataset.viper']
+        rs = ref_mod.PQStat()
+        for c, (tp, fp, fn, iou) in vals.items():
+            rs[c].tp, rs[c].fp, rs[c].fn, rs[c].iou = tp, fp, fn, iou
+        ref, ref_per = rs.pq_average(cats, None)
+        assert ref['n'] == got['n'] and ref['pq'] == got['pq'] and ref['sq'] == got['sq'] and ref['rq'] == got['rq']
+        assert set(ref_per) == set(per)

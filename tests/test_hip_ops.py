@@ -533,7 +533,8 @@ def test_rpn_select_matches_topk_gather_decode(dev, quant):
     shapes = [(96, 160), (40, 72), (16, 18)]
     strides = [4., 8., 16.]
     nlv = len(shapes)
-    base = torch.stack([HD.gen_base_anchors(int(s), (8, 16, 32), (0.5, 1.0, 2.0)) for s in strides]).to(dev).contiguous()
+    base = torch.stack([HD.gen_base_anchors(int(s), (8,), (0.5, 1.0, 2.0)) for s in strides]).to(dev).contiguous()      # [nlv, A = 3, 4]
+    assert base.shape == (nlv, A, 4)
     cls_t, reg_t = [], []
     for li, (H, W) in enumerate(shapes):
         c = _rand(H, W, 4, seed=10 + li, scale=2.0)
@@ -547,9 +548,13 @@ def test_rpn_select_matches_topk_gather_decode(dev, quant):
     rp = (c_void_p * nlv)(*[r.data_ptr() for r in reg_t]); rl = (c_int32 * nlv)(*[12] * nlv)
     Hs = (c_int32 * nlv)(*[h for h, _ in shapes]); Ws = (c_int32 * nlv)(*[w for _, w in shapes])
     st = (c_float * nlv)(*strides); stds = (c_float * 4)(1., 1., 1., 1.)
-    hip.check(lib.vps_rpn_select(cp, cl, rp, rl, Hs, Ws, st, nlv, A, hip.ptr(base), nms_pre, stds, 384., 640., hip.ptr(boxes),
-                                 hip.stream_ptr()), 'vps_rpn_select')
+    keys = torch.empty(sum(h * w * A for h, w in shapes), dtype=torch.int32, device=dev)
+    hist = torch.zeros(nlv * 4096, dtype=torch.int32, device=dev)
+    for _ in range(2):          # twice: the launch must leave its histogram scratch zero
+        hip.check(lib.vps_rpn_select(cp, cl, rp, rl, Hs, Ws, st, nlv, A, hip.ptr(base), nms_pre, stds, 384., 640., hip.ptr(keys), hip.ptr(hist),
+                                     hip.ptr(boxes), hip.stream_ptr()), 'vps_rpn_select')
     torch.cuda.synchronize()
+    assert int(hist.abs().sum()) == 0
     for li, (H, W) in enumerate(shapes):
         scores = cls_t[li][..., :A].reshape(-1).sigmoid()
         deltas = reg_t[li][..., :4 * A].reshape(-1, 4)

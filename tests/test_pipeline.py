@@ -105,3 +105,48 @@ def test_imread_and_load_ref_image_decode_every_file_once(tmp_path):
     assert load.decodes == 4                                                                # the reference decodes 8 times here
     with pytest.raises(NotImplementedError):
         load(dict(img_prefix='.', ref_prefix='.', img_info=dict(filename='x.png', id=1)))
+
+
+@pytest.mark.parametrize('mode', [True, False], ids=['processes', 'threads'])
+def test_clip_feeder_decodes_every_file_once_and_keeps_tensor_identity(tmp_path, mode):
+    """vps_amd.pipeline.ClipFeeder (the product's `load_frame` for clips on disk) with a host-side stand-in for DeviceImagePrep:
+    files decoded once by the thread pool, the SAME tensor object for frame t as `img` and as frame t+1's reference, old frames
+    dropped, a shard that starts mid-clip served, decoded pixels == imread"""
+    from PIL import Image
+    from vps_amd.pipeline import ClipFeeder, imread
+
+    class HostPrep:
+        device = torch.device('cpu')
+        calls = 0
+
+        def prep(self, img):
+            HostPrep.calls += 1
+            t = torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float()
+            return t, tuple(img.shape), tuple(img.shape), 1.0
+
+    rng = np.random.RandomState(0)
+    files = []
+    for i in range(7):
+        a = rng.randint(0, 255, (12, 20, 3)).astype(np.uint8)
+        fn = str(tmp_path / ('f%02d.png' % i))
+        Image.fromarray(a).save(fn)
+        files.append(fn)
+    fd = ClipFeeder(files, HostPrep(), workers=3, processes=mode)
+    assert len(fd) == 7
+    prev = None
+    for t in range(7):
+        img = fd(t)
+        assert img.shape == (1, 3, 12, 20)
+        assert fd(t) is img                                   # asked twice (as img, then as the next frame's reference): one object
+        if prev is not None:
+            assert fd(t - 1) is prev                          # frame t-1 is still there while frame t is current
+        assert torch.equal(img[0], torch.from_numpy(np.ascontiguousarray(imread(files[t]))).permute(2, 0, 1).float())
+        prev = img
+        assert set(fd._ready) <= {t - 1, t}
+    assert fd.decodes == 7 and HostPrep.calls == 7
+    fd.close()
+    fd2 = ClipFeeder(files, HostPrep(), workers=2, processes=mode)
+    x4 = fd2(4); x3 = fd2(3)                                  # a shard that starts at frame 4 loads its reference frame 3 afterwards
+    assert torch.equal(x3[0], torch.from_numpy(np.ascontiguousarray(imread(files[3]))).permute(2, 0, 1).float())
+    assert fd2(4) is x4 and fd2(5).shape == (1, 3, 12, 20)
+    fd2.close()

@@ -10,10 +10,13 @@ import torch
 from oracle import postprocess as opp
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'unify_cases.npz')
+# the same cases through the REAL tools/dataset/viper.py:661-727 (23 segmentation classes, 11 of them things: id_last_stuff 12)
+GOLD_VIPER = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'unify_cases_viper.npz')
+DATASETS = [('cityscapes_vps', GOLD, 19, 9), ('viper', GOLD_VIPER, 23, 11)]
 
 
-def _clips():
-    z = np.load(GOLD)
+def _clips(gold=GOLD):
+    z = np.load(gold)
     for ci in range(int(z['nclips'])):
         n = int(z['clip%d_n' % ci]); with_obj = bool(z['clip%d_with_obj' % ci])
         segs = [z['clip%d_f%d_seg' % (ci, f)] for f in range(n)]
@@ -24,10 +27,12 @@ def _clips():
         yield ci, segs, pans, clss, objs, int(z['clip%d_limit' % ci]), ['f%d' % f for f in range(n)], outs
 
 
-def test_oracle_matches_reference_function_bit_for_bit():
+@pytest.mark.parametrize('name,gold,nseg,ncls', DATASETS, ids=[d[0] for d in DATASETS])
+def test_oracle_matches_reference_function_bit_for_bit(name, gold, nseg, ncls):
+    assert int(np.load(gold)['id_last_stuff']) == nseg - ncls
     ncase = 0
-    for ci, segs, pans, clss, objs, limit, names, outs in _clips():
-        res = opp.get_unified_pan_result(segs, pans, clss, objs, limit, names)
+    for ci, segs, pans, clss, objs, limit, names, outs in _clips(gold):
+        res = opp.get_unified_pan_result(segs, pans, clss, objs, limit, names, id_last_stuff=nseg - ncls)
         for n, o in zip(names, outs):
             assert res[n].dtype == np.uint8 and res[n].shape == o.shape
             assert np.array_equal(res[n], o), 'clip %d frame %s differs in %d pixels' % (ci, n, int((res[n] != o).any(-1).sum()))
@@ -53,10 +58,12 @@ def test_host_dedup_equals_the_reference_statements():
 
 
 @pytest.mark.gpu
-def test_device_unify_matches_reference_golden(dev):
+@pytest.mark.parametrize('name,gold,nseg,ncls', DATASETS, ids=[d[0] for d in DATASETS])
+def test_device_unify_matches_reference_golden(dev, name, gold, nseg, ncls):
     from vps_amd import postprocess as pp
-    for ci, segs, pans, clss, objs, limit, names, outs in _clips():
-        u = pp.PanopticUnifier(dev)
+    assert pp.DATASETS[name]['num_seg_classes'] == nseg and pp.DATASETS[name]['num_classes'] == ncls
+    for ci, segs, pans, clss, objs, limit, names, outs in _clips(gold):
+        u = pp.PanopticUnifier(dev, **{k: pp.DATASETS[name][k] for k in ('num_seg_classes', 'num_classes')})
         res = u.get_unified_pan_result([torch.from_numpy(s).to(dev) for s in segs], [torch.from_numpy(p).to(dev) for p in pans],
                                        clss, objs, limit, names)
         for n, o in zip(names, outs):

@@ -32,7 +32,7 @@ import run_vps_synthetic as RV   # noqa: E402
 def run(tag, prec, args, dev, separated, splitk=None, streams=True):
     import vps_amd.detector as D
     from vps_amd import nhwc
-    old_t, old_o = nhwc.SPLITK_TARGET_BLOCKS, D.PanopticFuseTrack.overlap_streams
+    old_t = nhwc.SPLITK_TARGET_BLOCKS
     try:
         if splitk is not None:
             nhwc.SPLITK_TARGET_BLOCKS = splitk

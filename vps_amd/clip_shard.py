@@ -136,6 +136,10 @@ class ClipShardRunner:
                 recv_buf = be.ref_feature_buffer(load_frame(s))
                 ops.append(dist.P2POp(dist.irecv, recv_buf, rank - 1))
             reqs = self._post(ops) if ops else []
+            if rank > 0 and hasattr(be, 'prime'):
+                # the shard's first frame has no predecessor on this rank whose call could announce it: its image-only stages are
+                # enqueued now, beside the hand-off, not behind the wait for it
+                be.prime(load_frame(s), load_frame(s - 1))
         # 2) rank 0 posts the receives of every other rank's records + maps: per peer in the order of its sends (frame order), and
         # across peers by position in the shard, not peer by peer — the ranks finish their j-th frames at about the same time, and on
         # RCCL the point-to-point operations of a rank run in posting order on one communicator stream: posted peer by peer, the
@@ -270,6 +274,10 @@ class DetectorBackend:
             rec['ids'] = self.det._aux['det']['det_obj_ids']        # assigned inside the call (read with its end-of-frame read)
         return rec
 
+    def prime(self, img, ref_img):
+        if self.prefetch:
+            self.det.prime(img, ref_img)
+
     def assign(self, rec, is_first):
         if 'ids' in rec:
             return rec['ids']
@@ -282,3 +290,45 @@ class DetectorBackend:
         out['panoptic_det_obj_ids'] = np.asarray(ids)[np.asarray(keep)]
         out['t'] = rec['t']
         return out
+
+
+def predict_clip_time(nframes, world, t_frame, t_first, t_handoff, t_xfer, t_assign, primed=True):
+    """Critical-path estimate of `ClipShardRunner.run` on `world` GPUs from single-GPU stage times (seconds): a prediction to judge
+    the first real multi-GPU run against (no such run exists from this build: one GPU per box). Per rank r with n_r frames:
+
+        sender part    t_handoff   ResNet + FPN + gather of the shard's LAST frame, first thing on every rank but the last (its
+                                   levels are reused by that frame's own call, so only the early start costs: it delays frame 0)
+        wait           the shard's first neck needs the previous rank's feature: it arrives at t_handoff + t_xfer; the first
+                       frame's image-only stages run meanwhile when `primed` (DetectorBackend.prime), else behind the wait
+        frames         t_first (a frame whose image-only stages had no frame to hide behind) + (n_r - 1) * t_frame
+        rank 0         after its own shard, one tracker step (t_assign) per remote frame, each as soon as the record is in
+
+    -> dict(seconds, frames_per_s, per_rank_finish, critical). t_first - t_frame is what the pipelining hides in steady state."""
+    parts = partition(nframes, world)
+    n = [b - a for a, b in parts]
+    fin = []
+    for r in range(world):
+        if n[r] == 0:
+            fin.append(0.0)
+            continue
+        sends = r < world - 1 and n[r + 1] > 0
+        start = t_handoff if sends else 0.0                   # this rank's own hand-off work comes first on its streams
+        if r > 0:
+            arrive = t_handoff + t_xfer                         # every sender starts at 0: all hand-offs arrive at about the same time
+            image_only = max(t_first - t_frame, 0.0) + 0.7 * t_frame     # share of a frame that needs the images alone (~16 of 22 ms)
+            if primed:
+                first_done = max(start + image_only, arrive) + (t_first - image_only)
+            else:
+                first_done = max(start, arrive) + t_first
+        else:
+            first_done = start + t_first
+        fin.append(first_done + (n[r] - 1) * t_frame)
+    # rank 0 replays the remote frames in clip order: frame j of rank r is available when that rank has finished it
+    t = fin[0]
+    for r in range(1, world):
+        for j in range(n[r]):
+            avail = fin[r] - (n[r] - 1 - j) * t_frame
+            t = max(t, avail) + t_assign
+    total = max(t, max(fin))
+    return dict(seconds=total, frames_per_s=nframes / total, per_rank_finish=[round(x, 5) for x in fin],
+                critical='rank 0 replay' if t >= max(fin) else 'rank %d compute' % int(np.argmax(fin)))

@@ -217,7 +217,7 @@ __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&a
                         v[e] = vps_act(t, d.act, d.slope);
                         if constexpr (GN) { gs += v[e]; gq += v[e] * v[e]; }
                     }
-                    if (d.gn_rep != -77) *reinterpret_cast<f32x4*>(d.out + opix[a] * d.out_ld + d.out_coff + co) = v;   // EXPERIMENT knock-out
+                    *reinterpret_cast<f32x4*>(d.out + opix[a] * d.out_ld + d.out_coff + co) = v;
                 }
                 if constexpr (GN) {
                     // this lane's <= TM * 4 values belong to ONE group (4 | gn_cpg): channels co .. co+3 of group co / gn_cpg. The 32 lanes

@@ -942,7 +942,7 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int p = 0; p < SM::NLB; ++p) load_B(0, m, p);
+        for (int p = 0; p < NSB; ++p) load_B(0, m, p);
 #pragma unroll
     for (int i = 0; i < NLD; ++i) store_A(i, 0);
     load_A();
@@ -959,7 +959,7 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
             const int step = chunk * NTAP + tp;
             const int bstep = min(step + 1, nsteps - 1);        // weights of the next step (clamped: the last prefetch is unused)
             const int toff = (tp / KW) * HW + (tp % KW);
-            constexpr int NLB = SM::NLB;                        // weight planes loaded; the others are derived in registers
+            constexpr int NLB = NSB;                            // all packed planes loaded (deriving the third one measured slower here: 512->512 3x3 @64x128 0.475 -> 0.545 ms)
             x8 bcur[2][NSB][TN];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -1044,7 +1044,9 @@ void conv_mfma_h8_kernel(const vps_conv_desc d, const int tiles_m, const int til
     constexpr int NSA = SM::NSA, NSB = SM::NSB;
     constexpr int PLANE = NLD * 64 * LDS_LDH;           // 16-bit elements of one plane of one activation buffer
     constexpr int ABUF = NSA * PLANE;
-    constexpr int NLB = SM::NLB;                        // weight planes loaded and staged; the others are derived in registers
+    // all packed planes are loaded and staged: deriving the f16x3 mode's third plane in registers (derive_weight_plane) saves a third
+    // of the weight traffic but measured slower here (256->256 3x3 @256x512: 2.81 -> 2.88 ms; the tap loop is not short of load slots)
+    constexpr int NLB = NSB;
     constexpr int NFRAG = NLB * 2 * (BN / 32);          // 1 KB weight fragments of one tap of the block tile
     constexpr int BBUF = NFRAG * 512;
     static_assert((NFRAG * 64) % 512 == 0, "whole 16-byte chunks per thread");
@@ -1281,7 +1283,7 @@ void conv_mfma_h8s2_kernel(const vps_conv_desc d, const int tiles_m, const int t
     constexpr int NSA = SM::NSA, NSB = SM::NSB;
     constexpr int PLANE = NLD * 64 * LDS_LDH;
     constexpr int ABUF = NSA * PLANE;
-    constexpr int NLB = SM::NLB;                        // weight planes loaded and staged; the others are derived in registers
+    constexpr int NLB = NSB;                            // all packed planes loaded (see the stride-1 kernel above)
     constexpr int NFRAG = NLB * 2 * (BN / 32);
     constexpr int NBL = (NFRAG * 64 + 511) / 512;       // 16-byte weight chunks per thread
     constexpr bool WHOLE = (NFRAG * 64) % 512 == 0;

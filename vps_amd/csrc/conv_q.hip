@@ -55,7 +55,6 @@ void conv_mfma_bf16q_kernel(const vps_conv_desc d, const int M, const int tiles_
     const int k4 = t & 7;      // 4-channel group of the 32-wide k-step staged by this thread (8 lanes = one 128-byte line)
     const int r0 = t >> 3;     // rows r0 + 32 i of the tile
 
-    const int ko = d.gn_cpg;      // EXPERIMENT knock-out mask
     const int kstep0 = split * ksteps_per_split;
     int nsteps = d.kpad / BK - kstep0;
     if (nsteps > ksteps_per_split) nsteps = ksteps_per_split;
@@ -230,7 +229,7 @@ void conv_mfma_bf16q_kernel(const vps_conv_desc d, const int M, const int tiles_
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b) if (!(ko & 16)) acc[a][b] = split_mfma<MODE>(bf[SM::PB[q]][b], af[0][SM::PA[q]][a], acc[a][b]);
+                for (int b = 0; b < TN; ++b) acc[a][b] = split_mfma<MODE>(bf[SM::PB[q]][b], af[0][SM::PA[q]][a], acc[a][b]);
             bool last_use = SM::PB[q] < NLB;               // derived planes are not refilled
 #pragma unroll
             for (int q2 = q + 1; q2 < NT; ++q2) last_use = last_use && SM::PB[q2] != SM::PB[q];
@@ -249,15 +248,15 @@ void conv_mfma_bf16q_kernel(const vps_conv_desc d, const int M, const int tiles_
         // ---- slab 1: MFMAs with the step's non-MFMA work between them (program order pinned): stage tile step+1 (activations, then
         // weights), then request W(step+2) and A(step+3)
         auto work = [&](const int w) {
-            if (w < 4) { if (!(ko & 32)) store_A(w, cur ^ 1, slot); }
+            if (w < 4) store_A(w, cur ^ 1, slot);
             else if (w == 4) {
 #pragma unroll
                 for (int j = 0; j < (NBL + 1) / 2; ++j) store_B(j, cur ^ 1);
             } else if (w == 5) {
 #pragma unroll
                 for (int j = (NBL + 1) / 2; j < NBL; ++j) store_B(j, cur ^ 1);
-            } else if (w == 6) { if (!(ko & 4)) load_B(step + 2); }
-            else { if (!(ko & 8)) load_A(slot); }
+            } else if (w == 6) load_B(step + 2);
+            else load_A(slot);
         };
         int mf = 0;
 #pragma unroll
@@ -267,7 +266,7 @@ void conv_mfma_bf16q_kernel(const vps_conv_desc d, const int M, const int tiles_
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
-                    if (!(ko & 16)) acc[a][b] = split_mfma<MODE>(bf[SM::PB[q]][b], af[1][SM::PA[q]][a], acc[a][b]);
+                    acc[a][b] = split_mfma<MODE>(bf[SM::PB[q]][b], af[1][SM::PA[q]][a], acc[a][b]);
                     ++mf;
 #pragma unroll
                     for (int w = 0; w < NW; ++w) {
@@ -302,15 +301,12 @@ void conv_mfma_bf16q_kernel(const vps_conv_desc d, const int M, const int tiles_
 // -> 1 if a uniform-lead instance exists for this launch and was enqueued, 0 if the caller has to use another kernel
 __attribute__((visibility("hidden")))
 int vpsi_launch_conv_q(const vps_conv_desc& d_in, int M, int tiles_m, int tiles_n, int per_split, long nblk, bool tapmajor, hipStream_t s) {
-    vps_conv_desc d = d_in;
-    const int q_mode = getenv("VPS_UNIFORM_LEAD") ? atoi(getenv("VPS_UNIFORM_LEAD")) : 3;     // EXPERIMENT: read per launch
+    const vps_conv_desc& d = d_in;
+    // VPS_UNIFORM_LEAD in the environment (A/B runs): bit 0 = chunk-major layers (default on), bit 1 = tap-major layers (default off:
+    // the thin first layers measured 12 .. 23 % slower here than on the pipelined kernel - 3 .. 7 k-steps per tile, the longer prologue
+    // is not paid back)
+    static const int q_mode = getenv("VPS_UNIFORM_LEAD") ? atoi(getenv("VPS_UNIFORM_LEAD")) : 1;
     if (!(q_mode & (tapmajor ? 2 : 1))) return 0;
-    if (const char* ko = getenv("VPS_KO")) {       // EXPERIMENT knock-outs: 1 = no residual, 2 = no stores
-        const int k = atoi(ko);
-        if (k & 1) d.res = nullptr;
-        if (k & 2) d.gn_rep = -77;
-        d.gn_cpg = k;
-    }
     if (d.offset || !(d.prec == VPS_PREC_F16X3 || d.prec == VPS_PREC_BF16X3 || d.prec == VPS_PREC_BF16)) return 0;
     if (d.tile_n != 128 && d.tile_n != 64) return 0;
     // VPS_DEBUG_OCC=1: resident blocks per CU of the two f16x3 instances, once, on stderr (80 KB of LDS per block: two blocks need all 160 KB)

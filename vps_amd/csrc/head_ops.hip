@@ -88,40 +88,62 @@ void rpn_collect_kernel(const float* __restrict__ boxes, const int* __restrict__
 // ------------------------------------------------------------------------------------------------
 // RPN, per level (rpn_head.py:62-91 + core/bbox/transforms.py:34-68): objectness = sigmoid(rpn_cls) over the (h, w, anchor)
 // positions, the nms_pre best by score (torch.topk; a level with <= nms_pre positions keeps all of them and nms() sorts them:
-// the same descending list), their anchors + deltas -> delta2bbox -> [count][5] boxes in descending score order. ONE workgroup
-// per level (grid = levels), everything a host loop of torch kernels did before (sigmoid, topk, three gathers, decode):
-//   1. radix select of the count-th largest key (key = bits of the fp32 score, all positive: unsigned order = float order) on
-//      4096 / 1024 / 1024-bin LDS histograms, stopping as soon as everything at or above the threshold bin fits the sort buffer;
-//   2. those candidates -> 64-bit keys (score bits | ~index) -> bitonic sort, descending: equal scores in ascending index order
-//      (what a stable descending sort gives; the reference's own order among exactly equal scores is torch.topk's, unspecified);
-//   3. the first `count` are decoded (anchor = rounded base anchor + stride * (x, y), generated on the fly).
-// The score map is read 2 (typical) .. 4 times by one CU: it is <= 2 MB and stays in the XCD's L2.
+// the same descending list), their anchors + deltas -> delta2bbox -> [count][5] boxes in descending score order. Two launches
+// for ALL levels instead of a host loop of torch kernels per level (sigmoid, topk, three gathers, decode):
+//   rpn_score_kernel (the whole chip: the 0.5 M exponentials are the expensive part): key = bits of the fp32 score (all positive:
+//      unsigned order = float order) of every position -> scratch, and a 4096-bin histogram of the keys' top 12 bits per level
+//      (LDS-private per block, non-empty bins added to the level's global histogram);
+//   rpn_select_kernel (one workgroup per level): radix select of the count-th largest key - the first level of the search reads
+//      the global histogram, further 10-bit levels re-scan the level's keys, stopping as soon as everything at or above the
+//      threshold bin fits the sort buffer; those candidates -> 64-bit keys (score bits | ~index) -> bitonic sort, descending: equal
+//      scores in ascending index order (a stable descending sort; the reference's own order among exactly equal scores is
+//      torch.topk's, unspecified); the first `count` are decoded (anchor = rounded base anchor + stride * (x, y), made on the fly).
 // ------------------------------------------------------------------------------------------------
 struct RpnLevels {
     const float* cls[8];
     const float* reg[8];
     int cls_ld[8], reg_ld[8], H[8], W[8];
+    int koff[8];                // first key of the level in the scratch array
     float stride[8];
 };
+constexpr int RPN_BINS = 4096;
 
-__device__ __forceinline__ unsigned rpn_key(const float* __restrict__ cls, const int ld, const int A, const int i) {
-    const int pos = i / A, a = i - pos * A;
-    const float x = cls[(size_t)pos * ld + a];
-    const float s = 1.f / (1.f + expf(-x));          // at::sigmoid on the device: 1 / (1 + exp(-x)) in fp32
-    return __float_as_uint(s);
+__global__ __launch_bounds__(256)
+void rpn_score_kernel(const RpnLevels L, const int A, unsigned* __restrict__ keys, int* __restrict__ hist) {
+    __shared__ int h[RPN_BINS];
+    const int l = blockIdx.y;
+    const int npos = L.H[l] * L.W[l];
+    if ((int)blockIdx.x * 256 >= npos) return;
+    for (int b = threadIdx.x; b < RPN_BINS; b += 256) h[b] = 0;
+    __syncthreads();
+    const float* __restrict__ cls = L.cls[l];
+    const int ld = L.cls_ld[l];
+    unsigned* __restrict__ kl = keys + L.koff[l];
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npos; p += gridDim.x * 256) {
+        const float* row = cls + (size_t)p * ld;
+        for (int a = 0; a < A; ++a) {
+            const float s = 1.f / (1.f + expf(-row[a]));          // at::sigmoid on the device: 1 / (1 + exp(-x)) in fp32
+            const unsigned k = __float_as_uint(s);
+            kl[(size_t)p * A + a] = k;
+            atomicAdd(&h[k >> 20], 1);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < RPN_BINS; b += 256)
+        if (h[b]) atomicAdd(&hist[l * RPN_BINS + b], h[b]);
 }
 
 __global__ __launch_bounds__(1024)
 void rpn_select_kernel(const RpnLevels L, const int A, const float* __restrict__ base_anchors, const int nms_pre, const float sx,
                        const float sy, const float sw, const float sh, const float img_h, const float img_w, const float max_ratio,
-                       float* __restrict__ boxes) {
+                       const unsigned* __restrict__ keys_all, int* __restrict__ hist_all, float* __restrict__ boxes) {
     __shared__ u64 keys[SORT_CAP];
-    __shared__ int hist[4096];
+    __shared__ int hist[RPN_BINS];
     __shared__ int scan[1024];
     __shared__ int sh_bin, sh_above, sh_cnt;
     const int l = blockIdx.x, t = threadIdx.x;
-    const float* __restrict__ cls = L.cls[l];
-    const int ld = L.cls_ld[l], n = L.H[l] * L.W[l] * A;
+    const int n = L.H[l] * L.W[l] * A;
+    const unsigned* __restrict__ kin = keys_all + L.koff[l];
     const int count = min(n, nms_pre);
     float* __restrict__ out = boxes + (size_t)l * nms_pre * 5;
 
@@ -129,18 +151,25 @@ void rpn_select_kernel(const RpnLevels L, const int A, const float* __restrict__
     unsigned prefix = 0;
     int shift = 20, nbits = 12, above = 0;
     bool exact = false;          // the threshold key is known exactly (shift == 0 reached)
-    if (n > SORT_CAP || n > count) {
+    bool first = true;
+    // the level's global histogram is consumed here and left zero for the next launch
+    for (int b = t; b < RPN_BINS; b += 1024) { hist[b] = hist_all[l * RPN_BINS + b]; hist_all[l * RPN_BINS + b] = 0; }
+    __syncthreads();
+    if (n > count) {
         for (;;) {
             const int nbin = 1 << nbits;
-            for (int b = t; b < nbin; b += 1024) hist[b] = 0;
-            __syncthreads();
-            const int hs = shift + nbits;                  // bits >= hs are decided
-            for (int i = t; i < n; i += 1024) {
-                const unsigned k = rpn_key(cls, ld, A, i);
-                if (hs >= 32 || (k >> hs) == (prefix >> hs)) atomicAdd(&hist[(k >> shift) & (nbin - 1)], 1);
+            if (!first) {
+                for (int b = t; b < nbin; b += 1024) hist[b] = 0;
+                __syncthreads();
+                const int hs = shift + nbits;                  // bits >= hs are decided
+                for (int i = t; i < n; i += 1024) {
+                    const unsigned k = kin[i];
+                    if ((k >> hs) == (prefix >> hs)) atomicAdd(&hist[(k >> shift) & (nbin - 1)], 1);
+                }
+                __syncthreads();
             }
-            __syncthreads();
-            // bins from the top: thread t owns bins [nbin - 1 - 4t - 3, nbin - 1 - 4t] (nbin / 1024 of them: 4 or 1)
+            first = false;
+            // bins from the top: thread t owns `per` consecutive bins (4 or 1)
             const int per = nbin >> 10;
             int own = 0;
             for (int e = 0; e < per; ++e) own += hist[nbin - 1 - (t * per + e)];
@@ -168,7 +197,9 @@ void rpn_select_kernel(const RpnLevels L, const int A, const float* __restrict__
             prefix |= (unsigned)bin << shift;
             __syncthreads();
             if (shift == 0) { exact = true; break; }
-            if (above + pop <= SORT_CAP) break;            // everything from this bin upwards fits the sort buffer
+            // stop when everything from this bin upwards is a short list to sort (a re-scan of the level's keys costs ~15 us for the
+            // largest level, a bitonic pass over 8192 instead of 2048 keys more than that)
+            if (above + pop <= min(SORT_CAP, max(2 * nms_pre, 2048))) break;
             shift -= 10; nbits = 10;
         }
     } else {
@@ -181,10 +212,9 @@ void rpn_select_kernel(const RpnLevels L, const int A, const float* __restrict__
     if (t == 0) sh_cnt = 0;
     __syncthreads();
     const unsigned lo = shift >= 32 ? 0u : (prefix >> shift) << shift;
-    int room_eq = SORT_CAP;                                // ties that still fit
-    if (exact) room_eq = count - above;
+    const int room_eq = exact ? count - above : SORT_CAP;  // ties that are taken
     for (int i = t; i < n; i += 1024) {
-        const unsigned k = rpn_key(cls, ld, A, i);
+        const unsigned k = kin[i];
         if (exact ? k > lo : k >= lo) {
             const int slot = atomicAdd(&sh_cnt, 1);
             keys[slot] = ((u64)k << 32) | (u64)(0xFFFFFFFFu - (unsigned)i);
@@ -196,7 +226,7 @@ void rpn_select_kernel(const RpnLevels L, const int A, const float* __restrict__
         const int base0 = sh_cnt;
         for (int c0 = 0; c0 < n && taken < room_eq; c0 += 1024) {
             const int i = c0 + t;
-            const unsigned k = i < n ? rpn_key(cls, ld, A, i) : 0u;
+            const unsigned k = i < n ? kin[i] : 0u;
             const int f = (i < n && k == lo) ? 1 : 0;
             scan[t] = f;
             __syncthreads();
@@ -494,17 +524,26 @@ extern "C" int vps_rpn_collect(const float* boxes, const int32_t* keep, const in
 
 extern "C" int vps_rpn_select(const float* const* cls, const int32_t* cls_ld, const float* const* reg, const int32_t* reg_ld,
                               const int32_t* Hs, const int32_t* Ws, const float* strides, int nlv, int A, const float* base_anchors,
-                              int nms_pre, const float* stds, float img_h, float img_w, float* boxes, void* stream) {
-    if (!cls || !cls_ld || !reg || !reg_ld || !Hs || !Ws || !strides || !base_anchors || !stds || !boxes) return VPS_EARG(1);
+                              int nms_pre, const float* stds, float img_h, float img_w, uint32_t* keys, int32_t* hist, float* boxes,
+                              void* stream) {
+    if (!cls || !cls_ld || !reg || !reg_ld || !Hs || !Ws || !strides || !base_anchors || !stds || !keys || !hist || !boxes) return VPS_EARG(1);
     if (nlv < 1 || nlv > 8 || A < 1 || nms_pre < 1 || nms_pre > SORT_CAP) return VPS_EARG(2);
     RpnLevels L;
+    long off = 0, maxpos = 0;
     for (int l = 0; l < nlv; ++l) {
-        if (!cls[l] || !reg[l] || Hs[l] < 1 || Ws[l] < 1 || cls_ld[l] < A || reg_ld[l] < 4 * A || (long)Hs[l] * Ws[l] * A > 0x7fffffffL) return VPS_EARG(3);
+        if (!cls[l] || !reg[l] || Hs[l] < 1 || Ws[l] < 1 || cls_ld[l] < A || reg_ld[l] < 4 * A) return VPS_EARG(3);
         L.cls[l] = cls[l]; L.reg[l] = reg[l]; L.cls_ld[l] = cls_ld[l]; L.reg_ld[l] = reg_ld[l]; L.H[l] = Hs[l]; L.W[l] = Ws[l]; L.stride[l] = strides[l];
+        L.koff[l] = (int)off;
+        off += (long)Hs[l] * Ws[l] * A;
+        if (off > 0x7fffffffL) return VPS_EARG(3);
+        if ((long)Hs[l] * Ws[l] > maxpos) maxpos = (long)Hs[l] * Ws[l];
     }
     const float max_ratio = (float)fabs(log(16.0 / 1000.0));
+    long gx = (maxpos + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(rpn_score_kernel, dim3((unsigned)gx, (unsigned)nlv), dim3(256), 0, (hipStream_t)stream, L, A, keys, hist);
     hipLaunchKernelGGL(rpn_select_kernel, dim3(nlv), dim3(1024), 0, (hipStream_t)stream, L, A, base_anchors, nms_pre, stds[0], stds[1], stds[2],
-                       stds[3], img_h, img_w, max_ratio, boxes);
+                       stds[3], img_h, img_w, max_ratio, keys, hist, boxes);
     return vps_launch_status();
 }
 

@@ -281,27 +281,7 @@ class PanopticFuseTrack(HipModule):
         else:
             pf, self._pf = self._pf, None
             if side is not None and prefetch is not None:
-                # The NEXT frame's image-only stages (FlowNet2, ResNet + FPN + gather) go to a third stream before anything of THIS
-                # frame is enqueued, so they run beside this frame's neck and heads, not behind its semantic head: the prefetch
-                # stream is then busy back to back (it is the longest chain, ~16 ms of the frame's ~23 ms of kernel time) and the
-                # main / side streams fill the CUs its low-resolution layers leave idle. Its buffers come from a ring of three
-                # private workspaces: slot (t+1) % 3 was last written for frame t-2, whose flow / levels were read by neck(t-2)
-                # and whose gathered feature was last read by neck(t-1) as ref_bsf — both enqueued on the main stream in earlier
-                # calls, which the wait below orders this stream behind (the main stream is drained at this point anyway: the
-                # previous call ended with its end-of-frame read). The images may have been produced on the main stream too.
-                if self._pre is None or self._pre.device != dev:
-                    self._pre = torch.cuda.Stream(device=dev)
-                    self._ring = [nhwc.Workspace(dev) for _ in range(3)]
-                self._pre.wait_stream(main)
-                self._slot = (self._slot + 1) % 3
-                rws = self._ring[self._slot]
-                nimg, nref = prefetch
-                with torch.cuda.stream(self._pre):
-                    nflow = self.flownet2.run(nimg, nref, self._mean_t, self._std_t, rws)
-                    nlevels, ncat = self._backbone_fpn_gather(nimg, rws, ring=True)
-                    ev = torch.cuda.Event()
-                    ev.record(self._pre)
-                self._pf = dict(img=nimg, ref=nref, version=(nimg._version, nref._version), event=ev, flow=nflow, levels=nlevels, cat=ncat)
+                self._enqueue_image_stages(prefetch[0], prefetch[1], main)
             if pf is not None and side is not None and pf['img'] is img and pf['ref'] is ref_img and pf['version'] == (img._version, ref_img._version):
                 # (1)+(2) were enqueued on the prefetch stream during the previous call
                 main.wait_event(pf['event'])
@@ -448,6 +428,44 @@ class PanopticFuseTrack(HipModule):
         return bbox_results, mask_results, pano_results
 
     # ------------------------------------------------------------------------------------------------------
+    def _enqueue_image_stages(self, nimg, nref, main):
+        """The image-only stages (FlowNet2, ResNet + FPN + gather) of the frame the NEXT call will be made with go to a third stream
+        before anything of the current frame is enqueued, so they run beside the current frame's neck and heads, not behind its
+        semantic head: the prefetch stream is then busy back to back (it is the longest chain, ~16 ms of the frame's ~22 ms of
+        kernel time) and the main / side streams fill the CUs its low-resolution layers leave idle. Its buffers come from a ring of
+        three private workspaces: slot (t+1) % 3 was last written for frame t-2, whose flow / levels were read by neck(t-2) and
+        whose gathered feature was last read by neck(t-1) as ref_bsf - both enqueued on the main stream in earlier calls, which the
+        wait below orders this stream behind (the main stream is drained at this point anyway: the previous call ended with its
+        end-of-frame read). The images may have been produced on the main stream too."""
+        dev = nimg.device
+        if self._pre is None or self._pre.device != dev:
+            self._pre = torch.cuda.Stream(device=dev)
+            self._ring = [nhwc.Workspace(dev) for _ in range(3)]
+        self._pre.wait_stream(main)
+        self._slot = (self._slot + 1) % 3
+        rws = self._ring[self._slot]
+        with torch.cuda.stream(self._pre):
+            nflow = self.flownet2.run(nimg, nref, self._mean_t, self._std_t, rws)
+            nlevels, ncat = self._backbone_fpn_gather(nimg, rws, ring=True)
+            ev = torch.cuda.Event()
+            ev.record(self._pre)
+        self._pf = dict(img=nimg, ref=nref, version=(nimg._version, nref._version), event=ev, flow=nflow, levels=nlevels, cat=ncat)
+
+    @torch.no_grad()
+    def prime(self, img, ref_img):
+        """Enqueue the image-only stages of the frame the next `simple_test(img, ..., ref_img=ref_img)` call will process, now: a rank
+        that owns a later shard of a clip (clip_shard.py) calls this BEFORE it waits for the previous rank's feature hand-off, so
+        its first frame's FlowNet2 + ResNet / FPN run while the hand-off is in flight instead of behind it. No-op without the
+        stream schedule (profiling, overlap_streams off) or without the fusion neck."""
+        if not (self.with_fusion and self.overlap_streams and self.profile is None and img.is_cuda):
+            return False
+        self.ensure_packed(img.device)
+        pf, self._pf = self._pf, None
+        if pf is not None:
+            pf['event'].synchronize()
+        self._enqueue_image_stages(img, ref_img, torch.cuda.current_stream(img.device))
+        return True
+
     @staticmethod
     def _probe(img):
         """a 3 x 16 x 32 strided sample of a frame (device tensor, no sync): the fingerprint `reuse_ref_features` checks"""

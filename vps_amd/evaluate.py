@@ -42,11 +42,15 @@ class PQStat:
             self.pq_per_cat[label] += cat
         return self
 
-    def pq_average(self, categories, isthing):
+    def pq_average(self, categories, isthing, exclude=()):
+        """tools/eval_vpq.py:40-71; `exclude`: category ids left out of the average - tools/dataset/viper.py:64-90 is the same
+        function with `if label == 11: continue` (VIPER's "mobilebarrier"): `postprocess.DATASETS['viper']['pq_exclude']`"""
         pq, sq, rq, n = 0, 0, 0, 0
         per_class = {}
         for label, info in categories.items():
             if isthing is not None and isthing != (info['isthing'] == 1):
+                continue
+            if label in exclude:
                 continue
             c = self.pq_per_cat[label]
             if c.tp + c.fp + c.fn == 0:

@@ -182,8 +182,11 @@ class RPNHead(HipModule):
         st = (c_float * nlv)(*[float(v) for v in self.anchor_strides[:nlv]])
         stds = (c_float * 4)(*[float(v) for v in self.target_stds])
         assert all(float(v) == 0.0 for v in self.target_means)
+        nkeys = sum(x.H * x.W * A for x in levels)
+        keys = ws.get(tag + 'keys', (nkeys,), dtype=torch.int32, zero=False)
+        hist = ws.get(tag + 'hist', (nlv * 4096,), dtype=torch.int32, zero=True)        # zero once: every launch leaves it zero
         hip.check(lib.vps_rpn_select(cp, cl, rp, rl, Hs, Ws, st, nlv, A, hip.ptr(base_d), nms_pre, stds, float(img_shape[0]), float(img_shape[1]),
-                                     hip.ptr(boxes), hip.stream_ptr()), 'vps_rpn_select')
+                                     hip.ptr(keys), hip.ptr(hist), hip.ptr(boxes), hip.stream_ptr()), 'vps_rpn_select')
         assert cfg.min_bbox_size == 0 and not cfg.nms_across_levels
         cb = (nms_pre + 63) // 64
         ck = (tuple(counts), str(dev))

@@ -138,7 +138,7 @@ def load():
     lib.vps_panoptic_combine_dev.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                              c_void_p, c_void_p, c_int, c_int, c_void_p]
     lib.vps_rpn_select.argtypes = [POINTER(c_void_p), POINTER(c_int32), POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
-                                   POINTER(c_float), c_int, c_int, c_void_p, c_int, POINTER(c_float), c_float, c_float, c_void_p, c_void_p]
+                                   POINTER(c_float), c_int, c_int, c_void_p, c_int, POINTER(c_float), c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.vps_rpn_collect.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     lib.vps_maskroi_select.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, POINTER(c_float), c_float, c_float,
                                        c_void_p, c_void_p, c_void_p, c_void_p]

@@ -126,6 +126,128 @@ class PairFeeder:
         return cur.unsqueeze(0), ref.unsqueeze(0)            # [1,3,Hp,Wp] each, what model(img=[..], ref_img=[..]) takes
 
 
+def _decode_into_shm(path, shm_name, nbytes):
+    """decode worker (its own PROCESS): imread(path) -> the named shared-memory block; returns the array's shape"""
+    from multiprocessing import shared_memory
+    img = imread(path)
+    assert img.nbytes <= nbytes, 'frame larger than the staging block (%d > %d bytes)' % (img.nbytes, nbytes)
+    shm = shared_memory.SharedMemory(name=shm_name)
+    try:
+        np.ndarray(img.shape, dtype=np.uint8, buffer=shm.buf)[...] = img
+    finally:
+        shm.close()
+    return img.shape
+
+
+class ClipFeeder:
+    """`load_frame(t)` of a clip from image FILES, for `ClipShardRunner.run` and test_vpq-style loops (the
+    reference's side of it is `datasets/pipelines/loading.py:43-68` on `workers_per_gpu=2` loader processes, `configs/cityscapes/
+    fusetrack.py:193-194`, each decoding and normalising BOTH images of every pair).
+
+    `workers` decode PROCESSES (forked like the reference's DataLoader workers; they only run PIL / numpy) decode the files ahead
+    of the consumer, every file ONCE, into a ring of shared-memory blocks; the consumer copies a block into pinned memory, uploads
+    the uint8 frame (6 MB instead of the 25 MB fp32 tensor) and `DeviceImagePrep.prep` makes the normalised, padded fp32 tensor
+    on the device. Threads do not work here: PIL inflates with the interpreter lock held for long stretches, and beside a main
+    thread that is busy launching ~560 kernels per frame four decode threads deliver 6 frames/s (30 with an idle main thread;
+    measured). A prepared frame is kept until the consumer asks for a frame two positions later (frame t is frame t+1's
+    reference), so the same tensor OBJECT serves as `img` of frame t and `ref_img` of frame t+1 - what the detector's prefetch /
+    hand-off matching by tensor identity needs.
+
+        feeder = ClipFeeder(files, prep, workers=4)
+        outs = ClipShardRunner(DetectorBackend(model, H, W)).run(feeder, len(files))
+        feeder.close()
+    """
+
+    def __init__(self, files, prep, workers=4, ahead=None, processes=True):
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
+        self.files, self.prep = list(files), prep
+        self.workers = int(workers)
+        self.ahead = int(ahead) if ahead is not None else 2 * self.workers      # decoded frames in flight beyond the consumer
+        self.processes = bool(processes)
+        self._pool = ProcessPoolExecutor(self.workers, mp_context=mp.get_context('fork')) if self.processes else ThreadPoolExecutor(self.workers)
+        self._pending = {}          # t -> (future, shm block index or None)
+        self._ready = {}            # t -> prepared device tensor [1,3,Hp,Wp]
+        self._pinned = None
+        self._next = 0              # first index not yet submitted
+        self.decodes = 0
+        self._blocks, self._free, self._nbytes = [], [], 0
+        if self.processes and self.files:
+            from multiprocessing import shared_memory
+            from PIL import Image
+            with Image.open(self.files[0]) as im:                                # header only: the frame size of the clip
+                w, h = im.size
+            self._nbytes = h * w * 3
+            self._blocks = [shared_memory.SharedMemory(create=True, size=self._nbytes) for _ in range(self.ahead + 2)]
+            self._free = list(range(len(self._blocks)))
+
+    def __len__(self):
+        return len(self.files)
+
+    def _submit(self, t):
+        if self.processes:
+            b = self._free.pop()
+            return (self._pool.submit(_decode_into_shm, self.files[t], self._blocks[b].name, self._nbytes), b)
+        return (self._pool.submit(imread, self.files[t]), None)
+
+    def _submit_until(self, t_hi):
+        while self._next < min(t_hi, len(self.files)) and (not self.processes or self._free):
+            self._pending[self._next] = self._submit(self._next)
+            self._next += 1
+
+    def meta(self, t):
+        """img_meta entries of frame t that depend on the file (`Collect` keys of configs/cityscapes/fusetrack.py:190)"""
+        return dict(filename=self.files[t])
+
+    def __call__(self, t):
+        if t in self._ready:
+            return self._ready[t]
+        if t >= self._next:                       # random access (a shard that starts mid-clip): start the window there
+            self._next = max(self._next, t)
+        self._submit_until(t + 1 + self.ahead)
+        ent = self._pending.pop(t, None)
+        if ent is None:                           # not in the window (asked again after it was dropped, or behind it): decode it now
+            if self.processes and not self._free:
+                raise RuntimeError('ClipFeeder: frame %d requested outside the decode window with every staging block in flight' % t)
+            ent = self._submit(t)
+        fut, blk = ent
+        res = fut.result()
+        img = np.ndarray(res, dtype=np.uint8, buffer=self._blocks[blk].buf) if blk is not None else res
+        self.decodes += 1
+        dev = self.prep.device
+        if dev.type == 'cuda':
+            src = torch.from_numpy(img)
+            if self._pinned is None or self._pinned[0].shape != src.shape:
+                self._pinned = [torch.empty(src.shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
+                self._pin_ev = [None, None]
+            k = t & 1
+            if self._pin_ev[k] is not None:
+                self._pin_ev[k].synchronize()     # the upload that last used this staging buffer has finished
+            self._pinned[k].copy_(src)
+            d = self._pinned[k].to(dev, non_blocking=True)
+            ev = torch.cuda.Event(); ev.record()
+            self._pin_ev[k] = ev
+        else:
+            d = np.array(img)                      # host stand-in (tests): own copy, the block goes back to the ring
+        out = self.prep.prep(d)[0].unsqueeze(0)
+        if blk is not None:
+            del img
+            self._free.append(blk)
+            self._submit_until(t + 1 + self.ahead)
+        self._ready[t] = out
+        for old in [k for k in self._ready if k < t - 1]:      # frame t-1 stays: it is frame t's reference
+            del self._ready[old]
+        return out
+
+    def close(self):
+        for fut, blk in self._pending.values():
+            fut.cancel()
+        self._pool.shutdown(wait=True)
+        for b in self._blocks:
+            b.close(); b.unlink()
+        self._blocks, self._free, self._pending = [], [], {}
+
+
 def imread(path):
     """mmcv.imread(path) / cv2.imread(path, IMREAD_COLOR): uint8 [H,W,3] in BGR order; grey images are replicated to three
     channels, an alpha channel is dropped"""
@@ -137,14 +259,21 @@ def imread(path):
         return img
     except ImportError:
         pass
+    import io
     from PIL import Image
-    with Image.open(path) as im:
+    # The file is read in one piece and handed to the decoder in ONE call (`decodermaxblock`): PIL's load loop otherwise feeds the
+    # inflater 64 KB at a time from Python, and a decode THREAD then re-acquires the interpreter lock ~60 times per 1024x2048 frame -
+    # each time waiting for a main thread that is busy launching kernels to give it up (ClipFeeder: 26 frames/s instead of 46)
+    with open(path, 'rb') as f:
+        data = f.read()
+    with Image.open(io.BytesIO(data)) as im:
         # PIL equals cv2.imread bit for bit only for 8-bit PNG (lossless; the Cityscapes-VPS frames). A 16-bit PNG is not scaled
         # like cv2 does -> refused; a JPEG (VIPER) decodes with another IDCT / EXIF handling -> decoded, with a warning
         if im.mode in ('I;16', 'I;16B', 'I', 'F'):
             raise ValueError('imread: %s is not an 8-bit image (mode %s); cv2 is needed for cv2.imread semantics' % (path, im.mode))
         if im.format != 'PNG':
             warnings.warn('imread: %s decoded with PIL; pixels can differ from cv2.imread for lossy formats (%s)' % (path, im.format))
+        im.decodermaxblock = len(data) + 1
         rgb = np.asarray(im.convert('RGB'))
     return np.ascontiguousarray(rgb[:, :, ::-1])
 

@@ -36,6 +36,17 @@ def dedup_obj_ids(obj_id, max_oid):
     return np.asarray(work[::-1], dtype=np.int64), max_oid
 
 
+# class tables of the datasets the reference's post-processing is configured for: `config.dataset.num_seg_classes / num_classes`
+# (stuff classes = ids 0 .. num_seg_classes - num_classes - 1 of the semantic map, things behind them) and the categories the
+# evaluation leaves out of the PQ average. tools/dataset/cityscapes_vps.py + configs/cityscapes/test_cityscapes_1gpu.yaml:7-8;
+# tools/dataset/viper.py:93-130 (23 / 11: ids 0..12 stuff, 13..22 things + the void instance) and :74-76 (`#### exclude
+# "mobilebarrier"`, category 11)
+DATASETS = {
+    'cityscapes_vps': dict(num_seg_classes=19, num_classes=9, pq_exclude=()),
+    'viper': dict(num_seg_classes=23, num_classes=11, pq_exclude=(11,)),
+}
+
+
 class PanopticUnifier:
     def __init__(self, device='cuda', num_seg_classes=19, num_classes=9):
         self.device = torch.device(device)
