@@ -319,6 +319,14 @@ int vps_panoptic_combine_dev(const float* fcn_score, int score_ld, int Hs, int W
  * Device-resident detection post-processing (csrc/head_ops.hip): the order-defining HOST code of the reference's heads as
  * single-workgroup kernels, so that a frame needs ONE mid-frame D2H (the detection list) and one at its end (kept list + ids).
  * -------------------------------------------------------------------------------------------- */
+/* HOST functions (no device work, no stream): PNG decode for the input pipeline - `mmcv.imread` in datasets/pipelines/loading.py:43-68
+ * (cv2.imread(IMREAD_COLOR): BGR uint8). Called through the C-ABI they run without the Python interpreter lock, so a pool of plain
+ * threads scales. `file` = the file's bytes. vps_png_info: size / channel count of an 8-bit non-interlaced RGB, RGBA or grey PNG;
+ * any other PNG flavour (16-bit, palette, interlaced) returns an argument error and the caller uses its general decoder.
+ * vps_png_decode_bgr8: out [H][W][3] BGR (alpha dropped, grey replicated), out_capacity >= H*W*3 bytes. */
+int vps_png_info(const uint8_t* file, int64_t nbytes, int32_t* H, int32_t* W, int32_t* channels);
+int vps_png_decode_bgr8(const uint8_t* file, int64_t nbytes, uint8_t* out, int64_t out_capacity);
+
 /* ref: models/anchor_heads/rpn_head.py:62-91 (sigmoid objectness, `scores.topk(nms_pre)`, gathers) + core/anchor/anchor_generator.py:55-72
  * (grid anchors) + core/bbox/transforms.py:34-68 (delta2bbox, means 0, clipped to the image) for ALL levels: one chip-wide scoring
  * launch + one select / sort / decode launch with one workgroup per level. cls[l] / reg[l]: NHWC maps [H_l][W_l][ld] of level l

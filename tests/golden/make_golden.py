@@ -5,6 +5,7 @@ container, with the import shims of ref_shims.py (third-party stubs + oracle-bac
     python tests/golden/make_golden.py [fusetrack|fuse|track]   # needs /root/reference; writes tests/golden/<variant>_clip.npz
     python tests/golden/make_golden.py fullsize                  # 2 frames at 1024x2048 -> tests/golden/fusetrack_fullsize.npz
     python tests/golden/make_golden.py fullsize_sep              # 4 frames at 1024x2048, fitted well-separated box classifier (strict fixture)
+    python tests/golden/make_golden.py fullsize_dense            # 6 frames at 1024x2048, fitted dense box classifier (40..100 detections per frame, strict)
     python tests/golden/make_golden.py r101                      # ResNet-101 variant (BASELINE config 5), 2 frames at 128x256
     python tests/golden/make_golden.py seed1                     # FuseTrack, weight / clip seed 1, 3 frames at 128x192
 
@@ -30,7 +31,7 @@ H, W, NFRAMES, SEED = 128, 256, 3, 0
 FULL_H, FULL_W, FULL_NFRAMES = 1024, 2048, 2          # `fullsize`: the BASELINE frame size (configs[1]), FuseTrack only
 
 
-def main(variant='fusetrack', H=H, W=W, NFRAMES=NFRAMES, out_name=None, full=False, depth=None, seed=SEED, separated=False):
+def main(variant='fusetrack', H=H, W=W, NFRAMES=NFRAMES, out_name=None, full=False, depth=None, seed=SEED, separated=False, head='separated_fc_cls.npz', map_stride=1):
     """full=True: the 1024x2048 golden — same quantities, the dense stage tensors strided so the file stays a few MB"""
     import ref_shims
     mods = ref_shims.install()
@@ -46,7 +47,7 @@ def main(variant='fusetrack', H=H, W=W, NFRAMES=NFRAMES, out_name=None, full=Fal
     ours = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
     shapes = {k: tuple(v.shape) for k, v in ours.state_dict().items()}
     # separated=True: the box classification layer fitted by search_separated.py (every listing decision has a margin)
-    sd = synth.synth_state_dict(shapes, seed, overrides=synth.separated_overrides(os.path.join(HERE, 'separated_fc_cls.npz')) if separated else None)
+    sd = synth.synth_state_dict(shapes, seed, overrides=synth.separated_overrides(os.path.join(HERE, head)) if separated else None)
 
     # --- the reference detector; its __init__ loads FlowNet2 from cwd/work_dirs/flownet/FlowNet2_checkpoint.pth.tar ---
     tmp = tempfile.mkdtemp(prefix='vps_golden_')
@@ -107,8 +108,9 @@ def main(variant='fusetrack', H=H, W=W, NFRAMES=NFRAMES, out_name=None, full=Fal
             cap.clear()
             bbox_res, mask_res, pano = ref(return_loss=False, rescale=True, img=[img], img_meta=[[meta]], ref_img=[ref_img])
             p = 'f%d.' % t
-            out[p + 'fcn_outputs'] = pano['fcn_outputs'].numpy().astype(np.uint8)
-            out[p + 'panoptic_outputs'] = pano['panoptic_outputs'].numpy().astype(np.uint8)
+            # map_stride > 1 (the 6-frame dense fixture): every map_stride-th pixel of the two maps, so the file stays ~10 MB
+            out[p + 'fcn_outputs'] = pano['fcn_outputs'].numpy().astype(np.uint8)[..., ::map_stride, ::map_stride]
+            out[p + 'panoptic_outputs'] = pano['panoptic_outputs'].numpy().astype(np.uint8)[..., ::map_stride, ::map_stride]
             out[p + 'panoptic_cls_inds'] = pano['panoptic_cls_inds'].numpy()
             out[p + 'panoptic_cls_prob'] = pano['panoptic_cls_prob'].numpy()
             if has_track:
@@ -137,6 +139,7 @@ def main(variant='fusetrack', H=H, W=W, NFRAMES=NFRAMES, out_name=None, full=Fal
                                                        out[p + 'panoptic_det_obj_ids'][:8] if has_track else None))
     out['meta'] = np.array([H, W, NFRAMES, seed], dtype=np.int64)
     out['strides'] = np.array([s1, s2, c5 or 0], dtype=np.int64)
+    out['map_stride'] = np.int64(map_stride)
     out['state_dict_manifest'] = np.frombuffer(manifest.encode(), dtype=np.uint8)
     path = os.path.join(HERE, out_name or '%s_clip.npz' % variant)
     np.savez_compressed(path, **out)
@@ -150,6 +153,10 @@ if __name__ == '__main__':
     elif v == 'fullsize_sep':
         # the STRICT full-size fixture: 4 frames at 1024x2048, well-separated detections (tests/golden/separated_fc_cls.npz)
         main('fusetrack', FULL_H, FULL_W, 4, 'fusetrack_fullsize_sep.npz', full=True, separated=True)
+    elif v == 'fullsize_dense':
+        # the DENSE strict fixture: 6 frames at 1024x2048, 40..100 well-separated detections per frame (tests/golden/search_dense.py ->
+        # dense_fc_cls.npz, chosen by oracle margins only)
+        main('fusetrack', FULL_H, FULL_W, 6, 'fusetrack_fullsize_dense.npz', full=True, separated=True, head='dense_fc_cls.npz', map_stride=2)
     elif v == 'r101':
         main('fusetrack', H, W, 2, 'fusetrack_r101_clip.npz', depth=101)
     elif v == 'seed1':

@@ -107,8 +107,7 @@ def test_imread_and_load_ref_image_decode_every_file_once(tmp_path):
         load(dict(img_prefix='.', ref_prefix='.', img_info=dict(filename='x.png', id=1)))
 
 
-@pytest.mark.parametrize('mode', [True, False], ids=['processes', 'threads'])
-def test_clip_feeder_decodes_every_file_once_and_keeps_tensor_identity(tmp_path, mode):
+def test_clip_feeder_decodes_every_file_once_and_keeps_tensor_identity(tmp_path):
     """vps_amd.pipeline.ClipFeeder (the product's `load_frame` for clips on disk) with a host-side stand-in for DeviceImagePrep:
     files decoded once by the thread pool, the SAME tensor object for frame t as `img` and as frame t+1's reference, old frames
     dropped, a shard that starts mid-clip served, decoded pixels == imread"""
@@ -131,7 +130,7 @@ def test_clip_feeder_decodes_every_file_once_and_keeps_tensor_identity(tmp_path,
         fn = str(tmp_path / ('f%02d.png' % i))
         Image.fromarray(a).save(fn)
         files.append(fn)
-    fd = ClipFeeder(files, HostPrep(), workers=3, processes=mode)
+    fd = ClipFeeder(files, HostPrep(), workers=3)
     assert len(fd) == 7
     prev = None
     for t in range(7):
@@ -145,8 +144,35 @@ def test_clip_feeder_decodes_every_file_once_and_keeps_tensor_identity(tmp_path,
         assert set(fd._ready) <= {t - 1, t}
     assert fd.decodes == 7 and HostPrep.calls == 7
     fd.close()
-    fd2 = ClipFeeder(files, HostPrep(), workers=2, processes=mode)
+    fd2 = ClipFeeder(files, HostPrep(), workers=2)
     x4 = fd2(4); x3 = fd2(3)                                  # a shard that starts at frame 4 loads its reference frame 3 afterwards
     assert torch.equal(x3[0], torch.from_numpy(np.ascontiguousarray(imread(files[3]))).permute(2, 0, 1).float())
     assert fd2(4) is x4 and fd2(5).shape == (1, 3, 12, 20)
     fd2.close()
+
+
+@pytest.mark.parametrize('mode,shape', [('RGB', (37, 53)), ('RGBA', (16, 40)), ('L', (21, 19)), ('RGB', (256, 512))])
+def test_native_png_decoder_equals_pil(tmp_path, mode, shape):
+    """csrc/png_host.cpp (host code of libvpship, no GPU needed): bit-identical to PIL on every filter type the encoder picks
+    (smooth and noisy content, all compression levels), RGB / RGBA (alpha dropped) / grey (replicated); flavours outside its
+    scope (16-bit, palette, interlaced) are handed back to the general decoder"""
+    from PIL import Image
+    from vps_amd.pipeline import imread, png_decode
+    rng = np.random.RandomState(1)
+    H, W = shape
+    nch = {'RGB': 3, 'RGBA': 4, 'L': 1}[mode]
+    yy, xx = np.mgrid[0:H, 0:W]
+    for k, level in enumerate((0, 1, 6, 9)):
+        a = (np.stack([(xx * (3 + c) + yy * 2 + 17 * c) % 256 for c in range(nch)], -1) if k % 2 == 0 else rng.randint(0, 256, (H, W, nch))).astype(np.uint8)
+        a = a[..., 0] if nch == 1 else a
+        fn = str(tmp_path / ('t%d.png' % k))
+        Image.fromarray(a, mode).save(fn, compress_level=level)
+        got = imread(fn)
+        want = np.asarray(Image.open(fn).convert('RGB'))[:, :, ::-1]
+        assert got.dtype == np.uint8 and got.shape == (H, W, 3) and np.array_equal(got, want), (mode, level)
+    # out of scope -> None -> imread falls back to PIL
+    pal = str(tmp_path / 'pal.png')
+    Image.fromarray(rng.randint(0, 255, (8, 9)).astype(np.uint8), 'L').convert('P').save(pal)
+    assert png_decode(bytearray(open(pal, 'rb').read())) is None
+    assert imread(pal).shape == (8, 9, 3)
+    assert png_decode(bytearray(b'not a png at all, just thirty-three bytes.')) is None

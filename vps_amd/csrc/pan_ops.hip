@@ -235,20 +235,40 @@ void panoptic_combine_kernel(const float* __restrict__ score, int score_ld, int 
         }
         if (lane == 0) nlist = n;
     }
+    // The source texels of the tile's bilinear x`up` upsampling (for up = 4: 10 x 4 texels of `nclass` logits) are staged in LDS once:
+    // a pixel otherwise issues 4 x nclass strided 4-byte global reads (76 at 19 classes: the kernel was bound by the L1 tag rate,
+    // 112 us for 15 MB of traffic). Same values, same arithmetic order: bit-identical maps. up = 1 or very wide maps read global memory.
+    constexpr int TEX_MAX = 18 * 6, TEX_LD = 32;
+    __shared__ float tex[TEX_MAX * TEX_LD];
+    const float rs = 1.0f / (float)up;
+    auto src = [&](const int o, const int lim) {
+        float s_ = rs * ((float)o + 0.5f) - 0.5f; if (s_ < 0.f) s_ = 0.f;
+        return min((int)s_, lim - 1);
+    };
+    const int xs0 = src(tx0, Ws), ys0 = src(ty0, Hs);
+    const int TW = min(src(tx1 - 1, Ws) + 1, Ws - 1) - xs0 + 1, TH = min(src(ty1 - 1, Hs) + 1, Hs - 1) - ys0 + 1;
+    const bool staged = up >= 2 && nclass <= TEX_LD && TW * TH <= TEX_MAX;
+    if (staged) {
+        for (int i = threadIdx.x; i < TW * TH * nclass; i += 256) {
+            const int tt = i / nclass, c = i - tt * nclass;
+            const int tyy = tt / TW, txx = tt - tyy * TW;
+            tex[tt * TEX_LD + c] = score[((size_t)(ys0 + tyy) * Ws + xs0 + txx) * score_ld + c];
+        }
+    }
     __syncthreads();
     const int x = tx0 + (threadIdx.x & 31), y = ty0 + (threadIdx.x >> 5);
     if (x >= W || y >= H) return;
-    const float rs = 1.0f / (float)up;
     float sy = rs * ((float)y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
     float sx = rs * ((float)x + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
     const int y0 = min((int)sy, Hs - 1), x0 = min((int)sx, Ws - 1);
     const int yp = y0 < Hs - 1 ? 1 : 0, xp = x0 < Ws - 1 ? 1 : 0;
     const float ly = sy - (float)y0, lx = sx - (float)x0;
     const float hy = 1.f - ly, hx = 1.f - lx;
-    const float* p00 = score + ((size_t)y0 * Ws + x0) * score_ld;
-    const float* p01 = p00 + (size_t)xp * score_ld;
-    const float* p10 = p00 + (size_t)yp * Ws * score_ld;
-    const float* p11 = p10 + (size_t)xp * score_ld;
+    const float* p00 = staged ? tex + ((y0 - ys0) * TW + (x0 - xs0)) * TEX_LD : score + ((size_t)y0 * Ws + x0) * score_ld;
+    const size_t tstep = staged ? (size_t)TEX_LD : (size_t)score_ld, rstep = staged ? (size_t)TW * TEX_LD : (size_t)Ws * score_ld;
+    const float* p01 = p00 + (size_t)xp * tstep;
+    const float* p10 = p00 + (size_t)yp * rstep;
+    const float* p11 = p10 + (size_t)xp * tstep;
     float best_sem = -INFINITY, best_pan = -INFINITY;
     int i_sem = 0, i_pan = 0;
     for (int c = 0; c < nclass; ++c) {

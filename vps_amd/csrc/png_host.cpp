@@ -1,0 +1,112 @@
+// Host-side PNG decoder for the input pipeline (`mmcv.imread` of the Cityscapes-VPS / VIPER frames in
+// datasets/pipelines/loading.py:43-68). Why native: Python decoders hold the interpreter lock while they inflate, and beside a main
+// thread that launches ~560 kernels per frame a pool of PIL decode threads delivers 6 frames/s (30 with an idle main thread; forked
+// decode processes stall on the fork of a process with 30 GB of device mappings: 1.4 frames/s measured). A C-ABI call made through
+// ctypes runs WITHOUT the lock, so plain threads scale. Scope: what the datasets of the path contain - 8-bit, non-interlaced, colour
+// type 2 (RGB), 6 (RGBA, alpha dropped like cv2.IMREAD_COLOR) or 0 (grey, replicated); anything else returns VPS_EARG and the caller
+// falls back to its general decoder. Output: BGR uint8 [H][W][3] (cv2 / mmcv channel order). zlib does the inflate.
+#include <zlib.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/vps_hip.h"
+
+#define VPS_EARG(x) (-1000 - (x))
+
+namespace {
+
+inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]; }
+
+inline int paeth(int a, int b, int c) {
+    const int p = a + b - c;
+    const int pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+}  // namespace
+
+extern "C" int vps_png_info(const uint8_t* file, int64_t nbytes, int32_t* H, int32_t* W, int32_t* channels) {
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (!file || nbytes < 33 || memcmp(file, sig, 8) != 0 || be32(file + 8) != 13 || memcmp(file + 12, "IHDR", 4) != 0) return VPS_EARG(1);
+    const uint32_t w = be32(file + 16), h = be32(file + 20);
+    const int depth = file[24], ctype = file[25], interlace = file[28];
+    if (w == 0 || h == 0 || w > 65535 || h > 65535) return VPS_EARG(2);
+    if (depth != 8 || interlace != 0 || !(ctype == 0 || ctype == 2 || ctype == 6)) return VPS_EARG(3);      // caller falls back
+    if (H) *H = (int32_t)h;
+    if (W) *W = (int32_t)w;
+    if (channels) *channels = ctype == 0 ? 1 : (ctype == 2 ? 3 : 4);
+    return 0;
+}
+
+extern "C" int vps_png_decode_bgr8(const uint8_t* file, int64_t nbytes, uint8_t* out, int64_t out_capacity) {
+    int32_t H, W, C;
+    const int st = vps_png_info(file, nbytes, &H, &W, &C);
+    if (st) return st;
+    if (!out || out_capacity < (int64_t)H * W * 3) return VPS_EARG(4);
+    const size_t stride = (size_t)W * C;
+    uint8_t* raw = (uint8_t*)malloc((stride + 1) * (size_t)H);           // filter byte + pixels per scanline
+    if (!raw) return VPS_EARG(5);
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit(&zs) != Z_OK) { free(raw); return VPS_EARG(6); }
+    zs.next_out = raw;
+    zs.avail_out = (uInt)((stride + 1) * (size_t)H);
+    int64_t pos = 8;
+    int zret = Z_OK;
+    bool end = false;
+    while (pos + 12 <= nbytes && !end) {
+        const uint32_t len = be32(file + pos);
+        const uint8_t* type = file + pos + 4;
+        if (pos + 12 + (int64_t)len > nbytes) break;
+        if (memcmp(type, "IDAT", 4) == 0 && zret == Z_OK) {
+            zs.next_in = const_cast<Bytef*>(file + pos + 8);
+            zs.avail_in = len;
+            zret = inflate(&zs, Z_NO_FLUSH);
+            if (zret != Z_OK && zret != Z_STREAM_END) break;
+        } else if (memcmp(type, "IEND", 4) == 0) {
+            end = true;
+        }
+        pos += 12 + (int64_t)len;
+    }
+    const bool complete = zs.avail_out == 0 && (zret == Z_STREAM_END || zret == Z_OK);
+    inflateEnd(&zs);
+    if (!complete) { free(raw); return VPS_EARG(7); }
+    // un-filter in place (PNG specification 9.2: None, Sub, Up, Average, Paeth; bytes of the pixel to the left = C bytes back)
+    for (int y = 0; y < H; ++y) {
+        uint8_t* cur = raw + (size_t)y * (stride + 1) + 1;
+        const uint8_t* up = y ? cur - (stride + 1) : nullptr;
+        const int ft = cur[-1];
+        switch (ft) {
+            case 0: break;
+            case 1:
+                for (size_t i = C; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - C]);
+                break;
+            case 2:
+                if (up) for (size_t i = 0; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + up[i]);
+                break;
+            case 3:
+                for (size_t i = 0; i < stride; ++i) {
+                    const int a = i >= (size_t)C ? cur[i - C] : 0, b = up ? up[i] : 0;
+                    cur[i] = (uint8_t)(cur[i] + ((a + b) >> 1));
+                }
+                break;
+            case 4:
+                for (size_t i = 0; i < stride; ++i) {
+                    const int a = i >= (size_t)C ? cur[i - C] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)C) ? up[i - C] : 0;
+                    cur[i] = (uint8_t)(cur[i] + paeth(a, b, c));
+                }
+                break;
+            default:
+                free(raw);
+                return VPS_EARG(8);
+        }
+        uint8_t* o = out + (size_t)y * W * 3;
+        if (C == 1) {
+            for (int x = 0; x < W; ++x) { o[3 * x] = o[3 * x + 1] = o[3 * x + 2] = cur[x]; }
+        } else {
+            for (int x = 0; x < W; ++x) { o[3 * x] = cur[(size_t)C * x + 2]; o[3 * x + 1] = cur[(size_t)C * x + 1]; o[3 * x + 2] = cur[(size_t)C * x]; }
+        }
+    }
+    free(raw);
+    return 0;
+}

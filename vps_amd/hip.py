@@ -28,6 +28,7 @@ SYMBOLS = [
     'vps_row_softmax', 'vps_mask_count', 'vps_mask_commit', 'vps_mask_removal', 'vps_mask_level', 'vps_panoptic_combine',
     'vps_panoptic_combine_dev', 'vps_rpn_select', 'vps_rpn_collect', 'vps_maskroi_select', 'vps_maskroi_finish', 'vps_track_assign', 'vps_pan_instances',
     'vps_unify_hist', 'vps_unify_tables', 'vps_unify_write', 'vps_image_prep', 'vps_resize_u8', 'vps_segment_stats', 'vps_segment_paint', 'vps_pair_count',
+    'vps_png_info', 'vps_png_decode_bgr8',
 ]
 
 
@@ -60,10 +61,17 @@ class PanInst(Structure):
 
 
 _lib = None
+_host = None
 
 
 class VpsHipError(RuntimeError):
     pass
+
+
+def load_host():
+    """the handle whose calls release the interpreter lock: the host-side functions (PNG decode) that decode threads run in parallel"""
+    load()
+    return _host
 
 
 def load():
@@ -74,7 +82,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise VpsHipError('libvpship.so not found at %s — build it with `python -c "import __graft_entry__ as g; '
                           'g.build()"` or `make -C vps_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+    # PyDLL: the calls are made WITH the interpreter lock held. Every entry point but the two host-side PNG functions only enqueues
+    # work (microseconds); releasing the lock around each of the ~560 launches of a frame lets any other Python thread (the decode
+    # pool of pipeline.ClipFeeder) take it in between, and getting it back costs a condition-variable round trip per launch: the
+    # frame went from 21.6 to 38.5 ms beside six decode threads. The PNG functions are bound on a second, lock-releasing handle.
+    lib = ctypes.PyDLL(LIB_PATH)
     missing = [s for s in SYMBOLS if not hasattr(lib, s)]
     if missing:
         raise VpsHipError('libvpship.so is missing symbols: %s' % missing)
@@ -137,6 +149,12 @@ def load():
                                          c_void_p, c_void_p, c_int, c_int, c_void_p]
     lib.vps_panoptic_combine_dev.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                              c_void_p, c_void_p, c_int, c_int, c_void_p]
+    global _host
+    _host = ctypes.CDLL(LIB_PATH)                 # same library; these calls run WITHOUT the interpreter lock (long host work)
+    for h in (lib, _host):
+        h.vps_png_info.restype = h.vps_png_decode_bgr8.restype = c_int
+        h.vps_png_info.argtypes = [c_void_p, c_int64, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]
+        h.vps_png_decode_bgr8.argtypes = [c_void_p, c_int64, c_void_p, c_int64]
     lib.vps_rpn_select.argtypes = [POINTER(c_void_p), POINTER(c_int32), POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
                                    POINTER(c_float), c_int, c_int, c_void_p, c_int, POINTER(c_float), c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.vps_rpn_collect.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]

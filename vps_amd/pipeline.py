@@ -126,80 +126,99 @@ class PairFeeder:
         return cur.unsqueeze(0), ref.unsqueeze(0)            # [1,3,Hp,Wp] each, what model(img=[..], ref_img=[..]) takes
 
 
-def _decode_into_shm(path, shm_name, nbytes):
-    """decode worker (its own PROCESS): imread(path) -> the named shared-memory block; returns the array's shape"""
-    from multiprocessing import shared_memory
-    img = imread(path)
-    assert img.nbytes <= nbytes, 'frame larger than the staging block (%d > %d bytes)' % (img.nbytes, nbytes)
-    shm = shared_memory.SharedMemory(name=shm_name)
-    try:
-        np.ndarray(img.shape, dtype=np.uint8, buffer=shm.buf)[...] = img
-    finally:
-        shm.close()
-    return img.shape
-
-
 class ClipFeeder:
     """`load_frame(t)` of a clip from image FILES, for `ClipShardRunner.run` and test_vpq-style loops (the
     reference's side of it is `datasets/pipelines/loading.py:43-68` on `workers_per_gpu=2` loader processes, `configs/cityscapes/
     fusetrack.py:193-194`, each decoding and normalising BOTH images of every pair).
 
-    `workers` decode PROCESSES (forked like the reference's DataLoader workers; they only run PIL / numpy) decode the files ahead
-    of the consumer, every file ONCE, into a ring of shared-memory blocks; the consumer copies a block into pinned memory, uploads
-    the uint8 frame (6 MB instead of the 25 MB fp32 tensor) and `DeviceImagePrep.prep` makes the normalised, padded fp32 tensor
-    on the device. Threads do not work here: PIL inflates with the interpreter lock held for long stretches, and beside a main
-    thread that is busy launching ~560 kernels per frame four decode threads deliver 6 frames/s (30 with an idle main thread;
-    measured). A prepared frame is kept until the consumer asks for a frame two positions later (frame t is frame t+1's
-    reference), so the same tensor OBJECT serves as `img` of frame t and `ref_img` of frame t+1 - what the detector's prefetch /
-    hand-off matching by tensor identity needs.
+    `workers` decode THREADS run ahead of the consumer, every file ONCE: a worker reads the file into a reusable buffer and the
+    library's own PNG decoder (`csrc/png_host.cpp`, a C-ABI call that runs without the interpreter lock) writes the BGR frame
+    STRAIGHT INTO A PINNED staging buffer of a small ring - no per-frame host allocation, no copy on the consumer's thread. The
+    consumer uploads the uint8 frame (6 MB instead of the 25 MB fp32 tensor) and `DeviceImagePrep.prep` makes the normalised,
+    padded fp32 tensor on the device. Files the native decoder does not take (JPEG, 16-bit / palette PNG) go through `imread` and one
+    copy into the staging buffer. What did NOT work (measured on the GPU box): PIL decode threads - they hold the interpreter lock
+    for long stretches and beside a main thread that launches ~560 kernels per frame deliver 6 frames/s; forked decode processes -
+    the fork of a process that maps 30 GB of device memory stalls (1.4 frames/s). A prepared frame is kept until the consumer asks
+    for a frame two positions later (frame t is frame t+1's reference), so the same tensor OBJECT serves as `img` of frame t and
+    `ref_img` of frame t+1 - what the detector's prefetch / hand-off matching by tensor identity needs.
 
         feeder = ClipFeeder(files, prep, workers=4)
         outs = ClipShardRunner(DetectorBackend(model, H, W)).run(feeder, len(files))
         feeder.close()
     """
 
-    def __init__(self, files, prep, workers=4, ahead=None, processes=True):
-        import multiprocessing as mp
-        from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
+    def __init__(self, files, prep, workers=4, ahead=None):
+        from concurrent.futures import ThreadPoolExecutor
         self.files, self.prep = list(files), prep
         self.workers = int(workers)
         self.ahead = int(ahead) if ahead is not None else 2 * self.workers      # decoded frames in flight beyond the consumer
-        self.processes = bool(processes)
-        self._pool = ProcessPoolExecutor(self.workers, mp_context=mp.get_context('fork')) if self.processes else ThreadPoolExecutor(self.workers)
-        self._pending = {}          # t -> (future, shm block index or None)
+        self._pool = ThreadPoolExecutor(self.workers)
+        self._pending = {}          # t -> (future, staging slot)
         self._ready = {}            # t -> prepared device tensor [1,3,Hp,Wp]
-        self._pinned = None
         self._next = 0              # first index not yet submitted
         self.decodes = 0
-        self._blocks, self._free, self._nbytes = [], [], 0
-        if self.processes and self.files:
-            from multiprocessing import shared_memory
-            from PIL import Image
-            with Image.open(self.files[0]) as im:                                # header only: the frame size of the clip
-                w, h = im.size
-            self._nbytes = h * w * 3
-            self._blocks = [shared_memory.SharedMemory(create=True, size=self._nbytes) for _ in range(self.ahead + 2)]
-            self._free = list(range(len(self._blocks)))
+        self.stats = dict(wait_for_decode_s=0.0, upload_prep_s=0.0)      # where the consumer's time in __call__ went
+        self._stage, self._fbuf, self._free, self._events = [], [], [], []
 
     def __len__(self):
         return len(self.files)
 
-    def _submit(self, t):
-        if self.processes:
-            b = self._free.pop()
-            return (self._pool.submit(_decode_into_shm, self.files[t], self._blocks[b].name, self._nbytes), b)
-        return (self._pool.submit(imread, self.files[t]), None)
+    def _slots(self, nbytes):
+        """the staging ring: `ahead + 2` pinned frame buffers (plain host memory without a device) + as many file buffers"""
+        n = self.ahead + 2
+        pin = self.prep.device.type == 'cuda'
+        self._stage = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() if pin else torch.empty(nbytes, dtype=torch.uint8) for _ in range(n)]
+        self._fbuf = [bytearray(0) for _ in range(n)]
+        self._free = list(range(n))
+        self._events = [None] * n
+
+    def _decode(self, path, slot):
+        """worker thread: file -> staging slot; returns the frame's (H, W)"""
+        lib = hip.load_host()
+        size = osp.getsize(path)
+        if len(self._fbuf[slot]) < size:
+            self._fbuf[slot] = bytearray(size + (size >> 2))
+        buf = self._fbuf[slot]
+        with open(path, 'rb', buffering=0) as f:
+            n = f.readinto(memoryview(buf)[:size])
+        stage = self._stage[slot]
+        cbuf = (ctypes.c_char * len(buf)).from_buffer(buf)
+        H, W, C = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        if str(path).lower().endswith('.png') and lib.vps_png_info(cbuf, n, ctypes.byref(H), ctypes.byref(W), ctypes.byref(C)) == 0 \
+                and H.value * W.value * 3 <= stage.numel():
+            hip.check(lib.vps_png_decode_bgr8(cbuf, n, ctypes.c_void_p(stage.data_ptr()), stage.numel()), 'vps_png_decode_bgr8')
+            return H.value, W.value
+        img = imread(path)                         # the general decoder (cv2 / PIL) + one copy
+        assert img.nbytes <= stage.numel(), 'frame larger than the staging buffer (%d > %d bytes)' % (img.nbytes, stage.numel())
+        stage[:img.nbytes].copy_(torch.from_numpy(img).reshape(-1))
+        return img.shape[0], img.shape[1]
 
     def _submit_until(self, t_hi):
-        while self._next < min(t_hi, len(self.files)) and (not self.processes or self._free):
-            self._pending[self._next] = self._submit(self._next)
+        if not self._stage and self.files:
+            from PIL import Image
+            with Image.open(self.files[0]) as im:                                # header only: the frame size of the clip
+                w, h = im.size
+            self._slots(h * w * 3)
+        while self._next < min(t_hi, len(self.files)) and self._free:
+            slot = self._free.pop()
+            if self._events[slot] is not None:
+                self._events[slot].synchronize()                                  # the upload that last read this slot has finished
+                self._events[slot] = None
+            self._pending[self._next] = (self._pool.submit(self._decode, self.files[self._next], slot), slot)
             self._next += 1
+
+    def start(self, t=0):
+        """begin decoding the window that starts at frame t now (a loader in front of a running pipeline is `ahead` frames ahead)"""
+        self._next = max(self._next, t)
+        self._submit_until(t + 1 + self.ahead)
+        return self
 
     def meta(self, t):
         """img_meta entries of frame t that depend on the file (`Collect` keys of configs/cityscapes/fusetrack.py:190)"""
         return dict(filename=self.files[t])
 
     def __call__(self, t):
+        import time
         if t in self._ready:
             return self._ready[t]
         if t >= self._next:                       # random access (a shard that starts mid-clip): start the window there
@@ -207,50 +226,63 @@ class ClipFeeder:
         self._submit_until(t + 1 + self.ahead)
         ent = self._pending.pop(t, None)
         if ent is None:                           # not in the window (asked again after it was dropped, or behind it): decode it now
-            if self.processes and not self._free:
-                raise RuntimeError('ClipFeeder: frame %d requested outside the decode window with every staging block in flight' % t)
-            ent = self._submit(t)
-        fut, blk = ent
-        res = fut.result()
-        img = np.ndarray(res, dtype=np.uint8, buffer=self._blocks[blk].buf) if blk is not None else res
+            if not self._free:
+                raise RuntimeError('ClipFeeder: frame %d requested outside the decode window with every staging buffer in flight' % t)
+            slot = self._free.pop()
+            ent = (self._pool.submit(self._decode, self.files[t], slot), slot)
+        fut, slot = ent
+        c0 = time.perf_counter()
+        H, W = fut.result()
+        c1 = time.perf_counter()
+        self.stats['wait_for_decode_s'] += c1 - c0
         self.decodes += 1
+        src = self._stage[slot][:H * W * 3].view(H, W, 3)
         dev = self.prep.device
         if dev.type == 'cuda':
-            src = torch.from_numpy(img)
-            if self._pinned is None or self._pinned[0].shape != src.shape:
-                self._pinned = [torch.empty(src.shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
-                self._pin_ev = [None, None]
-            k = t & 1
-            if self._pin_ev[k] is not None:
-                self._pin_ev[k].synchronize()     # the upload that last used this staging buffer has finished
-            self._pinned[k].copy_(src)
-            d = self._pinned[k].to(dev, non_blocking=True)
+            d = src.to(dev, non_blocking=True)
             ev = torch.cuda.Event(); ev.record()
-            self._pin_ev[k] = ev
+            self._events[slot] = ev
         else:
-            d = np.array(img)                      # host stand-in (tests): own copy, the block goes back to the ring
+            d = src.numpy().copy()                 # host stand-in (tests): own copy, the slot goes back to the ring
         out = self.prep.prep(d)[0].unsqueeze(0)
-        if blk is not None:
-            del img
-            self._free.append(blk)
-            self._submit_until(t + 1 + self.ahead)
+        self.stats['upload_prep_s'] += time.perf_counter() - c1
+        self._free.append(slot)
+        self._submit_until(t + 1 + self.ahead)
         self._ready[t] = out
         for old in [k for k in self._ready if k < t - 1]:      # frame t-1 stays: it is frame t's reference
             del self._ready[old]
         return out
 
     def close(self):
-        for fut, blk in self._pending.values():
+        for fut, slot in self._pending.values():
             fut.cancel()
         self._pool.shutdown(wait=True)
-        for b in self._blocks:
-            b.close(); b.unlink()
-        self._blocks, self._free, self._pending = [], [], {}
+        self._pending = {}
 
 
-def imread(path):
+def png_decode(data):
+    """bytes of an 8-bit non-interlaced RGB / RGBA / grey PNG -> BGR uint8 [H,W,3] through the library's host decoder
+    (csrc/png_host.cpp: zlib inflate + un-filter, no interpreter lock while it runs); None for any other flavour"""
+    lib = hip.load_host()
+    buf = (ctypes.c_char * len(data)).from_buffer_copy(data) if not isinstance(data, (bytearray, memoryview)) else (ctypes.c_char * len(data)).from_buffer(data)
+    H, W, C = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    if lib.vps_png_info(buf, len(data), ctypes.byref(H), ctypes.byref(W), ctypes.byref(C)) != 0:
+        return None
+    out = np.empty((H.value, W.value, 3), dtype=np.uint8)
+    hip.check(lib.vps_png_decode_bgr8(buf, len(data), out.ctypes.data_as(ctypes.c_void_p), out.nbytes), 'vps_png_decode_bgr8')
+    return out
+
+
+def imread(path, native=True):
     """mmcv.imread(path) / cv2.imread(path, IMREAD_COLOR): uint8 [H,W,3] in BGR order; grey images are replicated to three
-    channels, an alpha channel is dropped"""
+    channels, an alpha channel is dropped. 8-bit PNGs (the Cityscapes-VPS frames) go through the library's own decoder, which
+    runs without the interpreter lock (decode threads scale beside a busy main thread); everything else through cv2 / PIL."""
+    if native and str(path).lower().endswith('.png'):
+        with open(path, 'rb') as f:
+            data = f.read()
+        img = png_decode(bytearray(data))
+        if img is not None:
+            return img
     try:
         import cv2                          # the reference's own decoder when the host has it
         img = cv2.imread(path, cv2.IMREAD_COLOR)
