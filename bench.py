@@ -78,9 +78,10 @@ def cpu_baseline(seed):
         torch.set_num_threads(old)
     med = statistics.median(small)
     return dict(value=round(1.0 / dt, 5), unit='frames/s', cores=cores, kind='port', n=1,
-                sample='1 real FuseTrack frame at %dx%d (the benched size), oracle/ on PyTorch-CPU fp32, %d threads, timed once: %.1f s; '
-                       'spread: 256x512 frame pair, 1 warm-up + 3 timed, median %.2f s (min %.2f max %.2f) = %.5f frames/s scaled by pixel count'
-                       % (H, W, cores, dt, med, min(small), max(small), (h * w) / float(H * W) / med))
+                sample='1 real FuseTrack frame at %dx%d (the benched size), oracle/ on PyTorch-CPU fp32, %d threads, timed once: %.1f s' % (H, W, cores, dt),
+                small_frame_spread=dict(size=[h, w], n=3, warmup=1, seconds=[round(v, 3) for v in small], median_s=round(med, 3),
+                                        frames_per_s_scaled_to_the_benched_size=round((h * w) / float(H * W) / med, 5),
+                                        note='run-to-run spread of the same oracle on a 256x512 frame pair (the full-size leg is timed once: ~45 s)'))
 
 
 class _TraceLib:
@@ -511,12 +512,15 @@ def main():
                     conv_ms_per_frame=round(ms, 3), avg_launch_us=round(1e3 * ms / max(nl, 1), 2))
         # HBM traffic of the conv kernels per frame: separate rocprofv3 --pmc passes (tools/pmc_traffic.py), not collectable from
         # inside this process; the newest committed measurement for this arithmetic mode is attached
-        for rnd in ('r03', 'r02', 'r01'):
+        for rnd in ('r04', 'r03', 'r02', 'r01'):
             pmc = os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s.json' % (rnd, args.prec))
             if os.path.exists(pmc):
-                roof['traffic'] = round(json.load(open(pmc))['conv_hbm_bytes_per_frame'])
+                pj = json.load(open(pmc))
+                roof['traffic'] = round(pj['conv_hbm_bytes_per_frame'])
                 roof['traffic_over_algorithmic'] = round(roof['traffic'] / max(abytes, 1), 3)
                 roof['traffic_source'] = 'profiles/' + os.path.basename(pmc) + ' (bytes per frame over all conv launches, like algorithmic_bytes_per_frame)'
+                # measured in a separate rocprofv3 pass, not in this run: say whether it was taken on the kernel sources this run uses
+                roof['traffic_measured_on_these_kernel_sources'] = (pj.get('csrc_sha16') == hip.csrc_sha16()) if pj.get('csrc_sha16') else 'unknown (measured before the stamp existed)'
                 break
         # every non-conv C-ABI launch of the instrumented frame, by symbol: [us per call] (HIP events, one stream)
         roof['in_frame_launch_us'] = {k: v for k, v in sorted(in_frame.items())}

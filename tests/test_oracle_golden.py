@@ -238,3 +238,52 @@ def test_separated_fullsize_oracle_matches_reference(sep_gold, sep_oracle_run):
         pan = r['panoptic_outputs'].numpy().astype(np.uint8); sem = r['fcn_outputs'].numpy().astype(np.uint8)
         assert (pan != g[p + 'panoptic_outputs']).mean() < 1e-4
         assert (sem != g[p + 'fcn_outputs']).mean() < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the DENSE strict fixture (round 4: tests/golden/search_dense.py -> dense_fc_cls.npz, chosen by oracle margins only;
+# make_golden.py fullsize_dense: the REAL reference on 6 frames at 1024x2048, 31..52 kept instances per frame, track ids past 170).
+# Frame 0 by default (~40 s of CPU), all six with VPS_SLOW_TESTS=1.
+# ---------------------------------------------------------------------------------------------------------------------
+def test_dense_fixture_margins_are_what_the_file_says():
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'dense_fc_cls.npz'))
+    m, req = z['margins'], z['required']              # per frame: detections, |score - 0.6| min, adjacent score gap min, |IoU - 0.5| min
+    assert m.shape == (6, 4) and (m[:, 0] >= 30).all() and m[0, 0] >= 50
+    assert m[:, 1].min() >= req[0] >= 1e-2 and m[:, 2].min() >= req[1] >= 2.5e-3 and m[:, 3].min() >= req[2] >= 2e-2
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'fusetrack_fullsize_dense.npz'))
+    kept = [len(g['f%d.panoptic_cls_inds' % t]) for t in range(6)]
+    ids = [g['f%d.panoptic_det_obj_ids' % t] for t in range(6)]
+    assert min(kept) >= 30 and max(int(i.max()) for i in ids) >= 60
+    # matched, lost and new objects in the real reference's own output: every later frame re-uses ids of earlier frames and opens new ones
+    seen = set(ids[0].tolist())
+    for t in range(1, 6):
+        cur = set(ids[t].tolist())
+        assert cur & seen and cur - seen, t
+        seen |= cur
+
+
+def test_dense_fullsize_oracle_matches_reference():
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'fusetrack_fullsize_dense.npz'))
+    H, W, n, seed = [int(v) for v in g['meta']]
+    ms = int(g['map_stride'])
+    assert (H, W, n) == (1024, 2048, 6)
+    n = n if os.environ.get('VPS_SLOW_TESTS') else 1
+    cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', 'fusetrack.py'))
+    model = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    over = synth.separated_overrides(os.path.join(ROOT, 'tests', 'golden', 'dense_fc_cls.npz'))
+    sd = synth.synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, seed, overrides=over)
+    o = FuseTrackOracle(sd)
+    frames = synth.synth_clip(H, W, n, seed)
+    prev = None
+    with torch.no_grad():
+        for t in range(n):
+            r = o.simple_test(frames[t], frames[t - 1] if t else frames[0], t == 0, ref_x=prev, return_aux=True)
+            prev = r['pre_neck']
+            p = 'f%d.' % t
+            assert np.array_equal(r['panoptic_cls_inds'].numpy(), g[p + 'panoptic_cls_inds'])
+            assert np.array_equal(r['panoptic_det_labels'].numpy(), g[p + 'panoptic_det_labels'])
+            assert np.array_equal(r['panoptic_det_obj_ids'].numpy(), g[p + 'panoptic_det_obj_ids'])
+            _close(r['panoptic_cls_prob'].numpy(), g[p + 'panoptic_cls_prob'], 1e-5, 1e-6)
+            pan = r['panoptic_outputs'].numpy().astype(np.uint8)[..., ::ms, ::ms]; sem = r['fcn_outputs'].numpy().astype(np.uint8)[..., ::ms, ::ms]
+            assert (pan != g[p + 'panoptic_outputs']).mean() < 1e-4
+            assert (sem != g[p + 'fcn_outputs']).mean() < 1e-4

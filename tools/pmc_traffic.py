@@ -28,7 +28,7 @@ def total(directory, counter, match):
 def main():
     fetch_dir, write_dir, frames = sys.argv[1], sys.argv[2], int(sys.argv[3])
     out = {'frames': frames, 'kernels': {}}
-    for name in ('conv_mfma_h8_kernel', 'conv_mfma_h8s2_kernel', 'conv_mfma_n16_kernel', 'conv_mfma_bf16h_kernel', 'conv_mfma_bf16p_kernel', 'conv_mfma_bf16s_kernel', 'conv_mfma_f32_kernel', 'conv_small3x3_kernel',
+    for name in ('conv_mfma_h8_kernel', 'conv_mfma_h8s2_kernel', 'conv_mfma_n16_kernel', 'conv_mfma_bf16h_kernel', 'conv_mfma_bf16p_kernel', 'conv_mfma_bf16q_kernel', 'conv_mfma_bf16s_kernel', 'conv_mfma_f32_kernel', 'conv_small3x3_kernel',
                  'conv_small_kernel', 'conv_splitk_reduce_kernel'):
         f, nf = total(fetch_dir, 'FETCH_SIZE', name)
         w, nw = total(write_dir, 'WRITE_SIZE', name)
@@ -37,6 +37,11 @@ def main():
                                     'write_bytes_per_frame': w * 1024 / frames,
                                     'raw': {'FETCH_SIZE_KiB_sum': f, 'fetch_dispatches': nf, 'WRITE_SIZE_KiB_sum': w, 'write_dispatches': nw}}
     out['conv_hbm_bytes_per_frame'] = sum(k['fetch_bytes_per_frame'] + k['write_bytes_per_frame'] for k in out['kernels'].values())
+    # which kernel sources this was measured on: bench.py attaches the newest committed measurement to its line and says whether the
+    # library it runs was built from the same sources (VERDICT r3 hygiene)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from vps_amd.hip import csrc_sha16
+    out['csrc_sha16'] = csrc_sha16()
     out['note'] = 'FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE as reported; Infinity-Cache hits are counted'
     print(json.dumps(out, indent=1))
 

@@ -68,6 +68,17 @@ class VpsHipError(RuntimeError):
     pass
 
 
+def csrc_sha16():
+    """sha256[:16] over the kernel sources of the library (csrc/*.hip, *.h, *.cpp, Makefile): stamps measurements with what they ran on"""
+    import glob
+    import hashlib
+    d = os.path.dirname(LIB_PATH)
+    hsh = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(d, '*.hip')) + glob.glob(os.path.join(d, '*.h')) + glob.glob(os.path.join(d, '*.cpp')) + [os.path.join(d, 'Makefile')]):
+        hsh.update(os.path.basename(fn).encode()); hsh.update(open(fn, 'rb').read())
+    return hsh.hexdigest()[:16]
+
+
 def load_host():
     """the handle whose calls release the interpreter lock: the host-side functions (PNG decode) that decode threads run in parallel"""
     load()
