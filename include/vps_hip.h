@@ -117,6 +117,11 @@ typedef struct vps_conv_desc {
      * tiles = ceil(M/128) * cout_pad/tile_n for the pipelined kernels; the halo kernels tile in 8x16 / 8x32 patches:
      * N * ceil(Qh/8) * ceil(Qw/16) * cout_pad/tile_n is an upper bound for all of them. */
     int32_t* tile_counter;
+    /* VPS_PREC_F16X3, optional: the weights of a thin-input layer (cin_pad 4 / 8 / 12, cout_pad 64, KH == KW, korder 0) in the packing
+     * of the thin-input kernel (csrc/conv_thin.hip): fp16 [KH][plane 0..1][ceil(KW*cin_pad/16)][cout/32][lane = 32*(k/8 % 2) + cout % 32][8],
+     * k = position within one kernel ROW's KW*cin_pad values (tap-major, zero-padded to a multiple of 16), same per-channel scaling
+     * as w_split. NULL, or a shape the kernel has no instance for: the launch uses w_split. */
+    const void* w_thin;
 } vps_conv_desc;
 
 int vps_conv2d(const vps_conv_desc* d, void* stream);

@@ -5,8 +5,9 @@ container, with the import shims of ref_shims.py (third-party stubs + oracle-bac
     python tests/golden/make_golden.py [fusetrack|fuse|track]   # needs /root/reference; writes tests/golden/<variant>_clip.npz
     python tests/golden/make_golden.py fullsize                  # 2 frames at 1024x2048 -> tests/golden/fusetrack_fullsize.npz
     python tests/golden/make_golden.py fullsize_sep              # 4 frames at 1024x2048, fitted well-separated box classifier (strict fixture)
-    python tests/golden/make_golden.py fullsize_dense            # 6 frames at 1024x2048, fitted dense box classifier (40..100 detections per frame, strict)
+    python tests/golden/make_golden.py fullsize_dense            # 6 frames at 1024x2048, fitted dense box classifier (32..53 detections per frame, strict)
     python tests/golden/make_golden.py r101                      # ResNet-101 variant (BASELINE config 5), 2 frames at 128x256
+    python tests/golden/make_golden.py config5_sep               # ResNet-101 at 1088x1920, 3 frames, fitted box classifier (strict fixture of config 5)
     python tests/golden/make_golden.py seed1                     # FuseTrack, weight / clip seed 1, 3 frames at 128x192
 
 The reference cannot travel to the GPU box; the vectors do. tests/test_oracle_golden.py checks the oracle against them
@@ -154,11 +155,15 @@ if __name__ == '__main__':
         # the STRICT full-size fixture: 4 frames at 1024x2048, well-separated detections (tests/golden/separated_fc_cls.npz)
         main('fusetrack', FULL_H, FULL_W, 4, 'fusetrack_fullsize_sep.npz', full=True, separated=True)
     elif v == 'fullsize_dense':
-        # the DENSE strict fixture: 6 frames at 1024x2048, 40..100 well-separated detections per frame (tests/golden/search_dense.py ->
+        # the DENSE strict fixture: 6 frames at 1024x2048, 32..53 well-separated detections per frame (tests/golden/search_dense.py ->
         # dense_fc_cls.npz, chosen by oracle margins only)
         main('fusetrack', FULL_H, FULL_W, 6, 'fusetrack_fullsize_dense.npz', full=True, separated=True, head='dense_fc_cls.npz', map_stride=2)
     elif v == 'r101':
         main('fusetrack', H, W, 2, 'fusetrack_r101_clip.npz', depth=101)
+    elif v == 'config5_sep':
+        # BASELINE config 5, strict: the ResNet-101 model on 3 frames at 1088x1920 with the fitted classification layer of
+        # VPS_SEP_CONFIG5=1 search_separated.py (config5_fc_cls.npz, chosen by oracle margins only)
+        main('fusetrack', 1088, 1920, 3, 'fusetrack_config5_sep.npz', full=True, separated=True, head='config5_fc_cls.npz', depth=101, map_stride=2)
     elif v == 'seed1':
         main('fusetrack', 128, 192, 3, 'fusetrack_clip_seed1.npz', seed=1)      # second weight / clip seed, another aspect ratio
     else:

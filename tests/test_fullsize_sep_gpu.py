@@ -29,9 +29,15 @@ REPORT = os.path.join(ROOT, 'gpurun_out', 'fullsize_sep_report.txt')
 # round 4: the DENSE strict fixture - 6 frames, 32..53 detections per frame (31..52 kept), track ids past 170, chosen by oracle margins
 # only (tests/golden/search_dense.py; margins stored in dense_fc_cls.npz: threshold >= 1e-2, kept-score gap >= 2.5e-3, NMS IoU >= 2e-2
 # from 0.5 against a measured score error <= 9e-4); golden from the REAL reference (make_golden.py fullsize_dense), maps at stride 2
+# config5: BASELINE config 5 made strict the same way - the ResNet-101 model (configs/viper/fusetrack_r101.py) on 3 frames at 1088x1920,
+# bbox_head.fc_cls fitted by VPS_SEP_CONFIG5=1 search_separated.py (first trial that passes the oracle's margin filter: threshold >= 4.3e-2,
+# kept-score gap >= 2.7e-2, NMS IoU >= 0.25 from 0.5), golden from the REAL reference built with depth=101 (make_golden.py config5_sep)
 FIXTURES = {
-    'separated': (GOLD, HEAD, 4),
-    'dense': (os.path.join(ROOT, 'tests', 'golden', 'fusetrack_fullsize_dense.npz'), os.path.join(ROOT, 'tests', 'golden', 'dense_fc_cls.npz'), 6),
+    'separated': (GOLD, HEAD, 4, (1024, 2048), os.path.join('configs', 'cityscapes', 'fusetrack.py')),
+    'dense': (os.path.join(ROOT, 'tests', 'golden', 'fusetrack_fullsize_dense.npz'), os.path.join(ROOT, 'tests', 'golden', 'dense_fc_cls.npz'), 6,
+              (1024, 2048), os.path.join('configs', 'cityscapes', 'fusetrack.py')),
+    'config5': (os.path.join(ROOT, 'tests', 'golden', 'fusetrack_config5_sep.npz'), os.path.join(ROOT, 'tests', 'golden', 'config5_fc_cls.npz'), 3,
+                (1088, 1920), os.path.join('configs', 'viper', 'fusetrack_r101.py')),
 }
 
 
@@ -39,19 +45,19 @@ def _rel(a, b):
     return float(np.abs(np.asarray(a, np.float64) - b).max() / max(float(np.abs(b).max()), 1e-12))
 
 
-@pytest.mark.parametrize('fixture', ['separated', 'dense'])
+@pytest.mark.parametrize('fixture', ['separated', 'dense', 'config5'])
 @pytest.mark.parametrize('prec_name', ['f16x3', 'bf16x6', 'f32'])
 def test_strict_full_size_parity_on_the_separated_fixture(dev, prec_name, fixture):
-    gold, head, nfr = FIXTURES[fixture]
+    gold, head, nfr, hw, cfg_path = FIXTURES[fixture]
     g = np.load(gold)
     H, W, n, seed = [int(v) for v in g['meta']]
     s1, s2, c5 = [int(v) for v in g['strides']]
     ms = int(g['map_stride']) if 'map_stride' in g.files else 1
-    assert (H, W, n) == (1024, 2048, nfr)
+    assert (H, W, n) == (hw[0], hw[1], nfr)
     old = nhwc.DEFAULT_PREC
     nhwc.DEFAULT_PREC = nhwc.PREC_NAMES[prec_name]
     try:
-        cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', 'fusetrack.py'))
+        cfg = vps_amd.Config.fromfile(os.path.join(ROOT, cfg_path))
         m = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
         synth.load_synth(m, seed, overrides=synth.separated_overrides(head))
         m.ensure_packed(dev)
@@ -91,8 +97,13 @@ def test_strict_full_size_parity_on_the_separated_fixture(dev, prec_name, fixtur
         # f32 frame 1 0.26 %, f16x3 frame 2 0.19 %, bf16x6 <= 0.08 %) - one or two of the 31..52 instances of some frame come out with a
         # boundary strip of differing pixels (instance <-> the stuff class around it, a few hundred pixels each way; score differences of
         # 1e-3 on that frame), listing and ids unchanged. Bound for it: 0.5 % of the pixels, the pairs are printed.
-        assert dprob < 2e-3 and dpan < (5e-3 if fixture == 'dense' else 1e-3) and dsem < 1e-3, lines[-1]
-        assert all(v < 2e-3 for v in stage.values()), lines[-1]
+        # config5: the 101-layer synthetic network amplifies fp32 summation-order differences ~5x more than the 50-layer one - in the
+        # EXACT-fp32 kernels as much as in the split modes (profiles/r04_fullsize_config5_strict_report.txt: head inputs 0.9 .. 2.4e-3,
+        # semantic logits 4.6 .. 7.3e-3 of max|ref|, scores 4 .. 6e-3 in f32 / f16x3 / bf16x6) - so its fixture was fitted with margins of
+        # 4.3e-2 / 2.7e-2 and is compared within 1e-2; the listing is strict all the same
+        tol = 1e-2 if fixture == 'config5' else 2e-3
+        assert dprob < tol and dpan < (1e-3 if fixture == 'separated' else 5e-3) and dsem < 1e-3, lines[-1]
+        assert all(v < tol for v in stage.values()), lines[-1]
     if fixture == 'dense':
         ids = np.concatenate([g['f%d.panoptic_det_obj_ids' % t] for t in range(n)])
         assert min(len(g['f%d.panoptic_cls_inds' % t]) for t in range(n)) >= 20 and int(ids.max()) >= 59, 'the dense fixture is dense'

@@ -79,6 +79,12 @@ CONV_CASES = [
     (64, 10, 3, 1, 1, 136, 520, 'relu', True, True),
     # 64 output channels on a map with >= 256 patches of 8x32 (where a 64-column 8-wave instance was tried and dropped): overhanging patches, residual
     (96, 64, 3, 1, 1, 130, 520, 'relu', True, True),
+    # thin-input layers on >= 512 patches: the thin-input kernel (csrc/conv_thin.hip) in f16x3 - all four instances, overhanging patches,
+    # BN + residual epilogue on one of them (the ResNet stem has BN + ReLU)
+    (6, 64, 3, 1, 1, 250, 530, 'leaky', False, False),
+    (11, 64, 3, 1, 1, 256, 512, 'leaky', True, False),
+    (3, 64, 7, 2, 3, 500, 1050, 'relu', True, False),
+    (12, 64, 7, 2, 3, 250, 1100, 'leaky', False, False),
 ]
 
 

@@ -156,3 +156,74 @@ def test_n16_weight_fragment_gather_from_the_common_packed_layout():
                     want = torch.stack([nat[p, c, int(l & 15), 32 * s + 8 * int(grp[l]):32 * s + 8 * int(grp[l]) + 8] for l in lanes])
                     assert torch.equal(frag, want), (transposed, s, p, c)
         assert float(nat[:, :, 16:].abs().max()) == 0.0       # channels 16..31 of the padded block are zero: one 16-row block suffices
+
+
+@pytest.mark.parametrize('cin,k,stride,PH', [(6, 3, 1, 8), (11, 3, 1, 8), (3, 7, 2, 8), (12, 7, 2, 4)], ids=['6to64_3x3', '11to64_3x3', '3to64_7x7s2', '12to64_7x7s2'])
+def test_thin_kernel_indexing_reproduces_the_convolution(cin, k, stride, PH):
+    """csrc/conv_thin.hip on the CPU: the block's input patch staged pixel-major with cin_pad channels per pixel, the k order (kernel
+    row j, position within the row's KS*C4 consecutive values, padded to 16), the lane's 8-k fragment = 8 consecutive staged values
+    at (row*S + j, column*S), the weight fragment gathered from `PackedConv.w_thin` exactly as the kernel indexes it, the padding k of
+    a row reading the NEXT pixels' values against zero weights - with both operands split as in f16x3 - against the float64 conv."""
+    S, KS, cout = stride, k, 64
+    g = torch.Generator().manual_seed(cin + k)
+    H, W = 21, 45                                             # patches overhang right and bottom; 2 x 2 (x 3 for PH = 4) blocks
+    x = torch.randn(1, cin, H, W, generator=g) * torch.logspace(-1, 1, cin).view(1, cin, 1, 1)
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5 * torch.logspace(-2, 1, cout).view(cout, 1, 1, 1)
+    pc = nhwc.PackedConv(w, None, None, stride, k // 2, device=torch.device('cpu'), prec=hip.PREC_F16X3)
+    assert pc.w_thin is not None and pc.korder == 0
+    C4 = pc.cin_pad
+    RL = KS * C4
+    NK16 = (RL + 15) // 16
+    assert tuple(pc.w_thin.shape) == (KS, 2, NK16, 2, 2, 32, 8)
+    wt = pc.w_thin.double().reshape(KS, 2, NK16, 2, 64, 8)                      # [j][plane][s][nb][lane][e]
+    g0, g1 = wt[:, 0], wt[:, 1]
+    g2 = (g0 * 2.0 ** -11).to(torch.float16).double()                           # derive_weight_plane
+    wpl = [g0, g1, g2]
+    Ho, Wo = pc.out_hw(H, W)
+    pad = k // 2
+    PR, PC = (PH - 1) * S + KS, 31 * S + KS
+    TM = PH // 4
+    xa = torch.zeros(1, C4, H, W); xa[:, :cin] = x
+    xs = split_act(xa, hip.PREC_F16X3)                                          # planes h0, h1 [1][C4][H][W]
+    y = torch.zeros(cout, Ho, Wo, dtype=torch.float64)
+    lane = torch.arange(64)
+    p32, kh = lane & 31, lane >> 5
+    for ty in range((Ho + PH - 1) // PH):
+        for tx in range((Wo + 31) // 32):
+            iy0, ix0 = ty * PH * S - pad, tx * 32 * S - pad
+            As = []
+            for pl in range(2):
+                a = torch.zeros(PR * PC * C4 + 16, dtype=torch.float64)
+                for r in range(PR):
+                    for c in range(PC):
+                        iy, ix = iy0 + r, ix0 + c
+                        if 0 <= iy < H and 0 <= ix < W:
+                            a[(r * PC + c) * C4:(r * PC + c + 1) * C4] = xs[pl][0, :, iy, ix]
+                As.append(a)
+            for wave in range(4):
+                for a_ in range(TM):
+                    acc = torch.zeros(2, 32, 32, dtype=torch.float64)          # [nb][cout % 32][pixel]
+                    for j in range(KS):
+                        for s in range(NK16):
+                            base = (((wave * TM + a_) * S + j) * PC + p32 * S) * C4 + s * 16 + kh * 8        # per lane
+                            idx = base[:, None] + torch.arange(8)[None]
+                            af = [As[0][idx], As[1][idx]]                       # [lane][8]
+                            for pa, pb in zip(PA[hip.PREC_F16X3], PB[hip.PREC_F16X3]):
+                                for nb in range(2):
+                                    wf = wpl[pb][j, s, nb]                      # [lane][8]: lane = 32 * kh + cout % 32
+                                    # D[co][px] += sum over the two k halves and the 8 values of a lane
+                                    for h in range(2):
+                                        acc[nb] += wf[32 * h:32 * h + 32] @ af[pa][32 * h:32 * h + 32].t()
+                    oy = ty * PH + wave * TM + a_
+                    if oy >= Ho:
+                        continue
+                    for px in range(32):
+                        ox = tx * 32 + px
+                        if ox < Wo:
+                            y[:, oy, ox] = acc[:, :, px].reshape(64)
+    y = y * pc.scale.double().view(-1, 1, 1)
+    ref = F.conv2d(x.double(), w.double(), stride=stride, padding=pad)[0]
+    den = F.conv2d(x.double().abs(), w.double().abs(), stride=stride, padding=pad)[0]
+    rel = float(((y - ref).abs() / den).max())
+    print('thin %s: max |err| / sum|x||w| = %.3e' % ((cin, k, stride, PH), rel))
+    assert rel <= BOUND[hip.PREC_F16X3]

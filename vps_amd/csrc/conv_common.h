@@ -63,13 +63,16 @@ __device__ __forceinline__ void decode_tile(const vps_conv_desc& d, int swz, con
 // GN: the sums the GroupNorm behind this conv needs (vps_conv_desc.gn_stats) are taken from the values as they are stored
 // EXTFLAG: the last-block flag of the split-K reduction lives in LDS the CALLER owns (`ext_flag`; a kernel that uses the whole LDS
 // budget of its occupancy target cannot afford the 4 static bytes)
-template <int TM, int TN, int BN, bool TILE2D = false, int PWL = 4, bool GN = false, bool EXTFLAG = false>
+// PHL = log2 of the patch height of a TILE2D block (8 rows everywhere but in the 4-row instance of the thin-input kernel)
+// RES = false: the caller guarantees d.res == NULL (the residual registers are not allocated)
+template <int TM, int TN, int BN, bool TILE2D = false, int PWL = 4, bool GN = false, bool EXTFLAG = false, int PHL = 3, bool RES = true>
 __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&acc)[TM][TN], const int M, const int tile_m,
                                               const int tile_n, const int cls, const int split, const int py, const int px,
                                               const int wm, const int wn, const int lane, const int tile_lin, int* ext_flag = nullptr) {
     const int prow = lane & 31;
     const int cq = 4 * (lane >> 5);
     const int cbase = tile_n * BN + wn * TN * 32 + cq;       // + b*32 + 8*g: first of this lane's 4 channels
+    const float* const d_res = RES ? d.res : nullptr;
 
     // ---- one output position per sub-tile a. Rows past the end are clamped to a valid position and not stored.
     size_t opix[TM], rpix[TM];
@@ -78,9 +81,9 @@ __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&a
     {
         int t2_n = 0, t2_y0 = 0, t2_x0 = 0;
         if constexpr (TILE2D) {
-            const int tiles_x = (d.Qw + (1 << PWL) - 1) >> PWL, tiles_y = (d.Qh + 7) >> 3;
+            const int tiles_x = (d.Qw + (1 << PWL) - 1) >> PWL, tiles_y = (d.Qh + (1 << PHL) - 1) >> PHL;
             const int tx = tile_m % tiles_x, tq = tile_m / tiles_x;
-            t2_x0 = tx << PWL; t2_y0 = (tq % tiles_y) * 8; t2_n = tq / tiles_y;
+            t2_x0 = tx << PWL; t2_y0 = (tq % tiles_y) << PHL; t2_n = tq / tiles_y;
         }
         const bool simple_pix = !TILE2D && (d.nclass == 1 && d.os_y == 1 && d.os_x == 1 && d.res_shift == 0);
 #pragma unroll
@@ -179,12 +182,12 @@ __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&a
     }
 
     const bool vec = !((d.cout | d.out_ld | d.out_coff) & 3) && !((uintptr_t)d.out & 15) &&
-                     (!d.res || (!((d.res_ld | d.res_coff) & 3) && !((uintptr_t)d.res & 15)));
+                     (!d_res || (!((d.res_ld | d.res_coff) & 3) && !((uintptr_t)d_res & 15)));
     if (vec) {
         // residual: all TM*TN*4 float4 values are requested (branch-free, clamped) before the first one is used. A load that
         // sits behind `if (row valid) if (column valid)` gets an s_waitcnt vmcnt(0) of its own.
         f32x4 rv[TM][TN][4];
-        if (d.res) {
+        if (d_res) {
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -192,19 +195,30 @@ __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&a
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int cc = min(cbase + b * 32 + 8 * g, d.cout - 4);
-                        rv[a][b][g] = *reinterpret_cast<const f32x4*>(d.res + rpix[a] * d.res_ld + d.res_coff + cc);
+                        rv[a][b][g] = *reinterpret_cast<const f32x4*>(d_res + rpix[a] * d.res_ld + d.res_coff + cc);
                     }
         }
+        // scale / shift of ALL channel groups are requested here too, before the first store. Loaded group by group between the stores
+        // (as this loop did until round 4) every group's `s_waitcnt vmcnt(0)` for its two loads also waited for the stores of the group
+        // before it - memory operations retire in order - i.e. 4 * TN serialised store round trips per tile: the thin-input layers
+        // spent 15 of 17 us per tile there (found in the ISA of conv_thin.hip; tools/storebench: the same store pattern alone runs at 4.9 TB/s)
+        f32x4 scv[TN][4], shv[TN][4];
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cc = min(cbase + b * 32 + 8 * g, d.cout - 4);
+                scv[b][g] = f32x4{1.f, 1.f, 1.f, 1.f}; shv[b][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (d.scale) scv[b][g] = *reinterpret_cast<const f32x4*>(d.scale + cc);
+                if (d.shift) shv[b][g] = *reinterpret_cast<const f32x4*>(d.shift + cc);
+            }
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int co = cbase + b * 32 + 8 * g;
                 const bool cok = co < d.cout;                    // cout % 4 == 0: a group is valid or invalid as a whole
-                const int cc = min(co, d.cout - 4);
-                f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-                if (d.scale) sc = *reinterpret_cast<const f32x4*>(d.scale + cc);
-                if (d.shift) sh = *reinterpret_cast<const f32x4*>(d.shift + cc);
+                const f32x4 sc = scv[b][g], sh = shv[b][g];
                 float gs = 0.f, gq = 0.f;
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {
@@ -213,7 +227,7 @@ __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&a
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float t = acc[a][b][4 * g + e] * sc[e] + sh[e];
-                        if (d.res) t += rv[a][b][g][e];
+                        if (d_res) t += rv[a][b][g][e];
                         v[e] = vps_act(t, d.act, d.slope);
                         if constexpr (GN) { gs += v[e]; gq += v[e] * v[e]; }
                     }
@@ -255,7 +269,7 @@ __device__ __forceinline__ void conv_epilogue(const vps_conv_desc& d, f32x16 (&a
                 const float sh = d.shift ? d.shift[cc] : 0.f;
                 float rvs[TM];
 #pragma unroll
-                for (int a = 0; a < TM; ++a) rvs[a] = d.res ? d.res[rpix[a] * d.res_ld + d.res_coff + cc] : 0.f;
+                for (int a = 0; a < TM; ++a) rvs[a] = d_res ? d_res[rpix[a] * d.res_ld + d.res_coff + cc] : 0.f;
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {
                     if (!inside[a] || !cok) continue;

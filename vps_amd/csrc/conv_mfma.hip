@@ -25,6 +25,7 @@
 #include "conv_common.h"
 
 int vpsi_launch_conv_q(const vps_conv_desc& d, int M, int tiles_m, int tiles_n, int per_split, long nblk, bool tapmajor, hipStream_t s);
+int vpsi_launch_conv_thin(const vps_conv_desc& d, hipStream_t s);
 
 
 namespace {
@@ -2119,6 +2120,8 @@ extern "C" int vps_conv2d(const vps_conv_desc* dp, void* stream) {
         else hipLaunchKernelGGL((conv_small_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, s, d, M, G, logG);
         return vps_launch_status();
     }
+    // thin-input layers at full resolution (3 / 6 / 11 / 12 -> 64 channels) with their own weight packing: conv_thin.hip
+    if (d.w_thin && vpsi_launch_conv_thin(d, s)) return vps_launch_status();
     // wave arrangement <TM, TN, WAVES_M, WAVES_N> of the 4 waves of a block. Weight fragments come from global memory (one 1 KB
     // load per fragment = 64 cycles of the CU's vector-memory pipe, tools/gapbench.hip), activation fragments from LDS (two
     // conflict-free 1 KB reads per 32 cycles are free). Measured per layer (profiles/r02_wave_arrangement_ab.txt): for 64-column

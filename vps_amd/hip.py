@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VPS_HIP_LIB: developer override to load an experimental build of the same ABI (kernel A/B timing)
 LIB_PATH = os.environ.get('VPS_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libvpship.so')
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
@@ -47,7 +47,7 @@ class ConvDesc(Structure):
         ('offset', c_void_p), ('off_ld', c_int32),
         ('tile_n', c_int32), ('ksplit', c_int32), ('ws', c_void_p),
         ('prec', c_int32), ('w_split', c_void_p), ('korder', c_int32), ('status', c_void_p),
-        ('gn_stats', c_void_p), ('gn_cpg', c_int32), ('gn_rep', c_int32), ('tile_counter', c_void_p),
+        ('gn_stats', c_void_p), ('gn_cpg', c_int32), ('gn_rep', c_int32), ('tile_counter', c_void_p), ('w_thin', c_void_p),
     ]
 
 

@@ -85,6 +85,7 @@ SPLITK_LAST_BLOCK = os.environ.get('VPS_SPLITK_LAST_BLOCK', '0') == '1'
 # 1: the 3x3 narrow-output layers with >= 64 input channels on large maps run on the MFMA tile kernel (a second packed copy). It won
 # against the first vector kernel (predict_flow2 0.133 -> 0.080 ms); the round-3 vector kernel does 0.059 ms in exact fp32: default off.
 SMALL_ON_MFMA = os.environ.get('VPS_SMALL_MFMA', '0') != '0'
+THIN_KERNEL = os.environ.get('VPS_THIN', '1') != '0'      # thin-input layers (cin_pad <= 12 -> 64) get the packing of csrc/conv_thin.hip too
 GN_REP = 32   # copies of the GroupNorm sums a conv epilogue spreads its atomics over (vps_conv_desc.gn_rep)
 
 
@@ -173,6 +174,17 @@ def from_nchw(x, ws=None, name=None, Cpad=None):
 # ------------------------------------------------------------------------------------------------------------
 # packed convolution
 # ------------------------------------------------------------------------------------------------------------
+def pack_thin(g, KS, C4):
+    """g: fp16 [2 planes][64][kpad], k = (j*KS + i)*C4 + c (tap-major) -> the packing of csrc/conv_thin.hip (vps_conv_desc.w_thin):
+    [KS kernel rows][plane][ceil(KS*C4/16)][cout/32][lane = 32*(k/8 % 2) + cout % 32][8], k = i*C4 + c within the row, zero-padded"""
+    RL = KS * C4
+    nk = (RL + 15) // 16
+    w = torch.zeros(2, 64, KS, nk * 16, dtype=g.dtype, device=g.device)
+    w[..., :RL] = g[:, :, :KS * RL].reshape(2, 64, KS, RL)
+    # [pl][nb][32][KS][nk][kh][8] -> [KS][pl][nk][nb][kh][32][8]
+    return w.view(2, 2, 32, KS, nk, 2, 8).permute(3, 0, 4, 1, 5, 2, 6).contiguous()
+
+
 def _tile_n(cout):
     return 32 if cout <= 32 else (64 if cout <= 64 else 128)
 
@@ -329,6 +341,10 @@ class PackedConv:
                 planes.append(h)
                 r = r - h.float()
         ws = torch.stack(planes, 0)                     # [planes][class][cout_pad][kpad]
+        self.w_thin = None
+        if (THIN_KERNEL and self.prec == hip.PREC_F16X3 and not self.deform and not self.transposed and self.korder == 0 and self.KH == self.KW
+                and self.KH in (3, 7) and self.cin_pad in (4, 8, 12) and self.cout_pad == 64 and self.tile_n == 64):
+            self.w_thin = pack_thin(ws[:2, 0], self.KH, self.cin_pad)
         if not (self.deform and self.korder == 0):
             # MFMA-fragment order for the direct-to-register weight path (every kernel but the two-barrier deformable one, which
             # only takes the tap-major deformable layers - none on the path):
@@ -404,6 +420,8 @@ class PackedConv:
             d.w = self.w.data_ptr()
         else:
             d.w_split = self.w_split.data_ptr()
+            if getattr(self, 'w_thin', None) is not None and self.prec == hip.PREC_F16X3:
+                d.w_thin = self.w_thin.data_ptr()
         d.cout, d.cout_pad, d.kpad = self.cout, self.cout_pad, self.kpad
         d.KH, d.KW, d.stride = self.KH, self.KW, self.stride
         d.pad_y[0], d.pad_y[1] = self.pad_y; d.pad_x[0], d.pad_x[1] = self.pad_x

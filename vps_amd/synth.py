@@ -100,9 +100,14 @@ def synth_state_dict(shapes, seed=0, prefix='', overrides=None):
 
 
 def separated_overrides(path):
-    """-> overrides dict of the fitted, well-separated box classification layer stored at `path` (.npz: weight, bias)"""
+    """-> overrides dict of the fitted, well-separated box classification layer stored at `path` (.npz: weight, bias) plus any other
+    state_dict tensor the file carries under its key (config5_fc_cls.npz: the rescaled `rpn_head.rpn_cls.*`)"""
     z = np.load(path)
-    return {'bbox_head.fc_cls.weight': torch.from_numpy(z['weight']), 'bbox_head.fc_cls.bias': torch.from_numpy(z['bias'])}
+    out = {'bbox_head.fc_cls.weight': torch.from_numpy(z['weight']), 'bbox_head.fc_cls.bias': torch.from_numpy(z['bias'])}
+    for k in z.files:
+        if k.endswith('.weight') or k.endswith('.bias'):
+            out[k] = torch.from_numpy(z[k])
+    return out
 
 
 def load_synth(model, seed=0, overrides=None):
