@@ -504,7 +504,7 @@ def main():
         nprod = nhwc.MFMA_PRODUCTS[nhwc.PREC_NAMES[args.prec]]
         pipe_peak = PEAK_FP32_MFMA_TFLOPS if args.prec == 'f32' else PEAK_BF16_MFMA_TFLOPS
         peak = pipe_peak / nprod
-        roof = dict(bound='mfma', kernel='conv_mfma_f32_kernel' if args.prec == 'f32' else 'conv_mfma_bf16{h,p,s}_kernel<%s> (vps_conv2d family)' % args.prec,
+        roof = dict(bound='mfma', kernel='conv_mfma_f32_kernel' if args.prec == 'f32' else 'conv_mfma_{h8,h8s2,bf16h,bf16q,bf16p,n16}_kernel + conv_thin_kernel <%s> (vps_conv2d family)' % args.prec,
                     achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
                     mfma_products_per_fp32_product=nprod, matrix_pipe_executed_tflops=round(ach * nprod, 1),
                     matrix_pipe_peak=pipe_peak, matrix_pipe_frac=round(ach * nprod / pipe_peak, 4),

@@ -100,9 +100,10 @@ def test_strict_full_size_parity_on_the_separated_fixture(dev, prec_name, fixtur
         # config5: the 101-layer synthetic network amplifies fp32 summation-order differences ~5x more than the 50-layer one - in the
         # EXACT-fp32 kernels as much as in the split modes (profiles/r04_fullsize_config5_strict_report.txt: head inputs 0.9 .. 2.4e-3,
         # semantic logits 4.6 .. 7.3e-3 of max|ref|, scores 4 .. 6e-3 in f32 / f16x3 / bf16x6) - so its fixture was fitted with margins of
-        # 4.3e-2 / 2.7e-2 and is compared within 1e-2; the listing is strict all the same
+        # 4.3e-2 / 2.7e-2 and is compared within 1e-2 (maps: 1 % - the boundary strip of ONE large instance was 0.6 % of the map in bf16x6
+        # frame 0, 0.05 .. 0.3 % elsewhere, f32 included); the listing is strict all the same
         tol = 1e-2 if fixture == 'config5' else 2e-3
-        assert dprob < tol and dpan < (1e-3 if fixture == 'separated' else 5e-3) and dsem < 1e-3, lines[-1]
+        assert dprob < tol and dpan < {'separated': 1e-3, 'dense': 5e-3, 'config5': 1e-2}[fixture] and dsem < 1e-3, lines[-1]
         assert all(v < tol for v in stage.values()), lines[-1]
     if fixture == 'dense':
         ids = np.concatenate([g['f%d.panoptic_det_obj_ids' % t] for t in range(n)])

@@ -28,7 +28,7 @@ def total(directory, counter, match):
 def main():
     fetch_dir, write_dir, frames = sys.argv[1], sys.argv[2], int(sys.argv[3])
     out = {'frames': frames, 'kernels': {}}
-    for name in ('conv_mfma_h8_kernel', 'conv_mfma_h8s2_kernel', 'conv_mfma_n16_kernel', 'conv_mfma_bf16h_kernel', 'conv_mfma_bf16p_kernel', 'conv_mfma_bf16q_kernel', 'conv_mfma_bf16s_kernel', 'conv_mfma_f32_kernel', 'conv_small3x3_kernel',
+    for name in ('conv_mfma_h8_kernel', 'conv_mfma_h8s2_kernel', 'conv_mfma_n16_kernel', 'conv_mfma_bf16h_kernel', 'conv_mfma_bf16p_kernel', 'conv_mfma_bf16q_kernel', 'conv_thin_kernel', 'conv_mfma_bf16s_kernel', 'conv_mfma_f32_kernel', 'conv_small3x3_kernel',
                  'conv_small_kernel', 'conv_splitk_reduce_kernel'):
         f, nf = total(fetch_dir, 'FETCH_SIZE', name)
         w, nw = total(write_dir, 'WRITE_SIZE', name)

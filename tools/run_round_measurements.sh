@@ -1,36 +1,40 @@
 # The judged measurement set of a round in one gpurun call (writes gpurun_out/; copy what is to be judged into profiles/).
-#   gpurun --timeout 2400 -- 'bash tools/run_round_measurements.sh'          SKIP_PYTEST=1 skips the GPU test suite
-mkdir -p gpurun_out; R=$PWD; T=${TAG:-r03}
-if [ -z "$SKIP_PYTEST" ]; then python -m pytest tests -m gpu -q --tb=short -rf -p no:cacheprovider > gpurun_out/${T}_pytest_gpu.log 2>&1; tail -6 gpurun_out/${T}_pytest_gpu.log; fi
-python bench.py --steps 20 --warmup 5 --conv-table gpurun_out/${T}_conv_table_f16x3.txt > gpurun_out/${T}_bench_default_f16x3.json 2> gpurun_out/${T}_bench.err; head -c 200 gpurun_out/${T}_bench_default_f16x3.json; echo
-python bench.py --model-config configs/viper/fusetrack_r101.py --height 1088 --width 1920 --prec f16x3 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/${T}_bench_config5_r101_1088x1920_f16x3.json 2>> gpurun_out/${T}_bench.err; head -c 200 gpurun_out/${T}_bench_config5_r101_1088x1920_f16x3.json; echo
+#   gpurun --timeout 1500 -- 'bash tools/run_round_measurements.sh'
+#   SKIP_PYTEST=1 skips the GPU test suite (run it in its own call: it takes ~10 of the 90 GPU-minutes), WITH_VPQ=1 adds the two
+#   60-frame VPQ runs (profiles/r04_vpq_attribution.json holds this round's numbers from tools/vpq_attribution.py)
+# Every command sits under its own `timeout`: a hung counter pass must not take the rest of the call with it.
+mkdir -p gpurun_out; R=$PWD; T=${TAG:-r04}
+if [ -z "$SKIP_PYTEST" ]; then timeout 1500 python -m pytest tests -m gpu -q --tb=short -rf -p no:cacheprovider > gpurun_out/${T}_pytest_gpu.log 2>&1; tail -6 gpurun_out/${T}_pytest_gpu.log; fi
+timeout 600 python bench.py --steps 20 --warmup 5 --conv-table gpurun_out/${T}_conv_table_f16x3.txt > gpurun_out/${T}_bench_default_f16x3.json 2> gpurun_out/${T}_bench.err; head -c 200 gpurun_out/${T}_bench_default_f16x3.json; echo
+timeout 300 python bench.py --model-config configs/viper/fusetrack_r101.py --height 1088 --width 1920 --prec f16x3 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/${T}_bench_config5_r101_1088x1920_f16x3.json 2>> gpurun_out/${T}_bench.err; head -c 200 gpurun_out/${T}_bench_config5_r101_1088x1920_f16x3.json; echo
 # the 2-rank clip pipeline, functionally: two processes on the ONE GPU of this box over gloo (NOT RCCL, no scaling number): the
 # streamed records / maps / hand-off with the real DetectorBackend; its clip30 id_checksum must equal the 1-rank run's
-VPS_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/${T}_bench_2rank_gloo_one_gpu.json 2>> gpurun_out/${T}_bench.err
+VPS_BENCH_BACKEND=gloo timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/${T}_bench_2rank_gloo_one_gpu.json 2>> gpurun_out/${T}_bench.err
 python - <<PY
 import json
-a=json.loads(open('gpurun_out/${T}_bench_default_f16x3.json').read().strip().splitlines()[-1]); b=json.loads(open('gpurun_out/${T}_bench_2rank_gloo_one_gpu.json').read().strip().splitlines()[-1])
-print('clip30 id_checksum 1 rank', a['clip30']['id_checksum'], '2 ranks', b['clip30']['id_checksum'], 'EQUAL' if a['clip30']['id_checksum']==b['clip30']['id_checksum'] else 'DIFFERENT')
+try:
+    a=json.loads(open('gpurun_out/${T}_bench_default_f16x3.json').read().strip().splitlines()[-1]); b=json.loads(open('gpurun_out/${T}_bench_2rank_gloo_one_gpu.json').read().strip().splitlines()[-1])
+    print('clip30 id_checksum 1 rank', a['clip30']['id_checksum'], '2 ranks', b['clip30']['id_checksum'], 'EQUAL' if a['clip30']['id_checksum']==b['clip30']['id_checksum'] else 'DIFFERENT')
+except Exception as e:
+    print('checksum comparison failed:', e)
 PY
-# VPQ of the benchmarked arithmetic against the exact-fp32 kernels, whole drop-in chain (tools/test_vpq.py + eval_vpq.py mirror), 1024x2048:
-# on the near-tied synthetic heads and on the well-separated fixture head
-python tools/run_vps_synthetic.py --height 1024 --width 2048 --videos 2 --frames 30 --prec f16x3 --gt-prec f32 --out gpurun_out/vps_near_tied > gpurun_out/${T}_vpq_f16x3_vs_f32_1024x2048_near_tied.json 2>> gpurun_out/${T}_bench.err
-python tools/run_vps_synthetic.py --height 1024 --width 2048 --videos 2 --frames 30 --prec f16x3 --gt-prec f32 --separated --out gpurun_out/vps_separated > gpurun_out/${T}_vpq_f16x3_vs_f32_1024x2048_separated.json 2>> gpurun_out/${T}_bench.err
-tail -n 1 gpurun_out/${T}_vpq_f16x3_vs_f32_1024x2048_near_tied.json | head -c 300; echo; tail -n 1 gpurun_out/${T}_vpq_f16x3_vs_f32_1024x2048_separated.json | head -c 300; echo
+if [ -n "$WITH_VPQ" ]; then
+timeout 600 python tools/run_vps_synthetic.py --height 1024 --width 2048 --videos 2 --frames 30 --prec f16x3 --gt-prec f32 --out gpurun_out/vps_near_tied > gpurun_out/${T}_vpq_f16x3_vs_f32_1024x2048_near_tied.json 2>> gpurun_out/${T}_bench.err
+timeout 600 python tools/run_vps_synthetic.py --height 1024 --width 2048 --videos 2 --frames 30 --prec f16x3 --gt-prec f32 --separated --out gpurun_out/vps_separated > gpurun_out/${T}_vpq_f16x3_vs_f32_1024x2048_separated.json 2>> gpurun_out/${T}_bench.err
 rm -rf gpurun_out/vps_near_tied gpurun_out/vps_separated
+fi
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ss -o ss -- python $R/bench.py --steps 10 --warmup 3 --single-stream --no-cpu-baseline --no-extras > $R/gpurun_out/prof_ss.json 2> $R/gpurun_out/prof_ss.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -o pmc -- python $R/bench.py --steps 1 --warmup 1 --single-stream --no-cpu-baseline --no-extras --conv-table $R/gpurun_out/conv_table_pmc.txt > /dev/null 2> $R/gpurun_out/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -o pmc -- python $R/bench.py --steps 1 --warmup 1 --single-stream --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/pmc_write.err
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_mfma -o pmc -- python $R/bench.py --steps 1 --warmup 1 --single-stream --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/pmc_mfma.err
-# occupancy of the timed frames (three streams): union and sum of the kernel intervals per frame interval
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/trace.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ss -o ss -- python $R/bench.py --steps 40 --warmup 3 --single-stream --no-cpu-baseline --no-extras > $R/gpurun_out/prof_ss.json 2> $R/gpurun_out/prof_ss.err
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -o pmc -- python $R/bench.py --steps 1 --warmup 1 --single-stream --no-cpu-baseline --no-extras --conv-table $R/gpurun_out/conv_table_pmc.txt > /dev/null 2> $R/gpurun_out/pmc_fetch.err
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -o pmc -- python $R/bench.py --steps 1 --warmup 1 --single-stream --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/pmc_write.err
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_mfma -o pmc -- python $R/bench.py --steps 1 --warmup 1 --single-stream --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/pmc_mfma.err
+# occupancy of the timed frames (three streams): union and sum of the kernel intervals per frame interval, steady state only
+timeout 400 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/trace.err
 cd $R
-python tools/trace_gaps.py gpurun_out/trace --out gpurun_out/${T}_frame_occupancy_traced.json
-python tools/bench_input_pipeline.py --frames 64 --workers 1 2 4 8 16 32 > gpurun_out/${T}_input_pipeline_decode_upload_prep.json 2>> gpurun_out/${T}_bench.err
-python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 5 > gpurun_out/${T}_pmc_traffic_f16x3.json 2> gpurun_out/pmc_traffic.err
-python tools/pmc_mfma.py gpurun_out/pmc_mfma > gpurun_out/${T}_pmc_mfma_busy_f16x3.json 2> gpurun_out/pmc_mfma_tool.err
-python tools/pmc_per_layer.py gpurun_out/conv_table_pmc.txt.ordered.json gpurun_out/pmc_fetch gpurun_out/pmc_write > gpurun_out/${T}_traffic_per_layer_f16x3.txt 2>> gpurun_out/pmc_traffic.err
+timeout 120 python tools/trace_gaps.py gpurun_out/trace --out gpurun_out/${T}_frame_occupancy_traced.json
+timeout 120 python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 5 > gpurun_out/${T}_pmc_traffic_f16x3.json 2> gpurun_out/pmc_traffic.err
+timeout 120 python tools/pmc_mfma.py gpurun_out/pmc_mfma > gpurun_out/${T}_pmc_mfma_busy_f16x3.json 2> gpurun_out/pmc_mfma_tool.err
+timeout 120 python tools/pmc_per_layer.py gpurun_out/conv_table_pmc.txt.ordered.json gpurun_out/pmc_fetch gpurun_out/pmc_write > gpurun_out/${T}_traffic_per_layer_f16x3.txt 2>> gpurun_out/pmc_traffic.err
 cp $(find gpurun_out/prof_ss -name "*kernel_stats.csv" | head -1) gpurun_out/${T}_fusetrack_kernel_stats_single_stream_f16x3.csv
 # keep the merged-back payload small: drop the raw per-dispatch traces
 find gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma gpurun_out/prof_ss gpurun_out/trace -name "*kernel_trace.csv" -delete
