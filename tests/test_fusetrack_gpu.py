@@ -269,6 +269,33 @@ def test_clip_shard_backend_and_handoff_feature(setup):
     assert np.array_equal(out[2]['panoptic_det_obj_ids'].cpu().numpy(), seq[1]['panoptic_det_obj_ids'])
 
 
+def test_graph_captured_image_stages_are_bitwise_the_eager_launches(setup):
+    """VPS_GRAPH=1 / detector.graph_image_stages: the next frame's FlowNet2 + ResNet + FPN + gather replayed from one hipGraph per ring
+    slot (first use of a slot eager, second captured, then replayed) == the eager launches, over a clip long enough to replay every
+    slot's graph (10 frames, ring of 3)"""
+    from vps_amd.clip_shard import ClipShardRunner, DetectorBackend
+    m, fr, dev = setup['model'], setup['frames'], setup['dev']
+    H, W, n = setup['H'], setup['W'], setup['n']
+    frd = [fr[t % n].to(dev).clone() for t in range(10)]
+    runs = []
+    old = m.graph_image_stages
+    try:
+        for graph in (False, True):
+            m.graph_image_stages = graph
+            m._graphs = {}
+            m._cache = None; m._pf = None; m.reset_tracker()
+            outs = ClipShardRunner(DetectorBackend(m, H, W, prefetch=True), 0, 1, None, dev).run(lambda t: frd[t], len(frd))
+            runs.append([{k: (v.cpu().numpy().copy() if torch.is_tensor(v) else np.asarray(v).copy()) for k, v in o.items()
+                          if k in ('panoptic_det_obj_ids', 'panoptic_outputs', 'fcn_outputs', 'panoptic_cls_prob')} for o in outs])
+        assert any(g.get('graph') is not None for g in m._graphs.values()), 'no slot was captured'
+    finally:
+        m.graph_image_stages = old
+        m._graphs = {}
+    for t in range(len(frd)):
+        for k in runs[0][t]:
+            assert np.array_equal(runs[0][t][k], runs[1][t][k]), (t, k)
+
+
 def test_streamed_records_of_another_rank_replay_to_the_sequential_ids(setup):
     """what rank r > 0 does in vps_amd/clip_shard.py, in one process: every frame is computed with deferred tracking, its detection
     record + maps are packed into the fixed-layout tensors that travel to rank 0, unpacked there and assigned in clip order

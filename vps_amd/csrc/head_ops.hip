@@ -107,6 +107,7 @@ struct RpnLevels {
     float stride[8];
 };
 constexpr int RPN_BINS = 4096;
+constexpr int RPN_UNR = 8;       // keys in flight per thread in the select kernel's scans
 
 __global__ __launch_bounds__(256)
 void rpn_score_kernel(const RpnLevels L, const int A, unsigned* __restrict__ keys, int* __restrict__ hist) {
@@ -162,9 +163,15 @@ void rpn_select_kernel(const RpnLevels L, const int A, const float* __restrict__
                 for (int b = t; b < nbin; b += 1024) hist[b] = 0;
                 __syncthreads();
                 const int hs = shift + nbits;                  // bits >= hs are decided
-                for (int i = t; i < n; i += 1024) {
-                    const unsigned k = kin[i];
-                    if ((k >> hs) == (prefix >> hs)) atomicAdd(&hist[(k >> shift) & (nbin - 1)], 1);
+                // RPN_UNR independent loads per thread and trip (clamped index, masked afterwards): with one load per trip the 384
+                // trips of the largest level were 384 L2 round trips - 60..100 us per pass, most of the kernel's 213 us (r04 kernel stats)
+                for (int c0 = 0; c0 < n; c0 += 1024 * RPN_UNR) {
+                    unsigned kk[RPN_UNR];
+#pragma unroll
+                    for (int j = 0; j < RPN_UNR; ++j) kk[j] = kin[min(c0 + j * 1024 + t, n - 1)];
+#pragma unroll
+                    for (int j = 0; j < RPN_UNR; ++j)
+                        if (c0 + j * 1024 + t < n && (kk[j] >> hs) == (prefix >> hs)) atomicAdd(&hist[(kk[j] >> shift) & (nbin - 1)], 1);
                 }
                 __syncthreads();
             }
@@ -213,11 +220,18 @@ void rpn_select_kernel(const RpnLevels L, const int A, const float* __restrict__
     __syncthreads();
     const unsigned lo = shift >= 32 ? 0u : (prefix >> shift) << shift;
     const int room_eq = exact ? count - above : SORT_CAP;  // ties that are taken
-    for (int i = t; i < n; i += 1024) {
-        const unsigned k = kin[i];
-        if (exact ? k > lo : k >= lo) {
-            const int slot = atomicAdd(&sh_cnt, 1);
-            keys[slot] = ((u64)k << 32) | (u64)(0xFFFFFFFFu - (unsigned)i);
+    for (int c0 = 0; c0 < n; c0 += 1024 * RPN_UNR) {
+        unsigned kk[RPN_UNR];
+#pragma unroll
+        for (int j = 0; j < RPN_UNR; ++j) kk[j] = kin[min(c0 + j * 1024 + t, n - 1)];
+#pragma unroll
+        for (int j = 0; j < RPN_UNR; ++j) {
+            const int i = c0 + j * 1024 + t;
+            const unsigned k = kk[j];
+            if (i < n && (exact ? k > lo : k >= lo)) {
+                const int slot = atomicAdd(&sh_cnt, 1);
+                keys[slot] = ((u64)k << 32) | (u64)(0xFFFFFFFFu - (unsigned)i);
+            }
         }
     }
     __syncthreads();
@@ -387,25 +401,56 @@ void maskroi_finish_kernel(const float* __restrict__ dets, const int* __restrict
 // emb [K][E], box [K][ldb] (first 4 used), label [K] int64; prev_* have room for M + K rows. scratch: int32 [M + 3K + 1].
 // out: ids [K] int32, m_out[0] = new M.
 // ------------------------------------------------------------------------------------------------
+// row arg-max (FIRST maximum, like torch.max / numpy argmax), one workgroup per detection: the columns over the threads (coalesced,
+// four loads in flight), (value, column) reduced with "greater value, or equal value and smaller column". One thread per row, as this
+// was inside track_assign_kernel, walked a row of M + 1 floats with one dependent L2 round trip per element: 0.29 ms per frame once the
+// memory holds a few thousand entries (r04 kernel stats).
+__global__ __launch_bounds__(256)
+void track_argmax_kernel(const float* __restrict__ comp, int M, int* __restrict__ mi, float* __restrict__ ml) {
+    const int i = blockIdx.x;
+    const float* __restrict__ row = comp + (size_t)i * (M + 1);
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c0 = 0; c0 <= M; c0 += 1024) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = row[min(c0 + u * 256 + (int)threadIdx.x, M)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = c0 + u * 256 + threadIdx.x;
+            if (j <= M && (v[u] > best || (v[u] == best && j < bi))) { best = v[u]; bi = j; }
+        }
+    }
+    // NaN scores never win a comparison: a row of NaNs keeps column 0x7fffffff here and column 0 in the reference's loop
+    if (bi == 0x7fffffff) { bi = 0; best = row[0]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oj = __shfl_xor(bi, off, 64);
+        if (ov > best || (ov == best && oj < bi)) { best = ov; bi = oj; }
+    }
+    __shared__ float sv[4];
+    __shared__ int sj[4];
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; sj[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > best || (sv[w] == best && sj[w] < bi)) { best = sv[w]; bi = sj[w]; }
+        const float r0 = row[0];
+        if (r0 != r0) { best = r0; bi = 0; }          // the reference's loop starts from row[0]: a NaN there is never beaten
+        mi[i] = bi;
+        ml[i] = best;
+    }
+}
+
 __global__ __launch_bounds__(256)
 void track_assign_kernel(const float* __restrict__ comp, int K, int M, int* __restrict__ scratch, int* __restrict__ ids, int* __restrict__ m_out) {
     int* setsrc = scratch;            // [M] detection written into entry obj, -1 = untouched
     int* addlist = scratch + M;       // [K] detections appended, in order
-    int* mi = scratch + M + K;        // [K] arg-max column, then the id of the detection
+    int* mi = scratch + M + K;        // [K] arg-max column (track_argmax_kernel), then the id of the detection
     float* ml = reinterpret_cast<float*>(scratch + M + 2 * K);   // [K] likelihood of the arg-max
     __shared__ int nadd;
     for (int i = threadIdx.x; i < M; i += 256) setsrc[i] = -1;
-    for (int i = threadIdx.x; i < K; i += 256) {
-        const float* row = comp + (size_t)i * (M + 1);
-        float best = row[0];
-        int bi = 0;
-        for (int j = 1; j <= M; ++j) {
-            const float v = row[j];
-            if (v > best) { best = v; bi = j; }
-        }
-        mi[i] = bi;
-        ml[i] = best;
-    }
     __syncthreads();
     if (threadIdx.x == 0) {
         // best_match_scores / best_match_ids of the reference live in prev-indexed scratch: reuse setsrc for the ids and keep the
@@ -571,6 +616,8 @@ extern "C" int vps_track_assign(const float* comp, int K, int M, const float* em
     if (!comp || !emb || !box || !label || !prev_emb || !prev_box || !prev_label || !scratch || !ids || !m_out) return VPS_EARG(1);
     if (K < 1 || M < 1 || E < 1 || ldb < 4) return VPS_EARG(2);
     // the sequential assignment on ONE workgroup, then the memory update spread over the touched entries
+    hipLaunchKernelGGL(track_argmax_kernel, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, comp, M, scratch + M + K,
+                       reinterpret_cast<float*>(scratch + M + 2 * K));
     hipLaunchKernelGGL(track_assign_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, comp, K, M, scratch, ids, m_out);
     hipLaunchKernelGGL(track_update_kernel, dim3((unsigned)min(M + K, 2048)), dim3(256), 0, (hipStream_t)stream, K, M, emb, E, box, ldb,
                        reinterpret_cast<const long long*>(label), prev_emb, prev_box, reinterpret_cast<long long*>(prev_label), scratch);

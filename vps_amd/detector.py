@@ -111,6 +111,10 @@ class PanopticFuseTrack(HipModule):
         self.profile = None                # set to {} to collect per-stage hip events (stages then run on one stream)
         self.overlap_streams = True        # independent branches of the frame on two HIP streams, + a prefetch stream (see simple_test)
         self._side = None
+        # hipGraph capture of the image-only stages of the NEXT frame (FlowNet2 + ResNet + FPN + gather: ~250 launches with static shapes
+        # and, per ring slot, static addresses): VPS_GRAPH=1. Opt-in: the frame is 94 % kernel time without it
+        self.graph_image_stages = os.environ.get('VPS_GRAPH', '0') != '0'
+        self._graphs = {}                  # ring slot -> dict(key, graph | None, img, ref, flow, levels, cat)
         self._pre = None                   # prefetch stream + its ring of workspaces (clip pipelines)
         self._ring = None
         self._slot = 0
@@ -444,12 +448,45 @@ class PanopticFuseTrack(HipModule):
         self._pre.wait_stream(main)
         self._slot = (self._slot + 1) % 3
         rws = self._ring[self._slot]
-        with torch.cuda.stream(self._pre):
-            nflow = self.flownet2.run(nimg, nref, self._mean_t, self._std_t, rws)
-            nlevels, ncat = self._backbone_fpn_gather(nimg, rws, ring=True)
+        if self.graph_image_stages and (self._handoff is None or self._handoff['img'] is not nimg) and nhwc.CONV_TRACE is None:
+            nflow, nlevels, ncat = self._image_stages_graph(nimg, nref, rws)
             ev = torch.cuda.Event()
             ev.record(self._pre)
+        else:
+            with torch.cuda.stream(self._pre):
+                nflow = self.flownet2.run(nimg, nref, self._mean_t, self._std_t, rws)
+                nlevels, ncat = self._backbone_fpn_gather(nimg, rws, ring=True)
+                ev = torch.cuda.Event()
+                ev.record(self._pre)
         self._pf = dict(img=nimg, ref=nref, version=(nimg._version, nref._version), event=ev, flow=nflow, levels=nlevels, cat=ncat)
+
+    def _image_stages_graph(self, nimg, nref, rws):
+        """The image-only stages of one ring slot as a captured graph. A slot's launches see the same operand addresses every time (its
+        private workspace, the packed weights, the status words) except the two images, which are copied into buffers of the slot
+        first. First use of a slot at a shape: eager (allocates the slot's buffers, raises the kernels' dynamic-LDS limits - calls a
+        capture does not allow); second use: captured, then replayed; from then on copy + replay. A layer that switched to bf16x6
+        (nhwc.F16_FALLBACKS) invalidates the graphs. Results are the slot's own FMaps, bit-identical to the eager launches."""
+        key = (tuple(nimg.shape), nhwc.F16_FALLBACKS[0])
+        g = self._graphs.get(self._slot)
+        if g is None or g['key'] != key:
+            g = dict(key=key, graph=None, img=rws.get('graph.img', tuple(nimg.shape)), ref=rws.get('graph.ref', tuple(nref.shape)))
+            self._graphs[self._slot] = g
+            with torch.cuda.stream(self._pre):
+                g['img'].copy_(nimg); g['ref'].copy_(nref)
+                g['flow'] = self.flownet2.run(g['img'], g['ref'], self._mean_t, self._std_t, rws)
+                g['levels'], g['cat'] = self._backbone_fpn_gather(g['img'], rws, ring=True)
+            return g['flow'], g['levels'], g['cat']
+        with torch.cuda.stream(self._pre):
+            g['img'].copy_(nimg); g['ref'].copy_(nref)
+        if g['graph'] is None:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=self._pre):
+                g['flow'] = self.flownet2.run(g['img'], g['ref'], self._mean_t, self._std_t, rws)
+                g['levels'], g['cat'] = self._backbone_fpn_gather(g['img'], rws, ring=True)
+            g['graph'] = graph
+        with torch.cuda.stream(self._pre):
+            g['graph'].replay()
+        return g['flow'], g['levels'], g['cat']
 
     @torch.no_grad()
     def prime(self, img, ref_img):
