@@ -285,6 +285,8 @@ def imread(path, native=True):
             return img
     try:
         import cv2                          # the reference's own decoder when the host has it
+        if not (callable(getattr(cv2, 'imread', None)) and getattr(cv2, '__version__', None)):
+            raise ImportError('a cv2 stand-in without imread (import shims of the golden-vector scripts)')
         img = cv2.imread(path, cv2.IMREAD_COLOR)
         if img is None:
             raise IOError('cv2.imread failed: %s' % path)
