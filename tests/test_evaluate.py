@@ -203,11 +203,18 @@ def test_pq_average_viper_variant_excludes_mobilebarrier():
         import sys
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
         import make_unify_golden as mg
-        mg.load_reference_function('tools.dataset.viper', 23, 11)
-        ref_mod = sys.modules['tools.dataset.viper']
-        rs = ref_mod.PQStat()
-        for c, (tp, fp, fn, iou) in vals.items():
-            rs[c].tp, rs[c].fp, rs[c].fn, rs[c].iou = tp, fp, fn, iou
-        ref, ref_per = rs.pq_average(cats, None)
+        before = set(sys.modules)
+        try:
+            mg.load_reference_function('tools.dataset.viper', 23, 11)
+            ref_mod = sys.modules['tools.dataset.viper']
+            rs = ref_mod.PQStat()
+            for c, (tp, fp, fn, iou) in vals.items():
+                rs[c].tp, rs[c].fp, rs[c].fn, rs[c].iou = tp, fp, fn, iou
+            ref, ref_per = rs.pq_average(cats, None)
+        finally:
+            # the import shims (inert stand-ins for cv2, pycocotools, ... and the reference's `tools` package) must not outlive this
+            # test: `pytest.importorskip('cv2')` of the third-party pins and `pipeline.imread` would take the stand-in for the library
+            for k in set(sys.modules) - before:
+                del sys.modules[k]
         assert ref['n'] == got['n'] and ref['pq'] == got['pq'] and ref['sq'] == got['sq'] and ref['rq'] == got['rq']
         assert set(ref_per) == set(per)

@@ -1,7 +1,7 @@
 // Thin-input convolutions on the fp16 matrix cores (f16x3 arithmetic): the first layers of the FlowNet2 sub-networks and of the
 // ResNet stem - 3 / 6 / 11 / 12 input channels, 64 output channels, 3x3 stride 1 or 7x7 stride 2 at full resolution
-// (FlowNetS.py:22 conv1 12->64 7x7 s2, FlowNetC.py:18 conv1 3->64 7x7 s2, FlowNetSD.py:18 conv0 6->64 3x3, FlowNetFusion.py:18
-// conv0 11->64 3x3, resnet.py:397 conv1 3->64 7x7 s2).
+// (mmdet/models/flow_modules/FlowNetS.py:20 conv1 12->64 7x7 s2, FlowNetC.py:20 conv1 3->64 7x7 s2, FlowNetSD.py:16 conv0 6->64 3x3,
+// FlowNetFusion.py:16 conv0 11->64 3x3, mmdet/models/backbones/resnet.py:454 conv1 3->64 7x7 s2).
 //
 // On the pipelined kernels these layers are 3..19 k-steps of a tap-major gather per 128-pixel tile: every k-step re-loads, re-splits and
 // re-stages 32 (tap, channel) values per pixel, and a tile is one chain of memory latencies (0.3 ms for 0.1 ms of HBM traffic).
@@ -35,7 +35,8 @@ typedef vec4<h16> h16x4;
 // trip per row); persistent with resident weights and the shared epilogue 0.236 ms - stores alone 0.209 ms of it (knock-outs): that
 // epilogue loads scale / shift per tile (a vmcnt(0) behind the previous tile's stores) and its stores sit behind `if (inside)` branches,
 // which leaves the compiler no lower bound for the stores in flight, so the next tile's staging waited with vmcnt(0) as well. Here:
-//   * the patch of tile t + 2 is requested before the MFMAs of tile t (two register sets, tile loop unrolled by two);
+//   * the patch of tile t + 2 is requested before the MFMAs of tile t (two register sets, tile loop unrolled by two; t + 1 with one
+//     set in the streamed-weight instance, whose registers also hold a kernel row of weights in flight);
 //   * scale / shift live in LDS (read with lgkmcnt, not vmcnt);
 //   * stores are unconditional buffer stores - a lane outside the map / beyond cout stores to an offset past the buffer, which the
 //     hardware drops - so the staging wait is an exact vmcnt(2 tiles of stores + one patch) and two tiles of stores stay in flight.

@@ -69,13 +69,21 @@ class VpsHipError(RuntimeError):
 
 
 def csrc_sha16():
-    """sha256[:16] over the kernel sources of the library (csrc/*.hip, *.h, *.cpp, Makefile): stamps measurements with what they ran on"""
+    """sha256[:16] over the CODE of the library's kernel sources (csrc/*.hip, *.h, *.cpp, Makefile; comments and white space are
+    dropped first, so that a comment edit does not un-stamp a measurement): stamps measurements with what they ran on"""
     import glob
     import hashlib
+    import re
     d = os.path.dirname(LIB_PATH)
     hsh = hashlib.sha256()
     for fn in sorted(glob.glob(os.path.join(d, '*.hip')) + glob.glob(os.path.join(d, '*.h')) + glob.glob(os.path.join(d, '*.cpp')) + [os.path.join(d, 'Makefile')]):
-        hsh.update(os.path.basename(fn).encode()); hsh.update(open(fn, 'rb').read())
+        txt = open(fn, 'r', errors='replace').read()
+        if not fn.endswith('Makefile'):
+            txt = re.sub(r'/\*.*?\*/', ' ', txt, flags=re.S)
+            txt = re.sub(r'//[^\n]*', ' ', txt)
+        else:
+            txt = re.sub(r'(?m)^#[^\n]*', ' ', txt)
+        hsh.update(os.path.basename(fn).encode()); hsh.update(' '.join(txt.split()).encode())
     return hsh.hexdigest()[:16]
 
 
