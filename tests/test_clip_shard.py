@@ -269,9 +269,11 @@ class ChainBackend:
         return np.asarray(ids)
 
     def finalize(self, rec, ids):
+        # like DetectorBackend.finalize: the record's tensors are handed on as they are, NOT copied here - whatever the runner recycles
+        # underneath them (its pooled receive buffers) shows up when the outputs are read at the end of the clip (round 4: a
+        # same-dtype `.to()` in `_unpack` left `panoptic_cls_prob` a view of a recycled buffer; found by tools/check_two_rank.py)
         return dict(t=rec['t'], panoptic_det_obj_ids=np.asarray(ids)[np.asarray(rec['keep_inds'])],
-                    cls=torch.as_tensor(rec['panoptic_cls_inds']).numpy().copy(), prob=torch.as_tensor(rec['panoptic_cls_prob']).numpy().copy(),
-                    pan=torch.as_tensor(rec['panoptic_outputs']).numpy().copy(), sem=torch.as_tensor(rec['fcn_outputs']).numpy().copy())
+                    cls=rec['panoptic_cls_inds'], prob=rec['panoptic_cls_prob'], pan=rec['panoptic_outputs'], sem=rec['fcn_outputs'])
 
 
 def _chain_frames(n):
@@ -293,7 +295,7 @@ def _worker_chain(rank, world, port, q, nframes):
     # every frame of the shard (and the reference of its first frame) is loaded exactly once
     assert sorted(loads) == list(range(max(s - 1, 0), e)) if e > s else loads == [], (rank, loads)
     if rank == 0:
-        q.put(outs)
+        q.put([{k: (torch.as_tensor(v).numpy().copy() if k != 't' else v) for k, v in o.items()} for o in outs])     # read at the END of the clip
     dist.barrier()
     dist.destroy_process_group()
 
@@ -307,7 +309,7 @@ def test_node_size_protocol_equals_sequential(world, nframes):
     for t in range(nframes):
         rec = be.process(frames[t], frames[t - 1 if t else 0], None, 10000 + t + 1, t == 0)
         rec['t'] = t
-        seq.append(be.finalize(rec, be.assign(rec, t == 0)))
+        seq.append({k: (torch.as_tensor(v).numpy().copy() if k != 't' else v) for k, v in be.finalize(rec, be.assign(rec, t == 0)).items()})
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()

@@ -65,8 +65,11 @@ def main():
                 'pan': bool(np.array_equal(torch.as_tensor(o['panoptic_outputs']).cpu().numpy(), r['panoptic_outputs'])),
                 'sem': bool(np.array_equal(torch.as_tensor(o['fcn_outputs']).cpu().numpy(), r['fcn_outputs'])),
             }
-            print('frame %d (rank %d): %s%s' % (t, 0 if t < (n + 1) // 2 else 1, same,
-                                                '' if same['ids'] else '  ids %s vs %s' % (np.asarray(o['panoptic_det_obj_ids']).tolist(), r['panoptic_det_obj_ids'].tolist())), flush=True)
+            extra = '' if same['ids'] else '  ids %s vs %s' % (np.asarray(o['panoptic_det_obj_ids']).tolist(), r['panoptic_det_obj_ids'].tolist())
+            if not same['prob']:
+                pa, pb = torch.as_tensor(o['panoptic_cls_prob']).cpu().numpy(), r['panoptic_cls_prob']
+                extra += ('  max |dprob| %.3e over %d of %d scores; pipeline %s sequential %s' % (float(np.abs(pa - pb).max()), int((pa != pb).sum()), pa.size, pa[:4].tolist(), pb[:4].tolist())) if pa.shape == pb.shape else '  prob shapes %s vs %s' % (pa.shape, pb.shape)
+            print('frame %d (rank %d): %s%s' % (t, 0 if t < (n + 1) // 2 else 1, same, extra), flush=True)
             bad += not all(same.values())
         print('2-rank pipeline %s the sequential run (%dx%d, %d frames, %s, backend %s)' % ('EQUALS' if not bad else 'DIFFERS FROM', H, W, n, args.prec, backend))
     dist.barrier()

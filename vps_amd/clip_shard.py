@@ -25,6 +25,8 @@ new design for BASELINE config 4:
 A backend with `supports_prefetch` also takes `next_img=` in process(): the next frame of the shard, whose image-only stages
 (FlowNet2, ResNet/FPN) it may enqueue behind the current frame's (vps_amd.detector: `prefetch`).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -86,7 +88,7 @@ class ClipShardRunner:
         o = 2
         rec['keep_inds'] = buf[o:o + k].to(torch.int64).cpu().numpy(); o += cap
         for key, dt in zip(self.VEC_KEYS, (torch.int64, torch.float32, torch.int64)):
-            rec[key] = buf[o:o + k].to(dt); o += cap
+            rec[key] = buf[o:o + k].to(dt, copy=True); o += cap      # a copy: `buf` is recycled by the runner (a same-dtype .to() is a view)
         for key, w, dt in lay:
             v = buf[o:o + K * w].to(dt, copy=True)        # own allocation: the kernels need 16-byte aligned operands
             rec[key] = v.reshape(K, w) if (w > 1 or key == 'det_bboxes') else v.reshape(K); o += cap * w
@@ -275,7 +277,7 @@ class DetectorBackend:
         return rec
 
     def prime(self, img, ref_img):
-        if self.prefetch:
+        if self.prefetch and os.environ.get('VPS_NO_PRIME', '0') == '0':
             self.det.prime(img, ref_img)
 
     def assign(self, rec, is_first):
