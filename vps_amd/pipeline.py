@@ -229,6 +229,9 @@ class ClipFeeder:
             if not self._free:
                 raise RuntimeError('ClipFeeder: frame %d requested outside the decode window with every staging buffer in flight' % t)
             slot = self._free.pop()
+            if self._events[slot] is not None:
+                self._events[slot].synchronize()                                  # as in _submit_until: the last upload from this slot is done
+                self._events[slot] = None
             ent = (self._pool.submit(self._decode, self.files[t], slot), slot)
         fut, slot = ent
         c0 = time.perf_counter()
