@@ -194,11 +194,33 @@ def hbm_kernels(dev):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command under torch.distributed.run, one rank per GPU over RCCL
+    (the launcher the driver uses for N > 1: same environment contract), rendezvous on 127.0.0.1 at a free port. A box with fewer
+    than N devices gets ONE JSON line with an `error` field and exit code 2 - nothing touches a GPU (VPS_BENCH_BACKEND=gloo lets
+    the ranks share devices: functional runs of the multi-rank path on a 1-GPU box, never a scaling number)."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < n and os.environ.get('VPS_BENCH_BACKEND', 'nccl') == 'nccl':
+        print(json.dumps({'error': 'bench.py --gpus %d needs %d GPUs on this node (one rank per GPU over RCCL); torch sees %d' % (n, n, ndev),
+                          'n_gpus': n, 'devices_visible': ndev}))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the untimed extras (hbm kernel table, 30-frame clip)')
@@ -215,11 +237,19 @@ def main():
     ap.add_argument('--png-workers', type=int, default=6, help='decode threads of the `from_png` leg (frames read from PNG files through vps_amd.pipeline.ClipFeeder)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(args.gpus)
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, 'launch with --nproc-per-node == --gpus'
-    assert torch.cuda.is_available(), 'bench.py measures the HIP path and needs the MI355X (no CPU fallback)'
+    if world != args.gpus:
+        if rank == 0:
+            print(json.dumps({'error': 'bench.py --gpus %d was started under a launcher with WORLD_SIZE=%d: use --nproc-per-node == --gpus '
+                                       '(or start it without a launcher: it re-launches itself)' % (args.gpus, world), 'n_gpus': args.gpus}))
+        return 2
+    if not torch.cuda.is_available():
+        print(json.dumps({'error': 'bench.py measures the HIP path and needs the MI355X (no CPU fallback); torch sees no GPU here', 'n_gpus': args.gpus}))
+        return 2
     ndev = torch.cuda.device_count()
     if local >= ndev:
         # only for smoke-testing the multi-rank code path on a 1-GPU box (VPS_BENCH_BACKEND=gloo): ranks share a device
@@ -228,13 +258,22 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    comm_ranks, backend = 1, None
+    # VPS_BENCH_DIST=1: create the communicator at world size 1 too (tests/test_rccl_gpu.py: the RCCL branch of this file on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get('VPS_BENCH_DIST', '0') == '1'
+    if use_dist:
         import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         backend = os.environ.get('VPS_BENCH_BACKEND', 'nccl')      # 'nccl' IS RCCL on ROCm
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
+        # proof that the communicator spans the job: an all-reduce of ones over the backend the timed region uses
+        ones = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(ones)
+        comm_ranks = int(ones.item())
 
     import vps_amd
     from vps_amd import hip, nhwc, synth
@@ -276,7 +315,7 @@ def main():
             plain_step(t, 1)
     reset()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     # ---- timed region: exactly K frames per rank --------------------------------------------------------------------------------
@@ -292,11 +331,11 @@ def main():
             out = plain_step(t, 2)
             ndet += int(out[2]['panoptic_cls_inds'].numel())
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -307,15 +346,15 @@ def main():
     if use_runner and not args.no_extras:
         reset()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         c0 = time.perf_counter()
         o30 = runner.run(load_frame, 30, video_id=3)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         c30 = time.perf_counter() - c0
-        if world > 1:
+        if use_dist:
             tm = torch.tensor([c30], dtype=torch.float64, device=dev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             c30 = float(tm.item())
@@ -573,8 +612,12 @@ def main():
             line['test_vpq_loop'] = plain
         if from_png is not None:
             line['from_png'] = from_png
+        if use_dist:
+            line['rccl_ranks' if backend == 'nccl' else backend + '_ranks'] = comm_ranks        # from an all_reduce of ones
+            line['config']['backend'] = 'RCCL (torch.distributed "nccl")' if backend == 'nccl' else backend + ' (functional run, ranks may share a GPU: not a scaling number)'
         if scaling_model is not None:
-            line['scaling_model'] = scaling_model
+            scaling_model['measured'] = False
+            line['extra'] = {'scaling_model': scaling_model}       # a critical-path MODEL (assumed link rate), kept out of the headline fields
         line['config']['host_reads_per_frame'] = '2 (the detection list after MaskROI: 8 KB; kept list + track ids + range report at the end: 2 KB)'
         line['f16_fallbacks'] = int(nhwc.F16_FALLBACKS[0])        # layers switched from f16x3 to bf16x6 by the fp16 range report (0 here)
         if clip30 is not None:
@@ -584,9 +627,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is reported at N = 1 only (it takes about a minute of host time)
             line['cpu_baseline'] = cpu_baseline(args.seed)
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main() or 0)

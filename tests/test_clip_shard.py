@@ -281,7 +281,7 @@ def _chain_frames(n):
     return [torch.rand(1, 3, 8, 16, generator=g) for _ in range(n)]
 
 
-def _worker_chain(rank, world, port, q, nframes):
+def _worker_chain(rank, world, port, q, nframes, cap=None):
     import torch.distributed as dist
     torch.set_num_threads(1)
     os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
@@ -289,8 +289,15 @@ def _worker_chain(rank, world, port, q, nframes):
     frames = _chain_frames(nframes)
     loads = []
     cb = ChainBackend()
-    outs = ClipShardRunner(cb, rank, world, dist).run(lambda t: (loads.append(t), frames[t])[1], nframes)
+    runner = ClipShardRunner(cb, rank, world, dist)
+    if cap is not None:
+        runner.recv_bytes_cap = cap
+    outs = runner.run(lambda t: (loads.append(t), frames[t])[1], nframes)
     s, e = partition(nframes, world)[rank]
+    if rank == 0 and world > 1:
+        # rank 0 never holds more posted receives per peer than its window (memory cap / bytes per frame / peers, at least recv_window)
+        per_frame = 4 * runner._layout()[2] + 2 * cb.Hm * cb.Wm
+        assert 1 <= runner.max_posted <= max(runner.recv_window, runner.recv_bytes_cap // (per_frame * (world - 1))), runner.max_posted
     assert (cb.primed is not None) == (rank > 0 and e > s), (rank, cb.primed is not None)      # later shards announce their first frame
     # every frame of the shard (and the reference of its first frame) is loaded exactly once
     assert sorted(loads) == list(range(max(s - 1, 0), e)) if e > s else loads == [], (rank, loads)
@@ -301,8 +308,11 @@ def _worker_chain(rank, world, port, q, nframes):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize('world,nframes', [(8, 30), (4, 6)])
-def test_node_size_protocol_equals_sequential(world, nframes):
+@pytest.mark.parametrize('world,nframes,cap', [(8, 30, None), (4, 6, None), (2, 24, 7000), (3, 40, 100)])
+def test_node_size_protocol_equals_sequential(world, nframes, cap):
+    """cap: ClipShardRunner.recv_bytes_cap - the last two cases force a receive window SHORTER than the shards (5 resp. 3 positions per
+    peer): receives are topped up while rank 0 works through its own shard (early-arrived records are unpacked into a stash) and in
+    the replay loop"""
     frames = _chain_frames(nframes)
     be = ChainBackend()
     seq = []
@@ -313,7 +323,7 @@ def test_node_size_protocol_equals_sequential(world, nframes):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_chain, args=(r, world, port, q, nframes)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_chain, args=(r, world, port, q, nframes, cap)) for r in range(world)]
     for p in procs:
         p.start()
     outs = q.get(timeout=500)

@@ -269,31 +269,29 @@ def test_clip_shard_backend_and_handoff_feature(setup):
     assert np.array_equal(out[2]['panoptic_det_obj_ids'].cpu().numpy(), seq[1]['panoptic_det_obj_ids'])
 
 
-def test_graph_captured_image_stages_are_bitwise_the_eager_launches(setup):
-    """VPS_GRAPH=1 / detector.graph_image_stages: the next frame's FlowNet2 + ResNet + FPN + gather replayed from one hipGraph per ring
-    slot (first use of a slot eager, second captured, then replayed) == the eager launches, over a clip long enough to replay every
-    slot's graph (10 frames, ring of 3)"""
+def test_image_stage_stream_fan_out_is_bitwise_the_single_prefetch_stream(setup):
+    """detector.pre_streams (VPS_PRE_STREAMS): the next frame's image-only stages on one prefetch stream (1), with ResNet + FPN + gather
+    beside FlowNet2 (2), with FlowNetSD beside the FlowNetC -> S -> S chain as well (3, the default), and the main chain on a
+    high-priority stream (main_priority) - all bitwise equal, over a clip long enough to reuse every ring slot (10 frames, ring of 3)"""
     from vps_amd.clip_shard import ClipShardRunner, DetectorBackend
     m, fr, dev = setup['model'], setup['frames'], setup['dev']
     H, W, n = setup['H'], setup['W'], setup['n']
     frd = [fr[t % n].to(dev).clone() for t in range(10)]
     runs = []
-    old = m.graph_image_stages
+    old, oldp = m.pre_streams, m.main_priority
     try:
-        for graph in (False, True):
-            m.graph_image_stages = graph
-            m._graphs = {}
+        for streams, prio in ((1, False), (2, False), (3, False), (3, True)):
+            m.pre_streams, m.main_priority = streams, prio
             m._cache = None; m._pf = None; m.reset_tracker()
             outs = ClipShardRunner(DetectorBackend(m, H, W, prefetch=True), 0, 1, None, dev).run(lambda t: frd[t], len(frd))
             runs.append([{k: (v.cpu().numpy().copy() if torch.is_tensor(v) else np.asarray(v).copy()) for k, v in o.items()
                           if k in ('panoptic_det_obj_ids', 'panoptic_outputs', 'fcn_outputs', 'panoptic_cls_prob')} for o in outs])
-        assert any(g.get('graph') is not None for g in m._graphs.values()), 'no slot was captured'
     finally:
-        m.graph_image_stages = old
-        m._graphs = {}
-    for t in range(len(frd)):
-        for k in runs[0][t]:
-            assert np.array_equal(runs[0][t][k], runs[1][t][k]), (t, k)
+        m.pre_streams, m.main_priority = old, oldp
+    for r in runs[1:]:
+        for t in range(len(frd)):
+            for k in runs[0][t]:
+                assert np.array_equal(runs[0][t][k], r[t][k]), (t, k)
 
 
 def test_streamed_records_of_another_rank_replay_to_the_sequential_ids(setup):

@@ -151,6 +151,49 @@ def test_clip_feeder_decodes_every_file_once_and_keeps_tensor_identity(tmp_path)
     fd2.close()
 
 
+def test_clip_feeder_keeps_its_read_ahead_in_the_runner_access_order(tmp_path):
+    """ClipShardRunner asks a rank that hands a feature on for its LAST frame first (e-1), then for s, (s-1), s+1 .. e-1.
+    The feeder treated the first request as the start of its window and never moved back: every shard frame was decoded on the
+    spot. Now a request behind the window rewinds it (decodes in flight beyond it give their slots back), `set_range` keeps the
+    read-ahead inside the shard, and every frame of the shard is decoded exactly once, all but the first two from the window."""
+    from PIL import Image
+    from vps_amd.clip_shard import partition
+    from vps_amd.pipeline import ClipFeeder, imread
+
+    class HostPrep:
+        device = torch.device('cpu')
+
+        def prep(self, img):
+            return torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float(), tuple(img.shape), tuple(img.shape), 1.0
+
+    rng = np.random.RandomState(3)
+    files = []
+    for i in range(24):
+        fn = str(tmp_path / ('g%02d.png' % i))
+        Image.fromarray(rng.randint(0, 255, (10, 16, 3)).astype(np.uint8)).save(fn)
+        files.append(fn)
+    want = [torch.from_numpy(np.ascontiguousarray(imread(f))).permute(2, 0, 1).float() for f in files]
+
+    for rank, world in ((0, 2), (1, 2), (1, 3)):
+        s, e = partition(len(files), world)[rank]
+        fd = ClipFeeder(files, HostPrep(), workers=2, ahead=3)
+        # the order ClipShardRunner.run produces on a rank that sends a hand-off (and, for rank > 0, primes with frame s-1)
+        if hasattr(fd, 'set_range'):
+            fd.set_range(max(s - 1, 0), e)
+        order = ([e - 1] if rank < world - 1 else []) + [s] + ([s - 1] if rank > 0 else [])
+        got = {t: fd(t) for t in order}
+        for t in range(s, e):
+            x = fd(t) if t not in got else got[t]
+            assert torch.equal(x[0], want[t]), (rank, t)
+            if t + 1 < e and t + 1 not in got:
+                got[t + 1] = fd(t + 1)                      # the announced next frame
+        nshard = e - max(s - 1, 0)
+        assert fd.decodes == nshard, (rank, world, fd.decodes, nshard)          # every frame once, none of another rank's
+        assert fd.out_of_window == 0, (rank, world, fd.out_of_window)            # nothing decoded on the spot
+        assert all(u < e for u in fd._pending), fd._pending
+        fd.close()
+
+
 @pytest.mark.parametrize('mode,shape', [('RGB', (37, 53)), ('RGBA', (16, 40)), ('L', (21, 19)), ('RGB', (256, 512))])
 def test_native_png_decoder_equals_pil(tmp_path, mode, shape):
     """csrc/png_host.cpp (host code of libvpship, no GPU needed): bit-identical to PIL on every filter type the encoder picks

@@ -92,3 +92,20 @@ def test_check_isa_reports_resources_and_mix():
     assert mix['void conv_mfma_h8s2_kernel<4, 3, 64>']['mfma'] == 108     # the 64-column instance: one column fragment per wave
     n16 = mix['void conv_mfma_n16_kernel<4, 3, 3>']
     assert n16['mfma'] == 54 and n16['barrier'] == 2                      # 9 taps x 3 products x 2 pixel groups of 16x16x32, two barriers per chunk
+
+
+def test_bench_multi_gpu_launch_fails_with_one_json_line_not_an_assert():
+    """`python bench.py --gpus N` without a launcher re-launches itself under torch.distributed.run; on a box with
+    fewer than N GPUs (this container has none) it prints ONE JSON line with an `error` field and exits 2 - no assert, no traceback.
+    The same for a launcher whose WORLD_SIZE disagrees with --gpus, and for N = 1 without a GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    for args, extra in ((['--gpus', '8'], {}), (['--gpus', '2'], {'WORLD_SIZE': '1'}), ([], {})):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=dict(env, **extra), capture_output=True, text=True, timeout=300)
+        import torch
+        if torch.cuda.is_available() and not args:
+            continue                     # on a GPU box the N = 1 run would be the real benchmark
+        lines = [l for l in p.stdout.strip().splitlines() if l.strip()]
+        assert p.returncode == 2 and len(lines) == 1, (args, p.returncode, p.stdout, p.stderr[-500:])
+        j = json.loads(lines[0])
+        assert 'error' in j and j['n_gpus'] == (int(args[1]) if args else 1)
+        assert 'Traceback' not in p.stderr

@@ -49,7 +49,8 @@ class ClipShardRunner:
     receives up front) — and assembles the outputs. No object collectives, no pickling, no barrier between "compute" and
     "replay": the only serial work is the tracker step itself (two small kernels per frame)."""
 
-    recv_window = 3        # positions per peer whose receives rank 0 keeps posted
+    recv_window = 3        # positions per peer whose receives rank 0 keeps posted, at least (see `_window`)
+    recv_bytes_cap = 2 << 30      # memory rank 0 may hold in posted receive buffers + early-unpacked records of the other ranks
 
     def __init__(self, backend, rank=0, world=1, dist=None, device=None, track_keys=('det_bboxes', 'det_labels', 'cls_prob', 'emb')):
         self.backend, self.rank, self.world, self.dist = backend, rank, world, dist
@@ -122,6 +123,8 @@ class ClipShardRunner:
         parts = partition(nframes, world)
         s, e = parts[rank]
         be = self.backend
+        if e > s and hasattr(user_load, 'set_range'):
+            user_load.set_range(max(s - 1, 0), e)        # a read-ahead loader (pipeline.ClipFeeder) stops at the end of this rank's shard
         if hasattr(be, 'inline_ids'):
             be.inline_ids = rank == 0        # rank 0 owns the head of the clip: its frames get their ids inside the detector call
         recv_buf = None
@@ -149,7 +152,7 @@ class ClipShardRunner:
         # Only a WINDOW of positions is posted at a time (`recv_window` per peer, buffers recycled as step 4 consumes them): a long
         # video would otherwise pin ~5 MB per remote frame on rank 0 and queue O(clip) receive kernels on the communicator stream
         # (ADVICE r3). A peer's sends complete in order, so its position j + window is posted when its position j has been consumed.
-        inbox, pool = {}, []
+        inbox, pool, stash = {}, [], {}
         post_recv = None
         if world > 1 and rank == 0:
             cap, lay, n = self._layout()
@@ -167,9 +170,23 @@ class ClipShardRunner:
                     buf = torch.zeros(n, dtype=torch.float32, device=dev)
                     maps = torch.empty(2, Hm, Wm, dtype=torch.uint8, device=dev)
                 inbox[t] = (buf, maps, self._post([dist.P2POp(dist.irecv, buf, r), dist.P2POp(dist.irecv, maps, r)]))
-            for j in range(min(self.recv_window, max(b - a for a, b in parts))):
-                for r in range(1, world):
-                    post_recv(r, j)
+            # window = as many positions per peer as the memory cap allows (a record + its maps are ~5 MB), at least `recv_window`: a
+            # shard that fits is posted completely (no send of a peer ever waits for its receive: an unmatched RCCL send spins on CUs
+            # of the sender beside its compute); a longer one is topped up while rank 0 works through its own shard (step 3) and in step 4
+            per_frame = 4 * n + 2 * Hm * Wm
+            window = max(self.recv_window, int(self.recv_bytes_cap // (per_frame * max(world - 1, 1))))
+            posted = {r: 0 for r in range(1, world)}          # positions posted so far, per peer
+            taken = {r: 0 for r in range(1, world)}           # positions unpacked so far, per peer
+            self.max_posted = 0
+
+            def fill():
+                for j in range(max(b - a for a, b in parts)):
+                    for r in range(1, world):
+                        if posted[r] == j and j < parts[r][1] - parts[r][0] and j - taken[r] < window:
+                            post_recv(r, j)
+                            posted[r] = j + 1
+                self.max_posted = max(self.max_posted, max(posted[r] - taken[r] for r in posted))
+            fill()
         # 3) this rank's frames
         outs, sent = [], []
         prev = None
@@ -199,6 +216,20 @@ class ClipShardRunner:
                 sent.append((buf, maps, self._post([dist.P2POp(dist.isend, buf, 0), dist.P2POp(dist.isend, maps, 0)])))
             prev = img
             memo.pop(t - 1, None)            # frame t-1 is no longer needed (frame t stays: it is frame t+1's reference)
+            if post_recv is not None:
+                # records that have arrived meanwhile are unpacked (copied out of the pooled buffers) and their buffers reposted, so a
+                # peer whose shard is longer than the window is never left with unmatched sends until step 4
+                for r in range(1, world):
+                    while taken[r] < posted[r] and len(stash) * per_frame < self.recv_bytes_cap:
+                        tt = parts[r][0] + taken[r]
+                        buf, maps, rq = inbox[tt]
+                        if not all(q.is_completed() for q in rq):
+                            break
+                        inbox.pop(tt)
+                        stash[tt] = self._unpack(buf, maps, tt)
+                        pool.append((buf, maps))
+                        taken[r] += 1
+                fill()
         for rq in reqs:
             rq.wait()
         # 4) rank 0: the other shards' frames in clip order, each as soon as its record has arrived
@@ -206,13 +237,17 @@ class ClipShardRunner:
             for r in range(1, world):
                 for j in range(parts[r][1] - parts[r][0]):
                     t = parts[r][0] + j
-                    buf, maps, rq = inbox.pop(t)
-                    for q in rq:
-                        q.wait()
-                    rec = self._unpack(buf, maps, t)       # copies everything it keeps: the buffers go back to the pool
+                    if t in stash:                         # arrived and unpacked while rank 0 was still computing
+                        rec = stash.pop(t)
+                    else:
+                        buf, maps, rq = inbox.pop(t)
+                        for q in rq:
+                            q.wait()
+                        rec = self._unpack(buf, maps, t)       # copies everything it keeps: the buffers go back to the pool
+                        pool.append((buf, maps))
+                        taken[r] += 1
+                        fill()
                     outs.append(be.finalize(rec, be.assign(rec, t == 0)))
-                    pool.append((buf, maps))
-                    post_recv(r, j + self.recv_window)
             return outs
         for buf, maps, rq in sent:
             for q in rq:

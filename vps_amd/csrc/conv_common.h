@@ -365,6 +365,18 @@ __device__ __forceinline__ f32x16 split_mfma(const vec8<typename Split<MODE>::el
 // fp32 float4 -> NSA planes of 4 elements. `amax` tracks max |x| of the staged values in the fp16 mode (range report).
 template <int MODE>
 __device__ __forceinline__ void split_act(const f32x4 v, vec4<typename Split<MODE>::elem> (&out)[Split<MODE>::NSA], float& amax) {
+#ifdef VPS_KO_NOSPLIT
+    // KNOCK-OUT build (tools/build_knockout.sh, never the product): the staged float4 is reinterpreted as the two fp16 planes of four
+    // values (0 VALU, no range report) - what a loader would cost if the PRODUCER had written the pair. Results are garbage; the
+    // build only bounds what pre-split activations could buy.
+    if constexpr (MODE == VPS_PREC_F16X3) {
+        typedef vec4<_Float16> h4;
+        struct two { h4 a, b; };
+        const two p = __builtin_bit_cast(two, v);
+        out[0] = p.a; out[1] = p.b;
+        return;
+    }
+#endif
     if constexpr (MODE == VPS_PREC_F16X3) {
         // per PAIR of elements: one packed RNE conversion for h0 (v_cvt_pk_f16_f32), the exact residual x - h0 as one mixed-precision
         // FMA reading the fp16 half directly (v_fma_mix_f32: no convert-back, no separate subtract; the compiler does not form it), the exact scaling by 2^11, one

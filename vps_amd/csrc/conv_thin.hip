@@ -271,7 +271,10 @@ int vpsi_launch_conv_thin(const vps_conv_desc& d, hipStream_t s) {
     static const int on = getenv("VPS_THIN") ? atoi(getenv("VPS_THIN")) : 1;
     if (!on || !d.w_thin || d.prec != VPS_PREC_F16X3 || d.offset || d.res || d.nclass != 1 || d.ksplit != 1 || d.korder != 0) return 0;
     if (d.KH != d.KW || d.cout_pad != 64 || d.tile_n != 64 || (d.cout & 3) || ((uintptr_t)d.w_thin & 15)) return 0;
-    if (d.pad_y[0] != d.KH / 2 || d.pad_x[0] != d.KH / 2) return 0;
+    if (d.pad_y[0] != d.KH / 2 || d.pad_x[0] != d.KH / 2 || d.pad_y[1] != d.KH / 2 || d.pad_x[1] != d.KH / 2) return 0;
+    // the input is addressed through a 32-bit buffer resource: a narrow window inside a buffer of >= 4 GiB would wrap (loads beyond the
+    // truncated size return zeros, silently) -> the pipelined kernel takes such a launch
+    if ((size_t)d.N * d.H * d.W * d.in_ld * sizeof(float) >= 0xFFFFFFF0ull) return 0;
     // float4 buffer stores: 16-byte aligned channel windows of an output below 4 GiB
     if (((d.out_ld | d.out_coff) & 3) || ((uintptr_t)d.out & 15) || (size_t)d.N * d.Ho * d.Wo * d.out_ld * sizeof(float) >= 0xFFFFFFF0ull) return 0;
     if (d.KH == 3 && d.stride == 1 && d.cin_pad == 8) return launch_thin<8, 3, 1, 8, 2, true>(d, s);

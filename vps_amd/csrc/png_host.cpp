@@ -28,6 +28,8 @@ inline int paeth(int a, int b, int c) {
 extern "C" int vps_png_info(const uint8_t* file, int64_t nbytes, int32_t* H, int32_t* W, int32_t* channels) {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
     if (!file || nbytes < 33 || memcmp(file, sig, 8) != 0 || be32(file + 8) != 13 || memcmp(file + 12, "IHDR", 4) != 0) return VPS_EARG(1);
+    // the IHDR chunk's CRC (type + 13 data bytes): a damaged header is refused before its fields size anything
+    if ((uint32_t)crc32(0L, file + 12, 17) != be32(file + 29)) return VPS_EARG(1);
     const uint32_t w = be32(file + 16), h = be32(file + 20);
     const int depth = file[24], ctype = file[25], interlace = file[28];
     if (w == 0 || h == 0 || w > 65535 || h > 65535) return VPS_EARG(2);
@@ -44,6 +46,10 @@ extern "C" int vps_png_decode_bgr8(const uint8_t* file, int64_t nbytes, uint8_t*
     if (st) return st;
     if (!out || out_capacity < (int64_t)H * W * 3) return VPS_EARG(4);
     const size_t stride = (size_t)W * C;
+    // zlib counts the output space in a 32-bit uInt: an image whose raw size does not fit (a 65535 x 65535 header passes the checks
+    // above: ~17 GB) would be inflated only in part, with `avail_out == 0` reached early and uninitialised rows behind it.
+    // Refused: the caller falls back to the general decoder. 1 GiB is > 100 frames of the path's size.
+    if ((stride + 1) * (size_t)H > ((size_t)1 << 30)) return VPS_EARG(9);
     uint8_t* raw = (uint8_t*)malloc((stride + 1) * (size_t)H);           // filter byte + pixels per scanline
     if (!raw) return VPS_EARG(5);
     z_stream zs;

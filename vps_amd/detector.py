@@ -111,10 +111,18 @@ class PanopticFuseTrack(HipModule):
         self.profile = None                # set to {} to collect per-stage hip events (stages then run on one stream)
         self.overlap_streams = True        # independent branches of the frame on two HIP streams, + a prefetch stream (see simple_test)
         self._side = None
-        # hipGraph capture of the image-only stages of the NEXT frame (FlowNet2 + ResNet + FPN + gather: ~250 launches with static shapes
-        # and, per ring slot, static addresses): VPS_GRAPH=1. Opt-in: the frame is 94 % kernel time without it
-        self.graph_image_stages = os.environ.get('VPS_GRAPH', '0') != '0'
-        self._graphs = {}                  # ring slot -> dict(key, graph | None, img, ref, flow, levels, cat)
+        # image-only stages of the NEXT frame: 1 = one prefetch stream (FlowNet2, then ResNet + FPN + gather), 2 = ResNet + FPN + gather
+        # on a stream of their own beside FlowNet2, 3 = FlowNetSD beside the FlowNetC -> S -> S chain as well. The branches are
+        # independent (they share the input images only), every one of them has long runs of low-resolution layers that launch fewer
+        # workgroups than the chip has CUs, and the convolutions are latency- not throughput-bound: side by side they
+        # fill each other's gaps. Bitwise the serial schedule (tests/test_fusetrack_gpu.py).
+        self.pre_streams = int(os.environ.get('VPS_PRE_STREAMS', '3'))
+        # 1: the frame's main chain (neck, heads, the host reads) runs on a HIGH-priority stream of the detector's own, so that its
+        # short kernels are not queued behind the prefetched frame's workgroups (A/B switch, off by default)
+        self.main_priority = os.environ.get('VPS_MAIN_PRIO', '0') != '0'
+        self._hp = None
+        self._sd = None
+        self._pre_aux = []                 # the extra prefetch streams (pre_streams > 1)
         self._pre = None                   # prefetch stream + its ring of workspaces (clip pipelines)
         self._ring = None
         self._slot = 0
@@ -192,6 +200,21 @@ class PanopticFuseTrack(HipModule):
         beyond the fp16 range (|x| > 65504; reported per layer through vps_conv_desc.status, read with the frame's end-of-frame
         read) is switched to bf16x6 for good and the frame is computed again from the state it started in — no exception, no
         wrong result; `nhwc.F16_FALLBACKS` counts the switched layers."""
+        if self.main_priority and img.is_cuda and self.overlap_streams and self.profile is None:
+            # the whole call on the detector's high-priority stream, ordered behind / in front of the caller's stream
+            cur = torch.cuda.current_stream(img.device)
+            if self._hp is None or self._hp.device != img.device:
+                self._hp = torch.cuda.Stream(device=img.device, priority=-1)
+            if cur != self._hp:
+                self._hp.wait_stream(cur)
+                try:
+                    with torch.cuda.stream(self._hp):
+                        return self._simple_test_guarded(img, img_meta, proposals, rescale, ref_img, inject, ref_feature, defer_tracking, prefetch)
+                finally:
+                    cur.wait_stream(self._hp)
+        return self._simple_test_guarded(img, img_meta, proposals, rescale, ref_img, inject, ref_feature, defer_tracking, prefetch)
+
+    def _simple_test_guarded(self, img, img_meta, proposals, rescale, ref_img, inject, ref_feature, defer_tracking, prefetch):
         if img.is_cuda:
             self.ensure_packed(img.device)      # a lazily packed model registers its f16x3 layers here: `guard` must see them (ADVICE r3)
         guard = nhwc._F16_NEXT[0] > 1 and img.is_cuda
@@ -305,7 +328,7 @@ class PanopticFuseTrack(HipModule):
                 if side is not None:
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
-                        flow = self.flownet2.run(img, ref_img, self._mean_t, self._std_t, ws)
+                        flow = self.flownet2.run(img, ref_img, self._mean_t, self._std_t, ws, sd_stream=self._sd_stream(dev))
                 else:
                     flow = self.flownet2.run(img, ref_img, self._mean_t, self._std_t, ws)
                 self._mark('flownet2')
@@ -433,60 +456,39 @@ class PanopticFuseTrack(HipModule):
 
     # ------------------------------------------------------------------------------------------------------
     def _enqueue_image_stages(self, nimg, nref, main):
-        """The image-only stages (FlowNet2, ResNet + FPN + gather) of the frame the NEXT call will be made with go to a third stream
-        before anything of the current frame is enqueued, so they run beside the current frame's neck and heads, not behind its
-        semantic head: the prefetch stream is then busy back to back (it is the longest chain, ~16 ms of the frame's ~22 ms of
-        kernel time) and the main / side streams fill the CUs its low-resolution layers leave idle. Its buffers come from a ring of
-        three private workspaces: slot (t+1) % 3 was last written for frame t-2, whose flow / levels were read by neck(t-2) and
-        whose gathered feature was last read by neck(t-1) as ref_bsf - both enqueued on the main stream in earlier calls, which the
-        wait below orders this stream behind (the main stream is drained at this point anyway: the previous call ended with its
-        end-of-frame read). The images may have been produced on the main stream too."""
+        """The image-only stages (FlowNet2, ResNet + FPN + gather) of the frame the NEXT call will be made with go to the prefetch
+        streams before anything of the current frame is enqueued, so they run beside the current frame's neck and heads, not behind
+        its semantic head: they are the longest chain (~16 ms of the frame's ~22 ms of kernel time) and the main / side streams fill
+        the CUs their low-resolution layers leave idle. With `pre_streams` > 1 the chain itself is split over independent streams
+        (ResNet + FPN + gather beside FlowNet2, FlowNetSD beside FlowNetC -> S -> S). Buffers come from a ring of three private
+        workspaces: slot (t+1) % 3 was last written for frame t-2, whose flow / levels were read by neck(t-2) and whose gathered
+        feature was last read by neck(t-1) as ref_bsf - both enqueued on the main stream in earlier calls, which the waits below
+        order every prefetch stream behind (the main stream is drained at this point anyway: the previous call ended with its
+        end-of-frame read). The images may have been produced on the main stream too. Every auxiliary stream is joined into the
+        first one before the event the consumer waits for is recorded."""
         dev = nimg.device
         if self._pre is None or self._pre.device != dev:
             self._pre = torch.cuda.Stream(device=dev)
+            self._pre_aux = [torch.cuda.Stream(device=dev) for _ in range(2)]
             self._ring = [nhwc.Workspace(dev) for _ in range(3)]
         self._pre.wait_stream(main)
         self._slot = (self._slot + 1) % 3
         rws = self._ring[self._slot]
-        if self.graph_image_stages and (self._handoff is None or self._handoff['img'] is not nimg) and nhwc.CONV_TRACE is None:
-            nflow, nlevels, ncat = self._image_stages_graph(nimg, nref, rws)
+        bb_stream = self._pre_aux[0] if self.pre_streams >= 2 else self._pre
+        sd_stream = self._pre_aux[1] if self.pre_streams >= 3 else None
+        if bb_stream is not self._pre:
+            bb_stream.wait_stream(main)
+            with torch.cuda.stream(bb_stream):
+                nlevels, ncat = self._backbone_fpn_gather(nimg, rws, ring=True)
+        with torch.cuda.stream(self._pre):
+            nflow = self.flownet2.run(nimg, nref, self._mean_t, self._std_t, rws, sd_stream=sd_stream)
+            if bb_stream is self._pre:
+                nlevels, ncat = self._backbone_fpn_gather(nimg, rws, ring=True)
+            else:
+                self._pre.wait_stream(bb_stream)
             ev = torch.cuda.Event()
             ev.record(self._pre)
-        else:
-            with torch.cuda.stream(self._pre):
-                nflow = self.flownet2.run(nimg, nref, self._mean_t, self._std_t, rws)
-                nlevels, ncat = self._backbone_fpn_gather(nimg, rws, ring=True)
-                ev = torch.cuda.Event()
-                ev.record(self._pre)
         self._pf = dict(img=nimg, ref=nref, version=(nimg._version, nref._version), event=ev, flow=nflow, levels=nlevels, cat=ncat)
-
-    def _image_stages_graph(self, nimg, nref, rws):
-        """The image-only stages of one ring slot as a captured graph. A slot's launches see the same operand addresses every time (its
-        private workspace, the packed weights, the status words) except the two images, which are copied into buffers of the slot
-        first. First use of a slot at a shape: eager (allocates the slot's buffers, raises the kernels' dynamic-LDS limits - calls a
-        capture does not allow); second use: captured, then replayed; from then on copy + replay. A layer that switched to bf16x6
-        (nhwc.F16_FALLBACKS) invalidates the graphs. Results are the slot's own FMaps, bit-identical to the eager launches."""
-        key = (tuple(nimg.shape), nhwc.F16_FALLBACKS[0])
-        g = self._graphs.get(self._slot)
-        if g is None or g['key'] != key:
-            g = dict(key=key, graph=None, img=rws.get('graph.img', tuple(nimg.shape)), ref=rws.get('graph.ref', tuple(nref.shape)))
-            self._graphs[self._slot] = g
-            with torch.cuda.stream(self._pre):
-                g['img'].copy_(nimg); g['ref'].copy_(nref)
-                g['flow'] = self.flownet2.run(g['img'], g['ref'], self._mean_t, self._std_t, rws)
-                g['levels'], g['cat'] = self._backbone_fpn_gather(g['img'], rws, ring=True)
-            return g['flow'], g['levels'], g['cat']
-        with torch.cuda.stream(self._pre):
-            g['img'].copy_(nimg); g['ref'].copy_(nref)
-        if g['graph'] is None:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=self._pre):
-                g['flow'] = self.flownet2.run(g['img'], g['ref'], self._mean_t, self._std_t, rws)
-                g['levels'], g['cat'] = self._backbone_fpn_gather(g['img'], rws, ring=True)
-            g['graph'] = graph
-        with torch.cuda.stream(self._pre):
-            g['graph'].replay()
-        return g['flow'], g['levels'], g['cat']
 
     @torch.no_grad()
     def prime(self, img, ref_img):
@@ -502,6 +504,15 @@ class PanopticFuseTrack(HipModule):
             pf['event'].synchronize()
         self._enqueue_image_stages(img, ref_img, torch.cuda.current_stream(img.device))
         return True
+
+    def _sd_stream(self, dev):
+        """the stream FlowNetSD runs on beside the FlowNetC -> S -> S chain of an UNprefetched frame (first frame of a clip, a caller
+        that owns the loop); None with fewer than three image-stage streams"""
+        if self.pre_streams < 3:
+            return None
+        if self._sd is None or self._sd.device != dev:
+            self._sd = torch.cuda.Stream(device=dev)
+        return self._sd
 
     @staticmethod
     def _probe(img):

@@ -250,9 +250,13 @@ class FlowNet2(HipModule):
             n.pack(device)
         self._nblk = 512
 
-    def run(self, img, ref, mean, std, ws, tag='fn2.'):
+    def run(self, img, ref, mean, std, ws, tag='fn2.', sd_stream=None):
         """img/ref: NCHW [1,3,H,W] normalised device tensors (the detector inputs); mean/std: device [3] tensors.
-        Returns the full-resolution flow FMap [1,H,W,2(+2)] (compute_flow before the x0.25 resize)."""
+        Returns the full-resolution flow FMap [1,H,W,2(+2)] (compute_flow before the x0.25 resize).
+        sd_stream: FlowNetSD needs the image pair alone (flownet2.py:166-169 runs it after FlowNetS_2, but nothing of the
+        C -> S1 -> S2 chain feeds it): with a second stream it runs BESIDE that chain - its low-resolution layers (<= 64x128: a few
+        dozen workgroups each) fill CUs the chain's leave idle and vice versa. Forked behind the pair buffer, joined in front of
+        the fusion stage; disjoint workspace names, one split-K scratch per stream: results are bitwise those of the serial order."""
         self.ensure_packed(img.device)
         assert abs(self.rgb_max - 255.0) < 1e-6
         _, _, H0, W0 = img.shape
@@ -274,6 +278,12 @@ class FlowNet2(HipModule):
             hip.check(lib.vps_flow_stage_full(x6.ptr(), x6.ld, flow_a.ptr(), flow_a.ld, flow_a.coff, fb.ptr(), fb.ld, fb.coff, H, W, mode, D,
                                               out.ptr(), out.ld, sp()), 'vps_flow_stage_full')
 
+        cur = sd_flow2 = None
+        if sd_stream is not None:
+            cur = torch.cuda.current_stream(img.device)
+            sd_stream.wait_stream(cur)            # the pair buffer is written (and this workspace's previous SD pass was joined below)
+            with torch.cuda.stream(sd_stream):
+                sd_flow2 = self.flownets_d.run(x6, ws, tag + 'SD.')
         # whole 12-float pixels per thread (vps_flow_stage_full); the channel-wise vps_flow_stage + vps_axpb pair is the general form
         c_flow2 = self.flownetc.run(x6, ws, tag + 'C.')
         concat1 = ws.fmap(tag + 'concat1', 1, H, W, 12)
@@ -282,7 +292,10 @@ class FlowNet2(HipModule):
         concat2 = ws.fmap(tag + 'concat2', 1, H, W, 12)
         full(0, s1_flow2, None, concat2)                               # :154-163
         s2_flow2 = self.flownets_2.run(concat2, ws, tag + 'S2.')
-        sd_flow2 = self.flownets_d.run(x6, ws, tag + 'SD.')
+        if sd_stream is None:
+            sd_flow2 = self.flownets_d.run(x6, ws, tag + 'SD.')
+        else:
+            cur.wait_stream(sd_stream)
         concat3 = ws.fmap(tag + 'concat3', 1, H, W, 11)
         full(1, s2_flow2, sd_flow2, concat3)                           # :166-187 nearest x4 of flow*20 resp. flow/20 (sic)
         flow = self.flownetfusion.run(concat3, ws, tag + 'F.')

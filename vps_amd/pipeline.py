@@ -148,6 +148,7 @@ class ClipFeeder:
     """
 
     def __init__(self, files, prep, workers=4, ahead=None):
+        from collections import deque
         from concurrent.futures import ThreadPoolExecutor
         self.files, self.prep = list(files), prep
         self.workers = int(workers)
@@ -155,13 +156,22 @@ class ClipFeeder:
         self._pool = ThreadPoolExecutor(self.workers)
         self._pending = {}          # t -> (future, staging slot)
         self._ready = {}            # t -> prepared device tensor [1,3,Hp,Wp]
+        self._done = set()          # frames delivered so far: the window does not decode them a second time (consumers keep what they got)
         self._next = 0              # first index not yet submitted
+        self._hi = len(self.files)  # the window never runs past this frame (`set_range`: the end of a rank's shard)
         self.decodes = 0
+        self.out_of_window = 0      # requests that found their frame neither prepared nor in flight (decoded on the spot)
         self.stats = dict(wait_for_decode_s=0.0, upload_prep_s=0.0)      # where the consumer's time in __call__ went
-        self._stage, self._fbuf, self._free, self._events = [], [], [], []
+        self._stage, self._fbuf, self._events = [], [], []
+        self._free = deque()        # staging slots, recycled FIFO: the slot taken next is the one whose upload is oldest
 
     def __len__(self):
         return len(self.files)
+
+    def set_range(self, lo, hi):
+        """the consumer will ask for frames of [lo, hi) only (ClipShardRunner: a rank's shard + its reference frame): the read-ahead
+        stops at hi instead of decoding frames another rank owns"""
+        self._hi = min(int(hi), len(self.files))
 
     def _slots(self, nbytes):
         """the staging ring: `ahead + 2` pinned frame buffers (plain host memory without a device) + as many file buffers"""
@@ -169,7 +179,7 @@ class ClipFeeder:
         pin = self.prep.device.type == 'cuda'
         self._stage = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() if pin else torch.empty(nbytes, dtype=torch.uint8) for _ in range(n)]
         self._fbuf = [bytearray(0) for _ in range(n)]
-        self._free = list(range(n))
+        self._free.clear(); self._free.extend(range(n))
         self._events = [None] * n
 
     def _decode(self, path, slot):
@@ -193,18 +203,29 @@ class ClipFeeder:
         stage[:img.nbytes].copy_(torch.from_numpy(img).reshape(-1))
         return img.shape[0], img.shape[1]
 
+    def _take_slot(self):
+        slot = self._free.popleft()
+        if self._events[slot] is not None:
+            self._events[slot].synchronize()                                  # the upload that last read this slot has finished
+            self._events[slot] = None
+        return slot
+
     def _submit_until(self, t_hi):
         if not self._stage and self.files:
             from PIL import Image
             with Image.open(self.files[0]) as im:                                # header only: the frame size of the clip
                 w, h = im.size
             self._slots(h * w * 3)
-        while self._next < min(t_hi, len(self.files)) and self._free:
-            slot = self._free.pop()
-            if self._events[slot] is not None:
-                self._events[slot].synchronize()                                  # the upload that last read this slot has finished
-                self._events[slot] = None
-            self._pending[self._next] = (self._pool.submit(self._decode, self.files[self._next], slot), slot)
+        t_hi = min(t_hi, self._hi)
+        while self._next < t_hi:
+            t = self._next
+            if t in self._done or t in self._ready or t in self._pending:         # delivered / in flight already (a one-off request ahead of the window)
+                self._next += 1
+                continue
+            if not self._free:
+                break
+            slot = self._take_slot()
+            self._pending[t] = (self._pool.submit(self._decode, self.files[t], slot), slot)
             self._next += 1
 
     def start(self, t=0):
@@ -217,21 +238,36 @@ class ClipFeeder:
         """img_meta entries of frame t that depend on the file (`Collect` keys of configs/cityscapes/fusetrack.py:190)"""
         return dict(filename=self.files[t])
 
+    def _rewind(self, t):
+        """a request BEHIND the window (ClipShardRunner asks for the hand-off frame e-1 first, then works through s .. e-1): the window
+        restarts at t. Decodes in flight beyond the new window give their staging slots back (cancelled, or waited for when a worker
+        already has them) - they would otherwise sit on the ring until the consumer gets there, and the frames in between would
+        all be decoded on the spot (every shard frame took the out-of-window path)."""
+        for u in [u for u in self._pending if u > t + self.ahead]:
+            fut, slot = self._pending.pop(u)
+            if not fut.cancel():
+                try:
+                    fut.result()
+                except Exception:
+                    pass
+            self._free.append(slot)
+        self._next = t
     def __call__(self, t):
         import time
         if t in self._ready:
             return self._ready[t]
-        if t >= self._next:                       # random access (a shard that starts mid-clip): start the window there
-            self._next = max(self._next, t)
+        if t not in self._pending:
+            if t >= self._next:                   # ahead of everything submitted (a shard that starts mid-clip): the window starts there
+                self._next = t
+            else:                                 # behind the window: it restarts at t
+                self._rewind(t)
         self._submit_until(t + 1 + self.ahead)
         ent = self._pending.pop(t, None)
-        if ent is None:                           # not in the window (asked again after it was dropped, or behind it): decode it now
+        if ent is None:                           # delivered before and dropped since, or the ring is full: decode it now
+            self.out_of_window += 1
             if not self._free:
                 raise RuntimeError('ClipFeeder: frame %d requested outside the decode window with every staging buffer in flight' % t)
-            slot = self._free.pop()
-            if self._events[slot] is not None:
-                self._events[slot].synchronize()                                  # as in _submit_until: the last upload from this slot is done
-                self._events[slot] = None
+            slot = self._take_slot()
             ent = (self._pool.submit(self._decode, self.files[t], slot), slot)
         fut, slot = ent
         c0 = time.perf_counter()
@@ -249,7 +285,8 @@ class ClipFeeder:
             d = src.numpy().copy()                 # host stand-in (tests): own copy, the slot goes back to the ring
         out = self.prep.prep(d)[0].unsqueeze(0)
         self.stats['upload_prep_s'] += time.perf_counter() - c1
-        self._free.append(slot)
+        self._free.append(slot)                    # to the BACK of the ring: it is reused after every other free slot
+        self._done.add(t)
         self._submit_until(t + 1 + self.ahead)
         self._ready[t] = out
         for old in [k for k in self._ready if k < t - 1]:      # frame t-1 stays: it is frame t's reference
