@@ -340,6 +340,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     total_frames = args.steps * world
+    ws_timed_gb = round(model.workspace_bytes() / 1e9, 2) if hasattr(model, 'workspace_bytes') else None      # what the timed configuration holds
 
     # ---- untimed: BASELINE config 4 as stated — the fixed 30-frame clip over N GPUs (strong scaling) ----------------------------
     clip30 = None
@@ -598,9 +599,11 @@ def main():
                        'detections_per_frame': round(ndet / max(total_frames, 1), 1),
                        'parallelism': ('clip-shard x%d (contiguous shards of %d frames), 1 p2p feature hand-off per shard boundary, tracker replay '
                                        'on rank 0 + result gather inside the timed region' % (world, args.steps)) if use_runner else 'single GPU',
-                       'pipelining': 'two HIP streams per frame + a third for the next frame of the clip (FlowNet2 + ResNet/FPN, image-only stages, ring of '
-                                     'three workspaces), enqueued before the current frame\'s neck' if (use_runner and not args.no_prefetch and not args.single_stream) else 'two HIP streams per frame' if not args.single_stream else 'one stream',
-                       'workspace_GB': round(sum(w.nbytes() for w in [getattr(model, '_ws', None)] + list(getattr(model, '_ring', None) or []) if w is not None) / 1e9, 2),
+                       'pipelining': ('two HIP streams per frame (neck + detection heads || semantic head) + %d for the image-only stages of the NEXT frame of the clip '
+                                      '(FlowNetC-S-S chain | ResNet + FPN + gather | FlowNetSD; ring of three workspaces), enqueued before the current frame\'s neck'
+                                      % getattr(model, 'pre_streams', 1)) if (use_runner and not args.no_prefetch and not args.single_stream) else 'two HIP streams per frame' if not args.single_stream else 'one stream',
+                       'workspace_GB': ws_timed_gb,
+                       'workspace_GB_after_the_untimed_extras': round(model.workspace_bytes() / 1e9, 2),       # + the one-stream instrumented frame, the per-call loop
                        'timed_region': 'inputs resident in HBM; excludes the H2D of the two 25 MB frames and the D2H of the two uint8 maps that '
                                        'tools/test_vpq.py:46-56 pays (~0.4 ms per frame over PCIe 5 x16 when not overlapped)'},
             'roofline': roof, 'stage_ms': stages,
@@ -626,9 +629,13 @@ def main():
             line['other_arithmetic'] = other
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is reported at N = 1 only (it takes about a minute of host time)
             line['cpu_baseline'] = cpu_baseline(args.seed)
-        print(json.dumps(line))
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line is the last thing this process writes (communicator teardown / library chatter comes before it)
+        sys.stdout.flush(); sys.stderr.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == '__main__':

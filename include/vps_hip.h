@@ -290,6 +290,15 @@ int vps_mask_commit(const float* logit, int S, int bx1, int by1, int bx2, int by
 int vps_mask_removal(const float* logits, int S, const int32_t* boxes, const int32_t* cls0, const int32_t* mask_idx,
                      int n, int ncls, int H, int W, uint8_t* occ, double thr, int32_t* flags, void* stream);
 
+/* the same loop in ONE launch with one workgroup PER BOX of the score-sorted walk (round 5): a box finds the earlier same-class boxes
+ * whose rectangles intersect its own, waits (bounded) until each has published its decision, then counts, decides (flags[i]) and
+ * commits - independent boxes run side by side, dependent ones back to back without a launch in between. Arguments as above
+ * (n <= 256, W % 4 == 0, occ 4-byte aligned; occ and `done` [n] are zeroed by the call). status: bit 2 (value 4) is OR-ed in when a
+ * wait expired (never expected: boxes wait for lower workgroup indices only) - the caller must treat the frame as failed. */
+int vps_mask_removal_dep(const float* logits, int S, const int32_t* boxes, const int32_t* cls0, const int32_t* mask_idx,
+                         int n, int ncls, int H, int W, uint8_t* occ, double thr, int32_t* flags, int32_t* done,
+                         int32_t* status, void* stream);
+
 /* one dependency LEVEL of the MaskRemoval loop (count launch + commit launch): `level` = nlevel indices (device) into the
  * score-sorted box arrays whose boxes are mutually independent (no earlier same-class box of the same level intersects
  * them); counts [n][2] and occ must have been zeroed by the caller before the first level; max_area = largest clipped

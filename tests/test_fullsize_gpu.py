@@ -15,6 +15,7 @@ import numpy as np
 import pytest
 import torch
 
+import tolerances as T
 import vps_amd
 from vps_amd import hip, nhwc, synth
 
@@ -111,6 +112,33 @@ def test_full_size_run_is_deterministic_and_stream_schedule_invariant(dev, clip,
     for t, (a, b) in enumerate(zip(default_run, again)):
         for k in b:
             assert np.array_equal(a[k], b[k]), (t, k)
+
+
+def test_full_size_workspace_fits_12_GB_in_the_pipelined_schedule(dev, clip):
+    """liveness-based reuse of the activation buffers - at 1024x2048, with the prefetch ring and all image-stage
+    streams active, the detector's workspaces (persistent buffers + block pool) stay below 12 GB (round 4: 35.7 GB); the pooled run is
+    bitwise the default run of this module (one stream pair, no prefetch) - which itself is compared against the exact-fp32 kernels"""
+    from vps_amd.clip_shard import ClipShardRunner, DetectorBackend
+    m = _model(hip.PREC_F16X3)
+    outs = ClipShardRunner(DetectorBackend(m, H, W, prefetch=True), 0, 1, None, dev).run(lambda t: clip[t % NFR], 6)
+    torch.cuda.synchronize()
+    gb = m.workspace_bytes() / 1e9
+    print('workspace at %dx%d, pipelined, 3 image-stage streams: %.2f GB (pool %.2f GB in %d blocks)' % (H, W, gb, m._ws.pool.total / 1e9, m._ws.pool.blocks))
+    assert gb < 12.0, gb
+    assert not m._ws._live and not m._lane._live
+    # the same frames through plain per-frame calls without prefetch on a model whose workspace keeps one buffer per activation
+    old = nhwc.POOLING
+    nhwc.POOLING = False
+    try:
+        m2 = _model(hip.PREC_F16X3)
+        ref = _run(m2, clip, dev)
+    finally:
+        nhwc.POOLING = old
+    for t in range(NFR):
+        assert np.array_equal(outs[t]['panoptic_outputs'].cpu().numpy(), ref[t]['panoptic_outputs']), t
+        assert np.array_equal(np.asarray(outs[t]['panoptic_det_obj_ids']), ref[t]['panoptic_det_obj_ids']), t
+    # (that model holds one buffer per activation but no prefetch ring: 11.7 GB against 8.1 GB for the pooled pipeline WITH its ring)
+    assert m2.workspace_bytes() > 1.3 * m.workspace_bytes()
 
 
 def test_full_size_reference_feature_cache_equals_recompute(dev, clip, default_run):
@@ -217,7 +245,7 @@ def test_full_size_outputs_match_reference_golden(dev, prec_name):
                      'panoptic class-map mismatch %.5f%% sem mismatch %.5f%%' % (prec_name, t, {k: '%.2e' % v for k, v in stage.items()}, nun,
                                                                               len(r['panoptic_cls_inds']), len(gc), unmatched, strict, 100 * dcls, 100 * dsem))
         print(lines[-1])
-        fails += ['f%d %s %.2e' % (t, k, v) for k, v in stage.items() if not v < 2e-3]
+        fails += ['f%d %s %.2e' % (t, k, v) for k, v in stage.items() if not v < T.stage_tol(k)]
         if nun > 30:
             fails.append('f%d proposals: %d of 1000 unmatched' % (t, nun))
         if unmatched > 1:

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 import torch
 
+import tolerances as T
 import vps_amd
 from vps_amd import synth
 
@@ -112,7 +113,7 @@ def test_stage_tensors_match_oracle(setup, runs, t):
     with open(os.path.join(ROOT, 'gpurun_out', 'stage_errors.txt'), 'a') as f:
         f.write('%s frame %d %s swaps %d\n' % (setup['prec'], t, errs, nswap))
     for k, v in errs.items():
-        assert v < 2e-3, (k, v, errs)
+        assert v < T.stage_tol(k), (k, v, errs)
 
 
 @pytest.mark.parametrize('t', [0, 1, 2])
@@ -151,7 +152,7 @@ def test_stage_tensors_match_reference_golden(setup, runs, t):
     errs['bbox_pred'] = _relmax(a['bbox_pred'][good], torch.from_numpy(g[p + 'bbox_pred'])[match][good])
     print('[%s] frame %d vs golden file: %s' % (setup['prec'], t, {k: '%.2e' % v for k, v in errs.items()}))
     for k, v in errs.items():
-        assert v < 2e-3, (k, v, errs)
+        assert v < T.stage_tol(k), (k, v, errs)
 
 
 def test_reference_feature_cache_equals_recompute(setup):
@@ -292,6 +293,36 @@ def test_image_stage_stream_fan_out_is_bitwise_the_single_prefetch_stream(setup)
         for t in range(len(frd)):
             for k in runs[0][t]:
                 assert np.array_equal(runs[0][t][k], r[t][k]), (t, k)
+
+
+def test_pooled_workspace_is_bitwise_the_buffer_per_activation_workspace(setup):
+    """nhwc.Workspace temporaries (liveness-based reuse of activation blocks per stream, round 5) against one persistent buffer per
+    activation (VPS_WS_POOL=0, the round-4 workspace): bitwise equal outputs over a clip long enough to recycle every ring slot, in the
+    pipelined schedule; and every temporary is back in its pool at the end of a frame"""
+    from vps_amd.clip_shard import ClipShardRunner, DetectorBackend
+    m, fr, dev = setup['model'], setup['frames'], setup['dev']
+    H, W, n = setup['H'], setup['W'], setup['n']
+    frd = [fr[t % n].to(dev).clone() for t in range(8)]
+    runs, sizes = [], []
+    old = nhwc.POOLING
+    try:
+        for pooling in (True, False):
+            nhwc.POOLING = pooling
+            m._ws = None; m._cache = None; m._pf = None; m.reset_tracker()          # fresh workspaces in that mode
+            outs = ClipShardRunner(DetectorBackend(m, H, W, prefetch=True), 0, 1, None, dev).run(lambda t: frd[t], len(frd))
+            torch.cuda.synchronize()
+            assert m._ws.pooling == pooling and not m._ws._live and not m._lane._live
+            sizes.append(m.workspace_bytes())
+            runs.append([{k: (v.cpu().numpy().copy() if torch.is_tensor(v) else np.asarray(v).copy()) for k, v in o.items()
+                          if k in ('panoptic_det_obj_ids', 'panoptic_outputs', 'fcn_outputs', 'panoptic_cls_prob')} for o in outs])
+    finally:
+        nhwc.POOLING = old
+        m._ws = None; m._cache = None; m._pf = None; m.reset_tracker()
+    for t in range(len(frd)):
+        for k in runs[0][t]:
+            assert np.array_equal(runs[0][t][k], runs[1][t][k]), (t, k)
+    print('workspace bytes pooled %.1f MB, one buffer per activation %.1f MB' % (sizes[0] / 1e6, sizes[1] / 1e6))
+    assert sizes[0] < 0.75 * sizes[1]
 
 
 def test_streamed_records_of_another_rank_replay_to_the_sequential_ids(setup):

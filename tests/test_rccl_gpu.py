@@ -87,6 +87,8 @@ def test_bench_rccl_branch_at_world_1(dev):
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--height', '128', '--width', '256',
                         '--no-extras', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=400, cwd=ROOT)
     assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
-    j = json.loads(p.stdout.strip().splitlines()[-1])
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, (p.stdout[-1500:], p.stderr[-1500:])           # ONE JSON line (library chatter may surround it)
+    j = json.loads(lines[0])
     assert j['n_gpus'] == 1 and j['rccl_ranks'] == 1 and j['steps'] == 3 and j['value'] > 0
     assert 'RCCL' in j['config']['backend']

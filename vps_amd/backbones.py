@@ -70,22 +70,33 @@ class ResNet(HipModule):
     def run(self, x, ws, tag):
         """x: FMap [1,H,W,3(+pad)] normalised RGB. Returns [C2..C5] FMaps (resnet.py:506-517)."""
         self.ensure_packed(x.t.device)
-        t = self._stem(x, ws=ws, name=tag + 'stem')
-        p = ws.fmap(tag + 'pool', t.N, (t.H + 1) // 2, (t.W + 1) // 2, 64)
+        # every map below is produced and consumed on the current stream: temporaries of the workspace, released after their last
+        # consumer is enqueued (the stage outputs are the caller's to release: FPN's lateral convolutions read them)
+        t = self._stem(x, ws=ws, name=tag + 'stem', temp=True)
+        p = ws.fmap(tag + 'pool', t.N, (t.H + 1) // 2, (t.W + 1) // 2, 64, temp=True)
         x = nhwc.pool3x3s2(t, p, 'max')
+        ws.release(t)
         outs = []
         for si, stage in enumerate(self._blocks):
             for bi, b in enumerate(stage):
                 n = '%sl%d.%d.' % (tag, si + 1, bi)
-                idn = x if b['ds'] is None else b['ds'](x, ws=ws, name=n + 'ds')
-                y = b['c1'](x, ws=ws, name=n + 'c1')
-                y = b['c2'](y, ws=ws, name=n + 'c2')
-                x = b['c3'](y, ws=ws, name=n + 'c3', res=idn)
+                idn = x if b['ds'] is None else b['ds'](x, ws=ws, name=n + 'ds', temp=True)
+                y1 = b['c1'](x, ws=ws, name=n + 'c1', temp=True)
+                y2 = b['c2'](y1, ws=ws, name=n + 'c2', temp=True)
+                ws.release(y1)
+                xn = b['c3'](y2, ws=ws, name=n + 'c3', res=idn, temp=True)
+                ws.release(y2, idn if idn is not x else None)
+                if not outs or x is not outs[-1]:
+                    ws.release(x)                      # the previous block's output (not a stage output: those stay for the caller)
+                x = xn
             if si in self.out_indices:
                 outs.append(x)
+        if not outs or x is not outs[-1]:
+            ws.release(x)
         return outs
 
     def forward(self, x):
         """NCHW operator-level API (reference call signature): tuple of NCHW stage outputs."""
         ws = nhwc.Workspace(x.device)
+        ws.pooling = False                  # one-off operator call: plain buffers
         return tuple(o.to_nchw() for o in self.run(nhwc.from_nchw(x), ws, 'bb.'))

@@ -20,13 +20,17 @@ __device__ __forceinline__ void cv_lin_coord(int d, int dst, int src, int& s0, i
     f = fx;
 }
 
+__device__ __forceinline__ float lerp_taps(const float* __restrict__ m28, int S, int x0, int x1, float fx, int y0, int y1, float fy) {
+    const float r0 = m28[y0 * S + x0] * (1.f - fx) + m28[y0 * S + x1] * fx;
+    const float r1 = m28[y1 * S + x0] * (1.f - fx) + m28[y1 * S + x1] * fx;
+    return r0 * (1.f - fy) + r1 * fy;
+}
+
 __device__ __forceinline__ float resized_logit(const float* __restrict__ m28, int S, int dx, int dy, int w, int h) {
     int x0, x1, y0, y1; float fx, fy;
     cv_lin_coord(dx, w, S, x0, x1, fx);
     cv_lin_coord(dy, h, S, y0, y1, fy);
-    const float r0 = m28[y0 * S + x0] * (1.f - fx) + m28[y0 * S + x1] * fx;
-    const float r1 = m28[y1 * S + x0] * (1.f - fx) + m28[y1 * S + x1] * fx;
-    return r0 * (1.f - fy) + r1 * fy;
+    return lerp_taps(m28, S, x0, x1, fx, y0, y1, fy);
 }
 
 struct BoxGeom {
@@ -186,6 +190,115 @@ void mask_level_commit_kernel(const float* __restrict__ logits, int S, const int
 }
 
 // ------------------------------------------------------------------------------------------------
+// MaskRemoval in ONE launch, dependency-driven (round 5; replaces ~20 level launch pairs = 0.6 ms of a frame): one workgroup per
+// box of the score-sorted walk. Box i depends on the EARLIER boxes j < i of its class whose rectangles intersect it (the only ones
+// whose occupancy it can see, mask_removal.py:75-80); it finds them itself, waits until each has published its decision, then counts,
+// decides and commits like the level kernels. Independent boxes run side by side, chains run back to back without a launch in between.
+//   * cross-workgroup traffic goes through AGENT-scope relaxed atomics (occupancy words: atomic OR / atomic load; `done` flags: atomic
+//     store / load), which are coherent across the XCDs' L2s access by access - no L2 write-back / invalidate fences (a device-scope
+//     fence per workgroup costs an L2 flush beside the conv kernels of the other streams: DESIGN.md 3.1, split-K last-block experiment);
+//     the flag is published after `s_waitcnt vmcnt(0)` of every lane + a barrier: all occupancy updates of the box are performed by then.
+//   * no deadlock: a box waits for LOWER workgroup indices only and workgroups are dispatched in index order. The wait is bounded all
+//     the same (SPIN_LIMIT polls ~ 1 s): on expiry status bit 2 is raised and the box decides on what it sees - a wedged GPU is not an option.
+//   * cv2.resize coordinates (an fp64 division per axis) are tabulated once per box in LDS instead of per pixel, the 28x28 logits sit
+//     in LDS; a thread handles one 4-pixel occupancy word per step (W % 4 == 0).
+// ------------------------------------------------------------------------------------------------
+constexpr int MR_THREADS = 1024;
+constexpr int MR_TAB = 2048;             // largest box edge with tabulated coordinates (larger: per-pixel coordinates)
+constexpr int MR_SPIN_LIMIT = 1 << 22;
+
+__global__ __launch_bounds__(MR_THREADS)
+void mask_removal_dep_kernel(const float* __restrict__ logits, int S, const int* __restrict__ boxes, const int* __restrict__ cls0,
+                             const int* __restrict__ mask_idx, int n, int H, int W, unsigned* __restrict__ occ_words, double thr,
+                             int* __restrict__ flags, int* __restrict__ done, int* __restrict__ status) {
+    __shared__ float m28[32 * 32];
+    __shared__ short tx0[MR_TAB], tx1[MR_TAB], ty0[MR_TAB], ty1[MR_TAB];
+    __shared__ float tfx[MR_TAB], tfy[MR_TAB];
+    __shared__ int deps[256];
+    __shared__ int ndeps, red[2][MR_THREADS / 64], decision;
+    const int i = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const BoxGeom g = box_geom(boxes[4 * i], boxes[4 * i + 1], boxes[4 * i + 2], boxes[4 * i + 3], H, W);
+    const int cls = cls0[i];
+    const int rw = g.x1 - g.x0, rh = g.y1 - g.y0;
+    const bool tab = g.w <= MR_TAB && g.h <= MR_TAB && S <= 32;
+    if (t == 0) ndeps = 0;
+    for (int k = t; k < S * S; k += MR_THREADS) m28[k] = logits[(size_t)mask_idx[i] * S * S + k];
+    if (tab) {
+        // coordinates of the CLIPPED columns / rows only (index = position inside the clipped region)
+        for (int k = t; k < rw; k += MR_THREADS) { int a, b; float f; cv_lin_coord(g.x0 + k - g.bx1, g.w, S, a, b, f); tx0[k] = (short)a; tx1[k] = (short)b; tfx[k] = f; }
+        for (int k = t; k < rh; k += MR_THREADS) { int a, b; float f; cv_lin_coord(g.y0 + k - g.by1, g.h, S, a, b, f); ty0[k] = (short)a; ty1[k] = (short)b; tfy[k] = f; }
+    }
+    __syncthreads();
+    // ---- dependencies: earlier same-class boxes whose clipped rectangles intersect this one (the host's level rule, panoptic_ops.py)
+    for (int j = t; j < i; j += MR_THREADS) {
+        if (cls0[j] != cls) continue;
+        const BoxGeom q = box_geom(boxes[4 * j], boxes[4 * j + 1], boxes[4 * j + 2], boxes[4 * j + 3], H, W);
+        if (q.x0 < g.x1 && g.x0 < q.x1 && q.y0 < g.y1 && g.y0 < q.y1) deps[atomicAdd(&ndeps, 1)] = j;
+    }
+    __syncthreads();
+    if (t < ndeps) {
+        int spins = 0;
+        while (__hip_atomic_load(&done[deps[t]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > MR_SPIN_LIMIT) { atomicOr(status, 4); break; }
+        }
+    }
+    __syncthreads();
+    auto logit_at = [&](const int kx, const int ky) -> float {
+        if (tab) return lerp_taps(m28, S, tx0[kx], tx1[kx], tfx[kx], ty0[ky], ty1[ky], tfy[ky]);
+        return resized_logit(m28, S, g.x0 + kx - g.bx1, g.y0 + ky - g.by1, g.w, g.h);
+    };
+    // ---- the clipped region in 4-pixel words: columns xw0 .. xw1 (word-aligned), rows y0 .. y1
+    const int xw0 = g.x0 & ~3, nwx = rw > 0 ? ((g.x1 + 3) >> 2) - (xw0 >> 2) : 0;
+    const long nwords = rh > 0 ? (long)nwx * rh : 0;
+    unsigned* __restrict__ plane = occ_words + ((size_t)cls * H * W >> 2);
+    int ms = 0, ov = 0;
+    for (long wd = t; wd < nwords; wd += MR_THREADS) {
+        const int ky = (int)(wd / nwx), xb = xw0 + 4 * (int)(wd - (long)ky * nwx);
+        const int yy = g.y0 + ky;
+        unsigned posm = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int xx = xb + e;
+            if (xx >= g.x0 && xx < g.x1 && logit_at(xx - g.x0, ky) > 0.f) posm |= 0xFFu << (8 * e);
+        }
+        if (posm) {
+            ms += __popc(posm) >> 3;
+            const unsigned o = __hip_atomic_load(&plane[((size_t)yy * W + xb) >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // bytes of `o` are 0 or 1: occupied positive pixels
+            ov += __popc(o & posm & 0x01010101u);
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) { ms += __shfl_xor(ms, off, 64); ov += __shfl_xor(ov, off, 64); }
+    if (lane == 0) { red[0][wave] = ms; red[1][wave] = ov; }
+    __syncthreads();
+    if (t == 0) {
+        int a = 0, b = 0;
+        for (int w = 0; w < MR_THREADS / 64; ++w) { a += red[0][w]; b += red[1][w]; }
+        const int keep = (a != 0 && !((double)b / (double)a > thr)) ? 1 : 0;
+        decision = keep;
+        flags[i] = keep;
+    }
+    __syncthreads();
+    if (decision) {
+        for (long wd = t; wd < nwords; wd += MR_THREADS) {
+            const int ky = (int)(wd / nwx), xb = xw0 + 4 * (int)(wd - (long)ky * nwx);
+            unsigned setm = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int xx = xb + e;
+                if (xx >= g.x0 && xx < g.x1 && logit_at(xx - g.x0, ky) > 0.f) setm |= 1u << (8 * e);
+            }
+            if (setm) __hip_atomic_fetch_or(&plane[((size_t)(g.y0 + ky) * W + xb) >> 2], setm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // every lane's occupancy updates have been performed (agent scope) before the flag goes out
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(&done[i], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused panoptic combine. For every full-resolution pixel:
 //   fcn_output[c] = bilinear x4 (align_corners=False) of fcn_score[c]           (upsnetFPN.py:81)
 //   sem = argmax_c fcn_output[c]                                                 (panoptic_fusetrack.py:593)
@@ -328,6 +441,23 @@ extern "C" int vps_mask_removal(const float* logits, int S, const int32_t* boxes
     e = hipMemsetAsync(flags, 0, sizeof(int32_t) * n, s);
     if (e != hipSuccess) return -(int)e;
     hipLaunchKernelGGL(mask_removal_kernel, dim3(ncls), dim3(1024), 0, s, logits, S, boxes, cls0, mask_idx, n, H, W, occ, thr, flags);
+    return vps_launch_status();
+}
+
+extern "C" int vps_mask_removal_dep(const float* logits, int S, const int32_t* boxes, const int32_t* cls0, const int32_t* mask_idx,
+                                    int n, int ncls, int H, int W, uint8_t* occ, double thr, int32_t* flags, int32_t* done,
+                                    int32_t* status, void* stream) {
+    if (!logits || !boxes || !cls0 || !mask_idx || !occ || !flags || !done || !status || S < 2 || n < 0 || n > 256 || ncls <= 0 || H <= 0 || W <= 0)
+        return VPS_EARG(1);
+    if ((W & 3) || ((uintptr_t)occ & 3)) return VPS_EARG(2);                     // 4-pixel occupancy words
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(occ, 0, (size_t)ncls * H * W, s);
+    if (e != hipSuccess) return -(int)e;
+    if (n == 0) return 0;
+    e = hipMemsetAsync(done, 0, sizeof(int32_t) * n, s);
+    if (e != hipSuccess) return -(int)e;
+    hipLaunchKernelGGL(mask_removal_dep_kernel, dim3(n), dim3(MR_THREADS), 0, s, logits, S, boxes, cls0, mask_idx, n, H, W,
+                       reinterpret_cast<unsigned*>(occ), thr, flags, done, status);
     return vps_launch_status();
 }
 

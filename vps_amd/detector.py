@@ -125,6 +125,7 @@ class PanopticFuseTrack(HipModule):
         self._pre_aux = []                 # the extra prefetch streams (pre_streams > 1)
         self._pre = None                   # prefetch stream + its ring of workspaces (clip pipelines)
         self._ring = None
+        self._lane = None
         self._slot = 0
         self._ws = None
         self._flip = 0
@@ -164,12 +165,14 @@ class PanopticFuseTrack(HipModule):
     def extract_feat(self, img):
         """reference API (NCHW in, tuple of NCHW FPN levels out)"""
         ws = nhwc.Workspace(img.device)
+        ws.pooling = False                 # one-off API call: plain buffers
         lv = self.neck.run(self.backbone.run(nhwc.from_nchw(img), ws, 'bb.'), ws, 'fpn.')
         return tuple(l.to_nchw() for l in lv)
 
     def compute_flow(self, img, ref_img, scale_factor=1):
         """panoptic_fusetrack.py:117-143 (NCHW API). Returns (flow [1,2,h,w], None)."""
         ws = nhwc.Workspace(img.device)
+        ws.pooling = False
         self.ensure_packed(img.device)
         flow = self.flownet2.run(img, ref_img, self._mean_t, self._std_t, ws)
         if scale_factor != 1:
@@ -269,9 +272,7 @@ class PanopticFuseTrack(HipModule):
             raise hip.VpsHipError('PanopticFuseTrack runs on the device only (no CPU path)')
         dev = img.device
         self.ensure_packed(dev)
-        if self._ws is None or self._ws.device != dev:
-            self._ws = nhwc.Workspace(dev)
-        ws = self._ws
+        ws = self._workspace(dev)
         if self.profile is not None:
             self.profile['events'] = []
         self._mark('start')
@@ -302,40 +303,36 @@ class PanopticFuseTrack(HipModule):
             x = [nhwc.from_nchw(l.to(dev), ws, 'inj.neck%d' % i) for i, l in enumerate(inject['neck_out'])]
         elif not self.with_fusion:
             # PanopticTrack (panoptic_track.py:447): the FPN outputs feed the heads directly
-            levels = self.neck.run(self.backbone.run(nhwc.from_nchw(img, ws, 'img_nhwc'), ws, 'bb.'), ws, 'fpn.')
+            with ws.scope():
+                levels = self.neck.run(self.backbone.run(nhwc.from_nchw(img, ws, 'img_nhwc'), ws, 'bb.'), ws, 'fpn.')
             x = levels
             self._mark('backbone_fpn')
         else:
             pf, self._pf = self._pf, None
-            if side is not None and prefetch is not None:
-                self._enqueue_image_stages(prefetch[0], prefetch[1], main)
-            if pf is not None and side is not None and pf['img'] is img and pf['ref'] is ref_img and pf['version'] == (img._version, ref_img._version):
-                # (1)+(2) were enqueued on the prefetch stream during the previous call
+            if side is not None:
+                # (1) flow + (2) backbone / FPN / gather of THIS frame: enqueued on the prefetch streams during the previous call
+                # (matched by tensor identity), or now - through the same machinery (the image-stage streams, the lane workspace
+                # whose temporaries all ring slots share, a ring slot for the outputs), ahead of the next frame's
+                hit = pf is not None and pf['img'] is img and pf['ref'] is ref_img and pf['version'] == (img._version, ref_img._version)
+                if not hit:
+                    if pf is not None:
+                        # an unused prefetch (the caller announced other tensors than it now passes): the prefetch streams may still be
+                        # reading those tensors, which the caller is now free to rewrite on the main stream - so the main stream orders
+                        # itself behind them. Its results sit in a ring slot nobody reads.
+                        main.wait_event(pf['event'])
+                    pf = self._enqueue_image_stages(img, ref_img, main)
+                if prefetch is not None:
+                    self._pf = self._enqueue_image_stages(prefetch[0], prefetch[1], main)
                 main.wait_event(pf['event'])
                 flow, levels, cat = pf['flow'], pf['levels'], pf['cat']
                 self._mark('flownet2')
             else:
                 if pf is not None:
-                    # an unused prefetch (the caller announced other tensors than it now passes): the prefetch stream may still be
-                    # reading those tensors, which the caller is now free to rewrite on the main stream — so the main stream orders
-                    # itself behind it. Its results sit in a ring workspace nobody reads (ring slots have ONE gathered-
-                    # feature buffer each and leave the A/B alternation of the main workspace alone).
-                    if main is not None:
-                        main.wait_event(pf['event'])
-                    else:
-                        pf['event'].synchronize()
-                # (1) flow ---------------------------------------------------------------------------------------------
-                if side is not None:
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side):
-                        flow = self.flownet2.run(img, ref_img, self._mean_t, self._std_t, ws, sd_stream=self._sd_stream(dev))
-                else:
-                    flow = self.flownet2.run(img, ref_img, self._mean_t, self._std_t, ws)
+                    pf['event'].synchronize()
+                # one stream (profiling, overlap_streams off): the serial schedule in the main workspace
+                flow = self.flownet2.run(img, ref_img, self._mean_t, self._std_t, ws)
                 self._mark('flownet2')
-                # (2) backbone + FPN of the target frame -----------------------------------------------------------------
                 levels, cat = self._backbone_fpn_gather(img, ws)
-                if side is not None:
-                    main.wait_stream(side)
             C = self.extra_neck.in_channels
             # flowR2T = F.interpolate(flow, 0.25, bilinear) * 0.25 written straight into the LiteFlowNet input buffer
             nhwc.resize(flow, cat.window(C + 81, 2), 'bilinear', 0.25)
@@ -350,7 +347,8 @@ class PanopticFuseTrack(HipModule):
             elif self.reuse_ref_features and iid >= 0 and is_first:
                 ref_bsf = cat.window(0, C)        # datasets/cityscapes_vps.py:137-148: the first frame's ref is itself
             else:
-                rl = self.neck.run(self.backbone.run(nhwc.from_nchw(ref_img, ws, 'ref_nhwc'), ws, 'rbb.'), ws, 'rfpn.')
+                with ws.scope():
+                    rl = self.neck.run(self.backbone.run(nhwc.from_nchw(ref_img, ws, 'ref_nhwc'), ws, 'rbb.'), ws, 'rfpn.')
                 ref_bsf = self.extra_neck.gather(rl, ws, 'neck.refcat').window(0, C)
                 self._mark('ref_backbone_fpn')
             self._cache = dict(iid=iid, cat=cat, shape=(H, W), probe=self._probe(img))
@@ -424,6 +422,9 @@ class PanopticFuseTrack(HipModule):
         if cstat & 1:
             raise hip.VpsHipError('vps_panoptic_combine: %d kept instances do not fit the uint8 panoptic map (at most %d)'
                                   % (k, 255 - self.panopticFPN.num_stuff_classes))
+        if cstat & 4:
+            raise hip.VpsHipError('vps_mask_removal_dep: a box waited for a box it depends on beyond the spin limit (the frame is not valid); '
+                                  'VPS_MASK_REMOVAL=level selects the per-level launches')
         keep_inds = th[8:8 + k].astype(np.int64)
         det_obj_ids = None
         if has_ids:
@@ -455,40 +456,56 @@ class PanopticFuseTrack(HipModule):
         return bbox_results, mask_results, pano_results
 
     # ------------------------------------------------------------------------------------------------------
+    def _workspace(self, dev):
+        """main workspace (neck, heads, results), the LANE workspace of the image-only stages (FlowNet2, ResNet + FPN: their persistent
+        internals - the zero-padded concat buffers - exist once, not once per ring slot) and the ring of three OUTPUT workspaces
+        (flow, FPN levels, gathered feature of a prefetched frame). One block pool (per stream) serves all of them."""
+        if self._ws is None or self._ws.device != dev:
+            self._ws = nhwc.Workspace(dev)
+            self._lane = nhwc.Workspace(dev, pool=self._ws.pool)
+            self._ring = [nhwc.Workspace(dev, pool=self._ws.pool) for _ in range(3)]
+        return self._ws
+
+    def workspace_bytes(self):
+        """device bytes held by the detector's workspaces: persistent buffers of the main / lane / ring workspaces + the block pool"""
+        if self._ws is None:
+            return 0
+        return sum(w.nbytes() for w in [self._ws, self._lane] + self._ring) + self._ws.pool.total
+
     def _enqueue_image_stages(self, nimg, nref, main):
-        """The image-only stages (FlowNet2, ResNet + FPN + gather) of the frame the NEXT call will be made with go to the prefetch
-        streams before anything of the current frame is enqueued, so they run beside the current frame's neck and heads, not behind
-        its semantic head: they are the longest chain (~16 ms of the frame's ~22 ms of kernel time) and the main / side streams fill
-        the CUs their low-resolution layers leave idle. With `pre_streams` > 1 the chain itself is split over independent streams
-        (ResNet + FPN + gather beside FlowNet2, FlowNetSD beside FlowNetC -> S -> S). Buffers come from a ring of three private
-        workspaces: slot (t+1) % 3 was last written for frame t-2, whose flow / levels were read by neck(t-2) and whose gathered
-        feature was last read by neck(t-1) as ref_bsf - both enqueued on the main stream in earlier calls, which the waits below
-        order every prefetch stream behind (the main stream is drained at this point anyway: the previous call ended with its
-        end-of-frame read). The images may have been produced on the main stream too. Every auxiliary stream is joined into the
-        first one before the event the consumer waits for is recorded."""
+        """The image-only stages (FlowNet2, ResNet + FPN + gather) of a frame go to the prefetch streams: for the frame the NEXT call
+        will be made with, before anything of the current frame is enqueued, so they run beside the current frame's neck and heads, not
+        behind its semantic head - they are the longest chain (~16 ms of the frame's ~22 ms of kernel time) and the main / side
+        streams fill the CUs their low-resolution layers leave idle. With `pre_streams` > 1 the chain itself is split over independent
+        streams (ResNet + FPN + gather beside FlowNet2, FlowNetSD beside FlowNetC -> S -> S). Internals live in the lane workspace
+        (shared by all frames: a prefetch stream runs one frame after the other), outputs in a ring of three: slot (t+1) % 3 was last
+        written for frame t-2, whose flow / levels were read by neck(t-2) and whose gathered feature was last read by neck(t-1) as
+        ref_bsf - both enqueued on the main stream in earlier calls, which the waits below order every prefetch stream behind. The
+        images may have been produced on the main stream too. Every auxiliary stream is joined into the first one before the event the
+        consumer waits for is recorded. -> the record the consuming call matches by tensor identity."""
         dev = nimg.device
+        self._workspace(dev)
         if self._pre is None or self._pre.device != dev:
             self._pre = torch.cuda.Stream(device=dev)
             self._pre_aux = [torch.cuda.Stream(device=dev) for _ in range(2)]
-            self._ring = [nhwc.Workspace(dev) for _ in range(3)]
         self._pre.wait_stream(main)
         self._slot = (self._slot + 1) % 3
-        rws = self._ring[self._slot]
+        lws = self._lane.with_out(self._ring[self._slot])
         bb_stream = self._pre_aux[0] if self.pre_streams >= 2 else self._pre
         sd_stream = self._pre_aux[1] if self.pre_streams >= 3 else None
         if bb_stream is not self._pre:
             bb_stream.wait_stream(main)
             with torch.cuda.stream(bb_stream):
-                nlevels, ncat = self._backbone_fpn_gather(nimg, rws, ring=True)
+                nlevels, ncat = self._backbone_fpn_gather(nimg, lws, ring=True)
         with torch.cuda.stream(self._pre):
-            nflow = self.flownet2.run(nimg, nref, self._mean_t, self._std_t, rws, sd_stream=sd_stream)
+            nflow = self.flownet2.run(nimg, nref, self._mean_t, self._std_t, lws, sd_stream=sd_stream)
             if bb_stream is self._pre:
-                nlevels, ncat = self._backbone_fpn_gather(nimg, rws, ring=True)
+                nlevels, ncat = self._backbone_fpn_gather(nimg, lws, ring=True)
             else:
                 self._pre.wait_stream(bb_stream)
             ev = torch.cuda.Event()
             ev.record(self._pre)
-        self._pf = dict(img=nimg, ref=nref, version=(nimg._version, nref._version), event=ev, flow=nflow, levels=nlevels, cat=ncat)
+        return dict(img=nimg, ref=nref, version=(nimg._version, nref._version), event=ev, flow=nflow, levels=nlevels, cat=ncat)
 
     @torch.no_grad()
     def prime(self, img, ref_img):
@@ -502,7 +519,7 @@ class PanopticFuseTrack(HipModule):
         pf, self._pf = self._pf, None
         if pf is not None:
             pf['event'].synchronize()
-        self._enqueue_image_stages(img, ref_img, torch.cuda.current_stream(img.device))
+        self._pf = self._enqueue_image_stages(img, ref_img, torch.cuda.current_stream(img.device))
         return True
 
     def _sd_stream(self, dev):
@@ -542,17 +559,17 @@ class PanopticFuseTrack(HipModule):
             # clip sharding: this frame's ResNet+FPN+gather already ran for the hand-off to the next GPU (gathered_feature)
             self._handoff = None
             return pre['levels'], pre['cat']
-        levels = self.neck.run(self.backbone.run(nhwc.from_nchw(img, ws, 'img_nhwc'), ws, 'bb.'), ws, 'fpn.')
+        with ws.scope():          # the stage outputs C2..C5 (temporaries the backbone leaves to its caller) go back when the levels exist
+            levels = self.neck.run(self.backbone.run(nhwc.from_nchw(img, ws, 'img_nhwc'), ws, 'bb.'), ws, 'fpn.')
         return levels, self.extra_neck.gather(levels, ws, 'neck.cat' + tag)
 
     def gathered_feature(self, img):
         """gather(FPN(ResNet(img))) (bfp_tcea.py:96-109,117): the tensor the NEXT frame needs as ref_bsf; [1,H/4,W/4,C]"""
         dev = img.device
         self.ensure_packed(dev)
-        if self._ws is None or self._ws.device != dev:
-            self._ws = nhwc.Workspace(dev)
-        ws = self._ws
-        lv = self.neck.run(self.backbone.run(nhwc.from_nchw(img, ws, 'ho_nhwc'), ws, 'hbb.'), ws, 'hfpn.')
+        ws = self._workspace(dev)
+        with ws.scope():
+            lv = self.neck.run(self.backbone.run(nhwc.from_nchw(img, ws, 'ho_nhwc'), ws, 'hbb.'), ws, 'hfpn.')
         cat = self.extra_neck.gather(lv, ws, 'neck.handoff')
         C = self.extra_neck.in_channels
         # kept for this frame's own simple_test call (its buffers have their own workspace names): the sender does not run
@@ -564,9 +581,7 @@ class PanopticFuseTrack(HipModule):
     def track_assign(self, rec, is_first):
         """sequential tracker step on a deferred record (clip_shard.py) -> ids (host array: the replay is the consumer)"""
         dev = rec['emb'].device
-        if self._ws is None or self._ws.device != dev:
-            self._ws = nhwc.Workspace(dev)
-        ids, _ = self._assign_ids(rec['det_bboxes'], rec['det_labels'], rec['cls_prob'], rec['emb'], is_first, self._ws)
+        ids, _ = self._assign_ids(rec['det_bboxes'], rec['det_labels'], rec['cls_prob'], rec['emb'], is_first, self._workspace(dev))
         K = rec['det_bboxes'].size(0)
         buf = torch.cat([ids[:K], self._mem_count])
         h = buf.cpu().numpy()

@@ -53,6 +53,14 @@ class _RefineS(_Net):
         for n in ('6_to_5', '5_to_4', '4_to_3', '3_to_2'):
             setattr(self, 'upsampled_flow' + n, nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=up_bias))
 
+    def _cats(self, ws, tag, N, h2, w2):
+        """the four decoder concat buffers [encoder | deconv | flow] (194 / 386 / 770 / 1026 channels, zero pad channels: persistent).
+        FlowNetC, FlowNetS_1 and FlowNetS_2 run one after the other on ONE stream and rewrite every window: they share one set
+        (`FlowNet2.run` passes them the same `cat_tag`; FlowNetSD may run beside them and has its own)"""
+        ct = getattr(self, 'cat_tag', None) or tag
+        return (ws.fmap(ct + 'cat2', N, h2, w2, 194), ws.fmap(ct + 'cat3', N, h2 // 2, w2 // 2, 386),
+                ws.fmap(ct + 'cat4', N, h2 // 4, w2 // 4, 770), ws.fmap(ct + 'cat5', N, h2 // 8, w2 // 8, 1026))
+
     def _decode(self, ws, tag, cats, c6):
         """cats = [cat2, cat3, cat4, cat5] buffers whose first window already holds the encoder feature"""
         p = self._p
@@ -82,32 +90,34 @@ class FlowNetC(_RefineS):
         p = self._p
         N, H, W = x6.N, x6.H, x6.W
         h2, w2 = H // 4, W // 4
-        cat2 = ws.fmap(tag + 'cat2', N, h2, w2, 194)
-        cat3 = ws.fmap(tag + 'cat3', N, h2 // 2, w2 // 2, 386)
-        cat4 = ws.fmap(tag + 'cat4', N, h2 // 4, w2 // 4, 770)
-        cat5 = ws.fmap(tag + 'cat5', N, h2 // 8, w2 // 8, 1026)
+        cat2, cat3, cat4, cat5 = self._cats(ws, tag, N, h2, w2)
         # the stem reads 3 channels out of the 6(+2)-channel pair buffer: pack once with cin padded to 4, second image via
         # a 4-aligned copy window
         xa = ws.fmap(tag + 'xa', N, H, W, 3)
         xb = ws.fmap(tag + 'xb', N, H, W, 3)
         hip.check(hip.load().vps_axpb(x6.ptr(), x6.ld, 0, xa.ptr(), xa.ld, 0, x6.npix, 3, 1.0, 0.0, hip.stream_ptr()), 'axpb')
         hip.check(hip.load().vps_axpb(x6.ptr(), x6.ld, 3, xb.ptr(), xb.ld, 0, x6.npix, 3, 1.0, 0.0, hip.stream_ptr()), 'axpb')
-        c1a = p['conv1'](xa, ws=ws, name=tag + 'c1a')
+        # single-consumer encoder maps: temporaries of the caller's scope (FlowNet2.run wraps every sub-network in `ws.scope()`)
+        c1a = p['conv1'](xa, ws=ws, name=tag + 'c1a', temp=True)
         c2a = p['conv2'](c1a, out=cat2.window(0, 128), ws=ws)
-        c3a = p['conv3'](c2a, ws=ws, name=tag + 'c3a')
-        c1b = p['conv1'](xb, ws=ws, name=tag + 'c1b')
-        c2b = p['conv2'](c1b, ws=ws, name=tag + 'c2b')
-        c3b = p['conv3'](c2b, ws=ws, name=tag + 'c3b')
+        ws.release(c1a)
+        c3a = p['conv3'](c2a, ws=ws, name=tag + 'c3a', temp=True)
+        c1b = p['conv1'](xb, ws=ws, name=tag + 'c1b', temp=True)
+        c2b = p['conv2'](c1b, ws=ws, name=tag + 'c2b', temp=True)
+        ws.release(c1b)
+        c3b = p['conv3'](c2b, ws=ws, name=tag + 'c3b', temp=True)
+        ws.release(c2b)
         in31 = ws.fmap(tag + 'in31', N, c3a.H, c3a.W, 473)
         p['conv_redir'](c3a, out=in31.window(0, 32), ws=ws)
         nhwc.correlation(c3a, c3b, in31.window(32, 441), 20, 2, hip.ACT_LEAKY, 0.1)   # corr + corr_activation
+        ws.release(c3a, c3b)
         p['conv3_1'](in31, out=cat3.window(0, 256), ws=ws)
-        t = p['conv4'](cat3.window(0, 256), ws=ws, name=tag + 'c4')
+        t = p['conv4'](cat3.window(0, 256), ws=ws, name=tag + 'c4', temp=True)
         p['conv4_1'](t, out=cat4.window(0, 512), ws=ws)
-        t = p['conv5'](cat4.window(0, 512), ws=ws, name=tag + 'c5')
+        t = p['conv5'](cat4.window(0, 512), ws=ws, name=tag + 'c5', temp=True)
         p['conv5_1'](t, out=cat5.window(0, 512), ws=ws)
-        t = p['conv6'](cat5.window(0, 512), ws=ws, name=tag + 'c6')
-        c6 = p['conv6_1'](t, ws=ws, name=tag + 'c61')
+        t = p['conv6'](cat5.window(0, 512), ws=ws, name=tag + 'c6', temp=True)
+        c6 = p['conv6_1'](t, ws=ws, name=tag + 'c61', temp=True)
         return self._decode(ws, tag, [cat2, cat3, cat4, cat5], c6)
 
 
@@ -126,20 +136,18 @@ class FlowNetS(_RefineS):
         p = self._p
         N, H, W = x12.N, x12.H, x12.W
         h2, w2 = H // 4, W // 4
-        cat2 = ws.fmap(tag + 'cat2', N, h2, w2, 194)
-        cat3 = ws.fmap(tag + 'cat3', N, h2 // 2, w2 // 2, 386)
-        cat4 = ws.fmap(tag + 'cat4', N, h2 // 4, w2 // 4, 770)
-        cat5 = ws.fmap(tag + 'cat5', N, h2 // 8, w2 // 8, 1026)
-        c1 = p['conv1'](x12, ws=ws, name=tag + 'c1')
+        cat2, cat3, cat4, cat5 = self._cats(ws, tag, N, h2, w2)
+        c1 = p['conv1'](x12, ws=ws, name=tag + 'c1', temp=True)
         p['conv2'](c1, out=cat2.window(0, 128), ws=ws)
-        t = p['conv3'](cat2.window(0, 128), ws=ws, name=tag + 'c3')
+        ws.release(c1)
+        t = p['conv3'](cat2.window(0, 128), ws=ws, name=tag + 'c3', temp=True)
         p['conv3_1'](t, out=cat3.window(0, 256), ws=ws)
-        t = p['conv4'](cat3.window(0, 256), ws=ws, name=tag + 'c4')
+        t = p['conv4'](cat3.window(0, 256), ws=ws, name=tag + 'c4', temp=True)
         p['conv4_1'](t, out=cat4.window(0, 512), ws=ws)
-        t = p['conv5'](cat4.window(0, 512), ws=ws, name=tag + 'c5')
+        t = p['conv5'](cat4.window(0, 512), ws=ws, name=tag + 'c5', temp=True)
         p['conv5_1'](t, out=cat5.window(0, 512), ws=ws)
-        t = p['conv6'](cat5.window(0, 512), ws=ws, name=tag + 'c6')
-        c6 = p['conv6_1'](t, ws=ws, name=tag + 'c61')
+        t = p['conv6'](cat5.window(0, 512), ws=ws, name=tag + 'c6', temp=True)
+        c6 = p['conv6_1'](t, ws=ws, name=tag + 'c61', temp=True)
         return self._decode(ws, tag, [cat2, cat3, cat4, cat5], c6)
 
 
@@ -171,26 +179,31 @@ class FlowNetSD(_Net):
         cat3 = ws.fmap(tag + 'cat3', N, h2 // 2, w2 // 2, 386)
         cat4 = ws.fmap(tag + 'cat4', N, h2 // 4, w2 // 4, 770)
         cat5 = ws.fmap(tag + 'cat5', N, h2 // 8, w2 // 8, 1026)
-        c0 = p['conv0'](x6.window(0, 6), ws=ws, name=tag + 'c0')
-        t = p['conv1'](c0, ws=ws, name=tag + 'c1')
-        c1 = p['conv1_1'](t, ws=ws, name=tag + 'c11')
-        t = p['conv2'](c1, ws=ws, name=tag + 'c2')
+        c0 = p['conv0'](x6.window(0, 6), ws=ws, name=tag + 'c0', temp=True)
+        t = p['conv1'](c0, ws=ws, name=tag + 'c1', temp=True)
+        ws.release(c0)                                   # 537 MB at 1024x2048: the largest map of the frame
+        c1 = p['conv1_1'](t, ws=ws, name=tag + 'c11', temp=True)
+        ws.release(t)
+        t = p['conv2'](c1, ws=ws, name=tag + 'c2', temp=True)
+        ws.release(c1)
         p['conv2_1'](t, out=cat2.window(0, 128), ws=ws)
-        t = p['conv3'](cat2.window(0, 128), ws=ws, name=tag + 'c3')
+        ws.release(t)
+        t = p['conv3'](cat2.window(0, 128), ws=ws, name=tag + 'c3', temp=True)
         p['conv3_1'](t, out=cat3.window(0, 256), ws=ws)
-        t = p['conv4'](cat3.window(0, 256), ws=ws, name=tag + 'c4')
+        t = p['conv4'](cat3.window(0, 256), ws=ws, name=tag + 'c4', temp=True)
         p['conv4_1'](t, out=cat4.window(0, 512), ws=ws)
-        t = p['conv5'](cat4.window(0, 512), ws=ws, name=tag + 'c5')
+        t = p['conv5'](cat4.window(0, 512), ws=ws, name=tag + 'c5', temp=True)
         p['conv5_1'](t, out=cat5.window(0, 512), ws=ws)
-        t = p['conv6'](cat5.window(0, 512), ws=ws, name=tag + 'c6')
-        c6 = p['conv6_1'](t, ws=ws, name=tag + 'c61')
+        t = p['conv6'](cat5.window(0, 512), ws=ws, name=tag + 'c6', temp=True)
+        c6 = p['conv6_1'](t, ws=ws, name=tag + 'c61', temp=True)
         flow = p['predict_flow6'](c6, ws=ws, name=tag + 'flow6')
         feat = c6
         for lvl, cat, enc_c, dec_c in ((5, cat5, 512, 512), (4, cat4, 512, 256), (3, cat3, 256, 128), (2, cat2, 128, 64)):
             p['upsampled_flow%d_to_%d' % (lvl + 1, lvl)](flow, out=cat.window(enc_c + dec_c, 2), ws=ws)
             p['deconv%d' % lvl](feat, out=cat.window(enc_c, dec_c), ws=ws)
-            inter = p['inter_conv%d' % lvl](cat, ws=ws, name='%sinter%d' % (tag, lvl))
+            inter = p['inter_conv%d' % lvl](cat, ws=ws, name='%sinter%d' % (tag, lvl), temp=True)
             flow = p['predict_flow%d' % lvl](inter, ws=ws, name='%sflow%d' % (tag, lvl))
+            ws.release(inter)
             feat = cat
         return flow
 
@@ -214,19 +227,23 @@ class FlowNetFusion(_Net):
         cat0 = ws.fmap(tag + 'cat0', N, H, W, 82)
         cat1 = ws.fmap(tag + 'cat1', N, H // 2, W // 2, 162)
         p['conv0'](x11, out=cat0.window(0, 64), ws=ws)
-        t = p['conv1'](cat0.window(0, 64), ws=ws, name=tag + 'c1')
+        t = p['conv1'](cat0.window(0, 64), ws=ws, name=tag + 'c1', temp=True)
         p['conv1_1'](t, out=cat1.window(0, 128), ws=ws)
-        t = p['conv2'](cat1.window(0, 128), ws=ws, name=tag + 'c2')
-        c2 = p['conv2_1'](t, ws=ws, name=tag + 'c21')
+        ws.release(t)
+        t = p['conv2'](cat1.window(0, 128), ws=ws, name=tag + 'c2', temp=True)
+        c2 = p['conv2_1'](t, ws=ws, name=tag + 'c21', temp=True)
+        ws.release(t)
         flow2 = p['predict_flow2'](c2, ws=ws, name=tag + 'flow2')
         p['upsampled_flow2_to_1'](flow2, out=cat1.window(160, 2), ws=ws)
         p['deconv1'](c2, out=cat1.window(128, 32), ws=ws)
-        inter1 = p['inter_conv1'](cat1, ws=ws, name=tag + 'inter1')
+        ws.release(c2)
+        inter1 = p['inter_conv1'](cat1, ws=ws, name=tag + 'inter1', temp=True)
         flow1 = p['predict_flow1'](inter1, ws=ws, name=tag + 'flow1')
+        ws.release(inter1)
         p['upsampled_flow1_to_0'](flow1, out=cat0.window(80, 2), ws=ws)
         p['deconv0'](cat1, out=cat0.window(64, 16), ws=ws)
-        inter0 = p['inter_conv0'](cat0, ws=ws, name=tag + 'inter0')
-        return p['predict_flow0'](inter0, ws=ws, name=tag + 'flow0')
+        inter0 = p['inter_conv0'](cat0, ws=ws, name=tag + 'inter0', temp=True)
+        return p['predict_flow0'](inter0, ws=ws, name=tag + 'flow0', keep=True)       # the network's output: the caller's `out` workspace
 
 
 class FlowNet2(HipModule):
@@ -248,6 +265,8 @@ class FlowNet2(HipModule):
     def pack(self, device):
         for n in (self.flownetc, self.flownets_1, self.flownets_2, self.flownets_d, self.flownetfusion):
             n.pack(device)
+        for n in (self.flownetc, self.flownets_1, self.flownets_2):
+            n.cat_tag = 'fn2.CSS.'
         self._nblk = 512
 
     def run(self, img, ref, mean, std, ws, tag='fn2.', sd_stream=None):
@@ -278,32 +297,42 @@ class FlowNet2(HipModule):
             hip.check(lib.vps_flow_stage_full(x6.ptr(), x6.ld, flow_a.ptr(), flow_a.ld, flow_a.coff, fb.ptr(), fb.ld, fb.coff, H, W, mode, D,
                                               out.ptr(), out.ld, sp()), 'vps_flow_stage_full')
 
+        # Every sub-network runs inside a workspace scope: its single-consumer maps are temporaries that go back to the stream's pool at
+        # the end, so FlowNetC / S1 / S2 / Fusion reuse ONE set of blocks (FlowNetSD on its own stream has its own)
         cur = sd_flow2 = None
         if sd_stream is not None:
             cur = torch.cuda.current_stream(img.device)
             sd_stream.wait_stream(cur)            # the pair buffer is written (and this workspace's previous SD pass was joined below)
-            with torch.cuda.stream(sd_stream):
+            with torch.cuda.stream(sd_stream), ws.scope():
                 sd_flow2 = self.flownets_d.run(x6, ws, tag + 'SD.')
         # whole 12-float pixels per thread (vps_flow_stage_full); the channel-wise vps_flow_stage + vps_axpb pair is the general form
-        c_flow2 = self.flownetc.run(x6, ws, tag + 'C.')
-        concat1 = ws.fmap(tag + 'concat1', 1, H, W, 12)
+        with ws.scope():
+            c_flow2 = self.flownetc.run(x6, ws, tag + 'C.')
+        concat1 = ws.fmap(tag + 'concat1', 1, H, W, 12, temp=True)
         full(0, c_flow2, None, concat1)                                # flownet2.py:142-151
-        s1_flow2 = self.flownets_1.run(concat1, ws, tag + 'S1.')
-        concat2 = ws.fmap(tag + 'concat2', 1, H, W, 12)
+        with ws.scope():
+            s1_flow2 = self.flownets_1.run(concat1, ws, tag + 'S1.')
+        ws.release(concat1)
+        concat2 = ws.fmap(tag + 'concat2', 1, H, W, 12, temp=True)
         full(0, s1_flow2, None, concat2)                               # :154-163
-        s2_flow2 = self.flownets_2.run(concat2, ws, tag + 'S2.')
+        with ws.scope():
+            s2_flow2 = self.flownets_2.run(concat2, ws, tag + 'S2.')
+        ws.release(concat2)
         if sd_stream is None:
-            sd_flow2 = self.flownets_d.run(x6, ws, tag + 'SD.')
+            with ws.scope():
+                sd_flow2 = self.flownets_d.run(x6, ws, tag + 'SD.')
         else:
             cur.wait_stream(sd_stream)
         concat3 = ws.fmap(tag + 'concat3', 1, H, W, 11)
         full(1, s2_flow2, sd_flow2, concat3)                           # :166-187 nearest x4 of flow*20 resp. flow/20 (sic)
-        flow = self.flownetfusion.run(concat3, ws, tag + 'F.')
+        with ws.scope():
+            flow = self.flownetfusion.run(concat3, ws, tag + 'F.')
         if (H, W) != (H0, W0):
             # ... and trims afterwards (:135-138, index_select of the first H0 rows / W0 columns)
-            trimmed = ws.fmap(tag + 'flow_trim', 1, H0, W0, flow.C, ld=flow.ld)
+            trimmed = ws.fmap(tag + 'flow_trim', 1, H0, W0, flow.C, ld=flow.ld, out=True)
             trimmed.t.copy_(flow.t[:, :H0, :W0, :])
             flow = trimmed
+        # (debugging: concat1 / concat2 are temporaries - their contents are valid until the next launch on this stream's pool)
         self._last = dict(x6=x6, c_flow2=c_flow2, concat1=concat1, s1_flow2=s1_flow2, concat2=concat2,
                           s2_flow2=s2_flow2, sd_flow2=sd_flow2, concat3=concat3)
         return flow
@@ -313,6 +342,7 @@ class FlowNet2(HipModule):
         assert inputs.shape[0] == 1
         dev = inputs.device
         ws = nhwc.Workspace(dev)
+        ws.pooling = False
         one = torch.ones(3, device=dev); zero = torch.zeros(3, device=dev)
         flow = self.run(inputs[:, :, 0].contiguous(), inputs[:, :, 1].contiguous(), zero, one, ws)
         return flow.to_nchw()

@@ -64,30 +64,40 @@ class UPSNetFPN(HipModule):
         assert len(levels) == self.num_levels
         l0 = levels[0]
         oc = self.out_channels
-        cat = ws.fmap(tag + 'cat', l0.N, l0.H, l0.W, oc * len(levels))
+        # the tower maps live on this head's stream only: temporaries (the 4 x 128-channel concat included: every window is written
+        # each frame); fcn_score is read by the combine kernel on the main stream: persistent
+        cat = ws.fmap(tag + 'cat', l0.N, l0.H, l0.W, oc * len(levels), temp=True)
         # GroupNorm sums: one zeroed slot per (level, tower layer); the deformable conv's epilogue adds into it (unsplit launches:
         # the two high-resolution levels), else vps_groupnorm_relu makes its own statistics pass
         stats = ws.get(tag + 'gnstats', (len(levels) * len(self._tower), nhwc.GN_REP, 64), dtype=torch.float64)
         stats.zero_()
         for li, x in enumerate(levels):
+            src = x
             for ti, t in enumerate(self._tower):
                 n = '%sl%dt%d' % (tag, li, ti)
                 off = t['off'](x, ws=ws, name=n + 'off')
                 slot = stats[li * len(self._tower) + ti]
-                raw = t['dcn'](x, ws=ws, name=n + 'dcn', offset=off, gn=(slot, t['G']))
+                raw = t['dcn'](x, ws=ws, name=n + 'dcn', offset=off, gn=(slot, t['G']), temp=True)
+                if x is not src:
+                    ws.release(x)
                 last = ti == len(self._tower) - 1
                 if last and li == 0:
                     dst = cat.window(0, oc)
                 else:
-                    dst = ws.fmap(n + 'gn', raw.N, raw.H, raw.W, raw.C)
+                    dst = ws.fmap(n + 'gn', raw.N, raw.H, raw.W, raw.C, temp=True)
                 x = nhwc.groupnorm_relu(raw, dst, t['G'], t['gamma'], t['beta'], t['eps'], slot, stats_ready=t['dcn'].gn_fused)
+                ws.release(raw)
             if li > 0:
                 nhwc.resize(x, cat.window(li * oc, oc), 'bilinear')
-        return self._pred(cat, ws=ws, name=tag + 'fcn_score')
+                ws.release(x)
+        score = self._pred(cat, ws=ws, name=tag + 'fcn_score')
+        ws.release(cat)
+        return score
 
     def forward(self, inputs):
         """reference signature: (fcn_output [1,19,H,W], fcn_score [1,19,H/4,W/4]) NCHW."""
         ws = nhwc.Workspace(inputs[0].device)
+        ws.pooling = False
         score = self.run([nhwc.from_nchw(t) for t in inputs], ws)
         up = nhwc.resize(score, ws.fmap('fcn_output', score.N, score.H * 4, score.W * 4, score.C), 'bilinear')
         return up.to_nchw(), score.to_nchw()
@@ -161,9 +171,10 @@ class RPNHead(HipModule):
         boxes = ws.get(tag + 'boxes', (nlv, nms_pre, 5), zero=False)
         cls_l, reg_l, counts = [], [], []
         for li, x in enumerate(levels):
-            t = self._conv(x, ws=ws, name='%sconv%d' % (tag, li))
+            t = self._conv(x, ws=ws, name='%sconv%d' % (tag, li), temp=True)
             cls_l.append(self._cls(t, ws=ws, name='%scls%d' % (tag, li)))
             reg_l.append(self._reg(t, ws=ws, name='%sreg%d' % (tag, li)))
+            ws.release(t)
             counts.append(min(x.H * x.W * A, nms_pre))
         # rpn_head.py:62-91 for all levels in ONE launch (sigmoid, top nms_pre by score, gathers, delta2bbox): vps_rpn_select.
         # Base anchors as the reference rounds them (anchor_generator.py:28-53), once per device

@@ -42,16 +42,19 @@ class FPN(HipModule):
         lats = [None] * n
         for i in range(n - 1, -1, -1):
             lats[i] = self._lat[i](feats[i], ws=ws, name='%slat%d' % (tag, i),
-                                   res=lats[i + 1] if i + 1 < n else None, res_shift=1 if i + 1 < n else 0)
-        outs = [self._out[i](lats[i], ws=ws, name='%sp%d' % (tag, i + 2)) for i in range(n)]
+                                   res=lats[i + 1] if i + 1 < n else None, res_shift=1 if i + 1 < n else 0, temp=True)
+        # the levels are what the rest of the frame (another stream, the next frame) reads: kept (`out` target of the workspace)
+        outs = [self._out[i](lats[i], ws=ws, name='%sp%d' % (tag, i + 2), keep=True) for i in range(n)]
+        ws.release(*lats)
         for j in range(self.num_outs - n):   # F.max_pool2d(k=1, stride=2) == stride-2 subsample (fpn.py:124-126)
             src = outs[-1]
-            dst = ws.fmap('%sp%d' % (tag, n + 2 + j), src.N, (src.H + 1) // 2, (src.W + 1) // 2, src.C)
+            dst = ws.fmap('%sp%d' % (tag, n + 2 + j), src.N, (src.H + 1) // 2, (src.W + 1) // 2, src.C, out=True)
             outs.append(nhwc.resize(src, dst, 'nearest'))
         return outs
 
     def forward(self, inputs):
         ws = nhwc.Workspace(inputs[0].device)
+        ws.pooling = False
         return tuple(o.to_nchw() for o in self.run([nhwc.from_nchw(t) for t in inputs], ws, 'fpn.'))
 
 
@@ -119,7 +122,7 @@ class BFPTcea(HipModule):
         also what the NEXT frame needs as ref_bsf (bfp_tcea.py:117), so the detector keeps the buffer alive."""
         C = self.in_channels
         l0 = levels[0]
-        cat = ws.fmap(name, l0.N, l0.H, l0.W, C + 81 + 2)
+        cat = ws.fmap(name, l0.N, l0.H, l0.W, C + 81 + 2, out=True)
         nhwc.bfp_gather(levels, cat.window(0, C))
         return cat
 
@@ -131,36 +134,54 @@ class BFPTcea(HipModule):
         N, H, W = cat.N, cat.H, cat.W
         bsf = cat.window(0, C)
         flow_init = cat.window(C + 81, 2)
-        warp1 = nhwc.flow_warp(ref_bsf, flow_init, ws.fmap(tag + 'warp1', N, H, W, C))
+        # everything between the gathered feature and the five outputs lives on the current stream only: temporaries, released after
+        # their last consumer (the aux dict hands flow_fine / warp / fused / refined out: valid until the next call on this workspace
+        # when pooling is on - tools that inspect them switch `ws.pooling` off)
+        T = lambda nm, c: ws.fmap(tag + nm, N, H, W, c, temp=True)
+        warp1 = nhwc.flow_warp(ref_bsf, flow_init, T('warp1', C))
         nhwc.correlation(bsf, warp1, cat.window(C, 81), 4, 1)
         x = cat
         for i, pc in enumerate(self._est):
-            x = pc(x, ws=ws, name='%sest%d' % (tag, i))
+            y = pc(x, ws=ws, name='%sest%d' % (tag, i), temp=True)
+            if x is not cat:
+                ws.release(x)
+            x = y
         flow_fine = x
-        warp2 = nhwc.flow_warp(warp1, flow_fine, ws.fmap(tag + 'warp2', N, H, W, C))
+        warp2 = nhwc.flow_warp(warp1, flow_fine, T('warp2', C))
+        ws.release(warp1)
         # TCEA_Fusion (tcea_modules.py:50-78), frames = [bsf, warp2], center 0
-        T = self._t
-        emb = ws.fmap(tag + 'emb', N, H, W, 2 * C)
-        T['tAtt_1'](bsf, out=emb.window(0, C), ws=ws)
-        T['tAtt_1'](warp2, out=emb.window(C, C), ws=ws)
-        emb_ref = T['tAtt_2'](bsf, ws=ws, name=tag + 'emb_ref')
-        al = nhwc.tcea_temporal(emb, emb_ref, bsf, warp2, ws.fmap(tag + 'aligned', N, H, W, 2 * C))
-        fea = T['fea_fusion'](al, ws=ws, name=tag + 'fea')
-        att = T['sAtt_1'](al, ws=ws, name=tag + 'att1')
+        P = self._t
+        emb = T('emb', 2 * C)
+        P['tAtt_1'](bsf, out=emb.window(0, C), ws=ws)
+        P['tAtt_1'](warp2, out=emb.window(C, C), ws=ws)
+        emb_ref = P['tAtt_2'](bsf, ws=ws, name=tag + 'emb_ref', temp=True)
+        al = nhwc.tcea_temporal(emb, emb_ref, bsf, warp2, T('aligned', 2 * C))
+        ws.release(emb, emb_ref)
+        fea = P['fea_fusion'](al, ws=ws, name=tag + 'fea', temp=True)
+        att = P['sAtt_1'](al, ws=ws, name=tag + 'att1', temp=True)
+        ws.release(al)
         Hh, Wh = (H + 1) // 2, (W + 1) // 2
-        pooled = ws.fmap(tag + 'attpool', N, Hh, Wh, 2 * C)
+        pooled = ws.fmap(tag + 'attpool', N, Hh, Wh, 2 * C, temp=True)
         nhwc.pool3x3s2(att, pooled.window(0, C), 'max')
         nhwc.pool3x3s2(att, pooled.window(C, C), 'avg')
-        att = T['sAtt_2'](pooled, ws=ws, name=tag + 'att2')
-        att = T['sAtt_3'](att, ws=ws, name=tag + 'att3')
-        att_up = nhwc.resize(att, ws.fmap(tag + 'attup', N, 2 * Hh, 2 * Wh, C), 'bilinear')
-        att = T['sAtt_4'](att_up, ws=ws, name=tag + 'att4')
-        add = T['sAtt_add_1'](att, ws=ws, name=tag + 'add1')
-        add = T['sAtt_add_2'](add, ws=ws, name=tag + 'add2')
-        fused = nhwc.tcea_modulate(fea, att, add, ws.fmap(tag + 'fused', N, H, W, C))
-        refined = self._refine(fused, ws=ws, name=tag + 'refined')
+        ws.release(att)
+        att = P['sAtt_2'](pooled, ws=ws, name=tag + 'att2', temp=True)
+        ws.release(pooled)
+        att3 = P['sAtt_3'](att, ws=ws, name=tag + 'att3', temp=True)
+        ws.release(att)
+        att_up = nhwc.resize(att3, ws.fmap(tag + 'attup', N, 2 * Hh, 2 * Wh, C, temp=True), 'bilinear')
+        ws.release(att3)
+        att = P['sAtt_4'](att_up, ws=ws, name=tag + 'att4', temp=True)
+        ws.release(att_up)
+        add1 = P['sAtt_add_1'](att, ws=ws, name=tag + 'add1', temp=True)
+        add = P['sAtt_add_2'](add1, ws=ws, name=tag + 'add2', temp=True)
+        ws.release(add1)
+        fused = nhwc.tcea_modulate(fea, att, add, T('fused', C))
+        ws.release(fea, att, add)
+        refined = self._refine(fused, ws=ws, name=tag + 'refined', temp=True)
         outs = [nhwc.bfp_scatter(refined, lv, ws.fmap('%sout%d' % (tag, i), lv.N, lv.H, lv.W, C))
                 for i, lv in enumerate(levels)]
+        ws.release(flow_fine, warp2, fused, refined)
         return outs, dict(flow_fine=flow_fine, warp=warp2, fused=fused, refined=refined)
 
     def forward(self, inputs, ref_inputs, flow_init, next_inputs=None, next_flow_init=None):
@@ -168,6 +189,7 @@ class BFPTcea(HipModule):
         assert next_inputs is None
         dev = inputs[0].device
         ws = nhwc.Workspace(dev)
+        ws.pooling = False
         lv = [nhwc.from_nchw(t) for t in inputs]
         cat = self.gather(lv, ws, 'cat')
         refcat = self.gather([nhwc.from_nchw(t) for t in ref_inputs], ws, 'refcat')

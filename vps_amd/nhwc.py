@@ -131,18 +131,77 @@ class FMap:
         return out
 
 
-class Workspace:
-    """Named persistent device buffers (one per activation of the frame graph), reused across frames: the allocator is never on
-    the critical path and pad lanes stay zero. Reuse is safe under the detector's stream discipline, which is an INVARIANT of
-    every caller (vps_amd/detector.py): a frame runs on two streams (in clip mode the next frame's image-only stages run on
-    a third stream, in a ring of three workspaces of their own); branches that run concurrently use DISJOINT buffer names, a stream is joined (wait_stream /
-    wait_event) before the other reads what it wrote and before the next frame rewrites it, and buffers are never freed, so no
-    allocation made on one stream is recycled under another. tests/test_fullsize_gpu.py compares the two-stream schedule with
-    the one-stream schedule bitwise; tests/test_fusetrack_gpu.py does the same for the pipelined schedule."""
+POOLING = os.environ.get('VPS_WS_POOL', '1') != '0'     # 0: every activation keeps a buffer of its own (the pre-round-5 workspace; A/B and debugging)
+
+
+class Pool:
+    """Free lists of fp32 blocks, one list PER STREAM: a block given back after its last consumer was enqueued on stream s may be handed
+    to the next producer enqueued on s (stream order makes the reuse safe without any event); it is never handed to work on another
+    stream. Blocks are never returned to the allocator, and a frame repeats the same take / give sequence, so every activation
+    sees the same address frame after frame (the cached conv descriptors stay valid)."""
+
+    SLACK = 1.5        # a free block serves requests down to 1/SLACK of its size (best fit); smaller requests get a block of their own
 
     def __init__(self, device):
         self.device = torch.device(device)
+        self.free = {}                # stream key -> list of flat fp32 tensors
+        self.total = 0                # bytes ever allocated
+        self.blocks = 0
+
+    def take(self, key, numel):
+        lst = self.free.setdefault(key, [])
+        best = -1
+        for i, blk in enumerate(lst):
+            n = blk.numel()
+            if n >= numel and n <= self.SLACK * numel and (best < 0 or n < lst[best].numel()):
+                best = i
+        if best >= 0:
+            return lst.pop(best)
+        self.total += 4 * numel
+        self.blocks += 1
+        return torch.empty(numel, dtype=torch.float32, device=self.device)
+
+    def give(self, key, blk):
+        self.free.setdefault(key, []).append(blk)
+
+
+def _stream_key():
+    return getattr(hip.stream_ptr(), 'value', None) or 0
+
+
+class Workspace:
+    """Device buffers of the frame graph, by name. Two kinds:
+
+    * PERSISTENT (`get`, `fmap`): one buffer per name, reused every frame - what crosses a stream or a frame boundary (the outputs of
+      the image-only stages, the neck outputs, fcn_score, the cached reference feature), every buffer with zero pad channels
+      (`ld > C`: pads are zeroed once and never written) and all small index / scratch buffers;
+    * TEMPORARY (`fmap(..., temp=True)`, `release`, `scope`): pad-free fp32 activations that are produced and consumed on ONE stream.
+      They come from the `Pool` of the stream that is current when they are taken and go back to it when they are released - from
+      then on the block may serve the next producer ON THAT STREAM (liveness-based reuse: round 5; 35.7 -> ~9 GB at 1024x2048).
+
+    INVARIANTS of every caller (vps_amd/detector.py and the modules): a temporary buffer is written and read only by work enqueued on
+    the stream it was taken on, between its `fmap` and its `release`; whatever another stream or the next frame reads is persistent;
+    branches that run concurrently use disjoint persistent names, a stream is joined (wait_stream / wait_event) before another reads
+    what it wrote and before the next frame rewrites it. `out`: a second workspace that receives the buffers a module marks
+    `out=True` - the ring slot of a prefetched frame (its flow / FPN levels / gathered feature live until the frame after next) while
+    the internals of the image-only stages are shared by all slots (the prefetch streams run them one frame after the other).
+    tests: the pooled schedule is bitwise the unpooled one (tests/test_fusetrack_gpu.py, tests/test_fullsize_gpu.py)."""
+
+    def __init__(self, device, pool=None, out=None):
+        self.device = torch.device(device)
         self.bufs = {}
+        self.pool = pool if pool is not None else Pool(device)
+        self.out = out
+        self.pooling = POOLING
+        self._live = {}              # id(view tensor) -> (block, stream key, name)
+        self._scopes = []
+
+    def with_out(self, out):
+        """a view of this workspace whose `out=True` buffers go to `out` (persistent names, temporaries and pool are shared)"""
+        v = Workspace.__new__(Workspace)
+        v.__dict__ = dict(self.__dict__)
+        v.out = out
+        return v
 
     def get(self, name, shape, dtype=torch.float32, zero=True):
         key = name
@@ -153,12 +212,55 @@ class Workspace:
             self.bufs[key] = t
         return t
 
-    def fmap(self, name, N, H, W, C, ld=None):
+    def fmap(self, name, N, H, W, C, ld=None, temp=False, out=False):
+        if out and self.out is not None:
+            return self.out.fmap(name, N, H, W, C, ld)
         ld = _ceil(C, 4) if ld is None else ld
+        if temp and self.pooling and ld == C:
+            numel = int(N) * int(H) * int(W) * int(ld)
+            key = _stream_key()
+            blk = self.pool.take(key, numel)
+            t = blk[:numel].view(int(N), int(H), int(W), int(ld))
+            self._live[id(t)] = (blk, key, name, t)
+            if self._scopes:
+                self._scopes[-1].append(id(t))
+            return FMap(t, C, 0)
         return FMap(self.get(name, (N, H, W, ld)), C, 0)
+
+    def release(self, *maps):
+        """the last consumer of these temporary maps has been enqueued (on the stream they were taken on): their blocks may be reused.
+        Persistent maps (and None) are ignored, a map is released once."""
+        for m in maps:
+            if m is None:
+                continue
+            ent = self._live.pop(id(m.t if isinstance(m, FMap) else m), None)
+            if ent is not None:
+                self.pool.give(ent[1], ent[0])
+
+    def scope(self):
+        """with ws.scope(): ...  - every temporary map taken inside and not released by then goes back at the end of the block"""
+        return _Scope(self)
 
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+
+class _Scope:
+    def __init__(self, ws):
+        self.ws = ws
+
+    def __enter__(self):
+        self.ids = []
+        self.ws._scopes.append(self.ids)
+        return self.ws
+
+    def __exit__(self, *exc):
+        self.ws._scopes.pop()
+        for i in self.ids:
+            ent = self.ws._live.pop(i, None)
+            if ent is not None:
+                self.ws.pool.give(ent[1], ent[0])
+        return False
 
 
 def from_nchw(x, ws=None, name=None, Cpad=None):
@@ -385,18 +487,19 @@ class PackedConv:
         p = self.pad_y[0]
         return (H + 2 * p - self.KH) // self.stride + 1, (W + 2 * p - self.KW) // self.stride + 1
 
-    def __call__(self, x, out=None, ws=None, name=None, res=None, res_shift=0, offset=None, act=None, gn=None):
-        """x: FMap. out: FMap window to write (allocated from `ws` under `name` if None).
+    def __call__(self, x, out=None, ws=None, name=None, res=None, res_shift=0, offset=None, act=None, gn=None, temp=False, keep=False):
+        """x: FMap. out: FMap window to write (allocated from `ws` under `name` if None; temp: as a temporary map the caller releases,
+        keep: in the workspace's `out` target - see Workspace).
         gn = (stats, G): float64 tensor [GN_REP, 2*G] of zeros that receives the GroupNorm sums of the output from the epilogue
         (vps_conv_desc.gn_stats; deformable layers of the split-operand modes). `self.gn_fused` tells whether the launch took
         them (it does not when the layer is split over K) - the caller then runs the statistics pass itself."""
         if getattr(self, '_mfma_twin', None) is not None and x.N * x.H * x.W >= 100000:
-            return self._mfma_twin(x, out, ws, name, res, res_shift, offset, act, gn)
+            return self._mfma_twin(x, out, ws, name, res, res_shift, offset, act, gn, temp, keep)
         assert x.C == self.cin or (x.C >= self.cin and x.C <= self.cin_pad), (x.C, self.cin)
         assert x.coff % 4 == 0 and x.ld % 4 == 0 and x.coff + self.cin_pad <= x.ld, (x.coff, x.ld, self.cin_pad)
         Ho, Wo = self.out_hw(x.H, x.W)
         if out is None:
-            out = ws.fmap(name, x.N, Ho, Wo, self.cout)
+            out = ws.fmap(name, x.N, Ho, Wo, self.cout, temp=temp, out=keep)
         assert (out.N, out.H, out.W) == (x.N, Ho, Wo) and out.C == self.cout, ((out.N, out.H, out.W, out.C), (x.N, Ho, Wo, self.cout))
         # The workspace is persistent, so a layer sees the same operand addresses every frame: the filled descriptor (and the
         # split-K scratch it points to) is cached per operand set; a hit costs one dict lookup + the launch instead of ~50

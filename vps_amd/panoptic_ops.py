@@ -16,7 +16,11 @@ import os
 
 from . import hip
 
-MASK_REMOVAL_SINGLE_LAUNCH = os.environ.get('VPS_MASK_REMOVAL', '') == 'single'
+# MaskRemoval's box walk on the device: 'dep' (default, round 5) = ONE launch, one workgroup per box waiting for the boxes it depends
+# on (vps_mask_removal_dep); 'level' = the round-3 schedule, one count + one commit launch per dependency level (~20 levels per frame);
+# 'single' = one workgroup per class walking its boxes in order (slowest; kept as the simplest statement of the loop)
+MASK_REMOVAL_MODE = os.environ.get('VPS_MASK_REMOVAL', 'dep')
+MASK_REMOVAL_SINGLE_LAUNCH = MASK_REMOVAL_MODE == 'single'
 
 
 class MaskROI(nn.Module):
@@ -137,9 +141,17 @@ class MaskRemoval(nn.Module):
         host = np.concatenate([sb.reshape(-1), sc, sorted_inds, order]).astype(np.int32)
         meta = torch.from_numpy(host).to(dev, non_blocking=True)
         counts = ws.get('mr.counts', (max(n, 1), 2), dtype=torch.int32, zero=False)
-        occ.zero_(); counts.zero_()
+        if not (MASK_REMOVAL_MODE == 'dep' and W % 4 == 0):
+            occ.zero_(); counts.zero_()             # (the one-launch entries zero what they use themselves)
         base = meta.data_ptr()
-        if MASK_REMOVAL_SINGLE_LAUNCH:
+        if MASK_REMOVAL_MODE == 'dep' and W % 4 == 0 and n <= MaskROI.KCAP:
+            done = ws.get('mr.done', (MaskROI.KCAP,), dtype=torch.int32, zero=False)
+            # status word = kinfo[2] (read with the frame's end-of-frame read; bit 2: a dependency wait expired)
+            hip.check(lib.vps_mask_removal_dep(hip.ptr(mp), S, ctypes.c_void_p(base), ctypes.c_void_p(base + 16 * n), ctypes.c_void_p(base + 20 * n),
+                                               n, ncls, H, W, hip.ptr(occ), float(self.fraction_threshold), hip.ptr(flags), hip.ptr(done),
+                                               ctypes.c_void_p(kinfo.data_ptr() + 8), sp), 'vps_mask_removal_dep')
+            nlv = 0
+        elif MASK_REMOVAL_SINGLE_LAUNCH:
             # A/B switch: the whole walk in ONE launch, one workgroup per class walking its boxes in order (csrc/pan_ops.hip)
             hip.check(lib.vps_mask_removal(hip.ptr(mp), S, ctypes.c_void_p(base), ctypes.c_void_p(base + 16 * n), ctypes.c_void_p(base + 20 * n),
                                            n, ncls, H, W, hip.ptr(occ), float(self.fraction_threshold), hip.ptr(flags), sp), 'vps_mask_removal')

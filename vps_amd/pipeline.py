@@ -156,6 +156,7 @@ class ClipFeeder:
         self._pool = ThreadPoolExecutor(self.workers)
         self._pending = {}          # t -> (future, staging slot)
         self._ready = {}            # t -> prepared device tensor [1,3,Hp,Wp]
+        self._meta = {}             # t -> shapes of the prepared frame (img_meta entries)
         self._done = set()          # frames delivered so far: the window does not decode them a second time (consumers keep what they got)
         self._next = 0              # first index not yet submitted
         self._hi = len(self.files)  # the window never runs past this frame (`set_range`: the end of a rank's shard)
@@ -235,8 +236,9 @@ class ClipFeeder:
         return self
 
     def meta(self, t):
-        """img_meta entries of frame t that depend on the file (`Collect` keys of configs/cityscapes/fusetrack.py:190)"""
-        return dict(filename=self.files[t])
+        """img_meta entries of frame t that depend on the file (`Collect` meta keys, datasets/pipelines/formating.py:185-186:
+        filename, ori_shape, img_shape, pad_shape, scale_factor, flip); the shapes are known once the frame has been delivered"""
+        return dict(self._meta.get(t, {}), filename=self.files[t])
 
     def _rewind(self, t):
         """a request BEHIND the window (ClipShardRunner asks for the hand-off frame e-1 first, then works through s .. e-1): the window
@@ -283,7 +285,9 @@ class ClipFeeder:
             self._events[slot] = ev
         else:
             d = src.numpy().copy()                 # host stand-in (tests): own copy, the slot goes back to the ring
-        out = self.prep.prep(d)[0].unsqueeze(0)
+        out, img_shape, pad_shape, sf = self.prep.prep(d)
+        out = out.unsqueeze(0)
+        self._meta[t] = dict(img_shape=tuple(img_shape), pad_shape=tuple(pad_shape), scale_factor=sf, ori_shape=(H, W, 3), flip=False)
         self.stats['upload_prep_s'] += time.perf_counter() - c1
         self._free.append(slot)                    # to the BACK of the ring: it is reused after every other free slot
         self._done.add(t)
