@@ -240,6 +240,9 @@ int vps_tcea_temporal(const float* emb, int emb_ld, const float* emb_ref, int re
 /* out = fea * sigmoid(att) * 2 + att_add. ref: tcea_modules.py:74-77 */
 int vps_tcea_modulate(const float* fea, const float* att, const float* att_add, float* out,
                       int64_t n, void* stream);
+/* the same on channel windows: pointers at the first channel of each window, leading dimensions in floats, C channels (4 | C, ld) */
+int vps_tcea_modulate_ld(const float* fea, int fea_ld, const float* att, int att_ld, const float* att_add, int add_ld,
+                         float* out, int out_ld, int64_t npix, int C, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Detection ops

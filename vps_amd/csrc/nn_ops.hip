@@ -355,6 +355,28 @@ void tcea_modulate_kernel(const float* __restrict__ fea, const float* __restrict
     }
 }
 
+// the same on channel WINDOWS (leading dimensions, 4 | C): the fused feature lives in one half of the merged fea_fusion | sAtt_1 output
+__global__ __launch_bounds__(256)
+void tcea_modulate_ld_kernel(const float* __restrict__ fea, int fea_ld, const float* __restrict__ att, int att_ld,
+                             const float* __restrict__ att_add, int add_ld, float* __restrict__ out, int out_ld, long npix, int C) {
+    const int c4n = C >> 2;
+    const long total = npix * c4n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / c4n;
+        const int c = (int)(i - pix * c4n) * 4;
+        const f32x4 f = *reinterpret_cast<const f32x4*>(fea + (size_t)pix * fea_ld + c);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(att + (size_t)pix * att_ld + c);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(att_add + (size_t)pix * add_ld + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float s = 1.f / (1.f + expf(-a[e]));
+            o[e] = f[e] * s * 2.f + d[e];
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)pix * out_ld + c) = o;
+    }
+}
+
 }  // namespace
 
 extern "C" int vps_resize(const float* in, int in_ld, int in_coff, int Hi, int Wi, float* out, int out_ld, int out_coff,
@@ -466,6 +488,15 @@ extern "C" int vps_tcea_temporal(const float* emb, int emb_ld, const float* emb_
     long g = (npix + 3) / 4; if (g > 16384) g = 16384;
     hipLaunchKernelGGL(tcea_temporal_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, emb, emb_ld, emb_ref, ref_ld,
                        fea0, f0_ld, fea1, f1_ld, out, out_ld, (long)npix, C);
+    return vps_launch_status();
+}
+
+extern "C" int vps_tcea_modulate_ld(const float* fea, int fea_ld, const float* att, int att_ld, const float* att_add, int add_ld,
+                                    float* out, int out_ld, int64_t npix, int C, void* stream) {
+    if (!fea || !att || !att_add || !out || npix <= 0 || C <= 0) return VPS_EARG(1);
+    if ((C | fea_ld | att_ld | add_ld | out_ld) & 3 || (((uintptr_t)fea | (uintptr_t)att | (uintptr_t)att_add | (uintptr_t)out) & 15)) return VPS_EARG(2);
+    hipLaunchKernelGGL(tcea_modulate_ld_kernel, dim3(stream_grid((long)npix * (C >> 2), 256)), dim3(256), 0, (hipStream_t)stream, fea, fea_ld,
+                       att, att_ld, att_add, add_ld, out, out_ld, (long)npix, C);
     return vps_launch_status();
 }
 

@@ -253,20 +253,36 @@ void mask_removal_dep_kernel(const float* __restrict__ logits, int S, const int*
     const long nwords = rh > 0 ? (long)nwx * rh : 0;
     unsigned* __restrict__ plane = occ_words + ((size_t)cls * H * W >> 2);
     int ms = 0, ov = 0;
-    for (long wd = t; wd < nwords; wd += MR_THREADS) {
-        const int ky = (int)(wd / nwx), xb = xw0 + 4 * (int)(wd - (long)ky * nwx);
-        const int yy = g.y0 + ky;
-        unsigned posm = 0;
+    // four words per thread and step: the four occupancy loads (agent scope: they miss the L2, ~2 us each) are requested together,
+    // unconditionally (a word without a positive pixel is masked out afterwards) - one load per step made a 200 x 200 box a chain
+    // of ten memory round trips per pass
+    for (long wd0 = t; wd0 < nwords; wd0 += 4 * MR_THREADS) {
+        unsigned posm[4], o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int xx = xb + e;
-            if (xx >= g.x0 && xx < g.x1 && logit_at(xx - g.x0, ky) > 0.f) posm |= 0xFFu << (8 * e);
+        for (int u = 0; u < 4; ++u) {
+            const long wd = wd0 + (long)u * MR_THREADS;
+            posm[u] = 0; o[u] = 0;
+            if (wd < nwords) {
+                const int ky = (int)(wd / nwx), xb = xw0 + 4 * (int)(wd - (long)ky * nwx);
+                o[u] = __hip_atomic_load(&plane[((size_t)(g.y0 + ky) * W + xb) >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-        if (posm) {
-            ms += __popc(posm) >> 3;
-            const unsigned o = __hip_atomic_load(&plane[((size_t)yy * W + xb) >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // bytes of `o` are 0 or 1: occupied positive pixels
-            ov += __popc(o & posm & 0x01010101u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long wd = wd0 + (long)u * MR_THREADS;
+            if (wd < nwords) {
+                const int ky = (int)(wd / nwx), xb = xw0 + 4 * (int)(wd - (long)ky * nwx);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int xx = xb + e;
+                    if (xx >= g.x0 && xx < g.x1 && logit_at(xx - g.x0, ky) > 0.f) posm[u] |= 0xFFu << (8 * e);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ms += __popc(posm[u]) >> 3;
+            ov += __popc(o[u] & posm[u] & 0x01010101u);          // bytes of the occupancy word are 0 or 1
         }
     }
     for (int off = 32; off >= 1; off >>= 1) { ms += __shfl_xor(ms, off, 64); ov += __shfl_xor(ov, off, 64); }

@@ -110,7 +110,10 @@ class BFPTcea(HipModule):
                      P(fe[2][0], act=L, device=device), P(fe[3], device=device)]
         t = self.tcea_fusion
         self._t = dict(tAtt_1=P(t.tAtt_1, device=device), tAtt_2=P(t.tAtt_2, device=device),
-                       fea_fusion=P(t.fea_fusion, act=L, device=device), sAtt_1=P(t.sAtt_1, act=L, device=device),
+                       # fea_fusion and sAtt_1 are both 1x1 convolutions + LeakyReLU of the SAME 512-channel input: ONE launch with the two
+                       # weight blocks stacked (the 268 MB input is read once; per output channel the arithmetic is unchanged)
+                       fea_att1=nhwc.PackedConv(torch.cat([t.fea_fusion.weight, t.sAtt_1.weight], 0), torch.cat([t.fea_fusion.bias, t.sAtt_1.bias], 0),
+                                                None, 1, 0, act=L, device=device),
                        sAtt_2=P(t.sAtt_2, act=L, device=device), sAtt_3=P(t.sAtt_3, act=L, device=device),
                        sAtt_4=P(t.sAtt_4, device=device), sAtt_add_1=P(t.sAtt_add_1, act=L, device=device),
                        sAtt_add_2=P(t.sAtt_add_2, device=device))
@@ -157,14 +160,13 @@ class BFPTcea(HipModule):
         emb_ref = P['tAtt_2'](bsf, ws=ws, name=tag + 'emb_ref', temp=True)
         al = nhwc.tcea_temporal(emb, emb_ref, bsf, warp2, T('aligned', 2 * C))
         ws.release(emb, emb_ref)
-        fea = P['fea_fusion'](al, ws=ws, name=tag + 'fea', temp=True)
-        att = P['sAtt_1'](al, ws=ws, name=tag + 'att1', temp=True)
+        fa = P['fea_att1'](al, ws=ws, name=tag + 'fea_att1', temp=True)
+        fea, att = fa.window(0, C), fa.window(C, C)
         ws.release(al)
         Hh, Wh = (H + 1) // 2, (W + 1) // 2
         pooled = ws.fmap(tag + 'attpool', N, Hh, Wh, 2 * C, temp=True)
         nhwc.pool3x3s2(att, pooled.window(0, C), 'max')
         nhwc.pool3x3s2(att, pooled.window(C, C), 'avg')
-        ws.release(att)
         att = P['sAtt_2'](pooled, ws=ws, name=tag + 'att2', temp=True)
         ws.release(pooled)
         att3 = P['sAtt_3'](att, ws=ws, name=tag + 'att3', temp=True)
@@ -177,7 +179,7 @@ class BFPTcea(HipModule):
         add = P['sAtt_add_2'](add1, ws=ws, name=tag + 'add2', temp=True)
         ws.release(add1)
         fused = nhwc.tcea_modulate(fea, att, add, T('fused', C))
-        ws.release(fea, att, add)
+        ws.release(fa, att, add)
         refined = self._refine(fused, ws=ws, name=tag + 'refined', temp=True)
         outs = [nhwc.bfp_scatter(refined, lv, ws.fmap('%sout%d' % (tag, i), lv.N, lv.H, lv.W, C))
                 for i, lv in enumerate(levels)]

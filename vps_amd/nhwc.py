@@ -80,7 +80,11 @@ CONV_TRACE = None
 # split do it (vps_conv_desc.tile_counter): measured 31.2 instead of 42.2 frames/s (profiles/r03_bench_splitk_last_block_ab.json) -
 # the device-scope release / acquire around the ticket (buffer_wbl2 / buffer_inv: the partials of a tile come from blocks on
 # different XCDs, each with its own L2) writes back and invalidates a whole L2 per block. Kept as an option, OFF.
-SPLITK_TARGET_BLOCKS = int(os.environ.get('VPS_SPLITK_TARGET', '512'))     # blocks a split launch aims at (two per CU)
+# blocks a split launch aims at. 512 (two per CU) until round 4, when a frame had at most two kernels in flight; with the image-only
+# stages on three streams of their own the other streams fill the CUs a low-resolution layer leaves idle, and fewer, longer splits
+# win (less partial-sum traffic, smaller reduce launches): 1024 / 512 / 256 / 128 -> 49.9 / 51.1 / 51.5 / 51.8 frames/s, conv time of
+# the one-stream instrumented frame 20.5 / 20.0 / 19.9 / 21.0 ms (gpurun_out c5, round 5) -> 256
+SPLITK_TARGET_BLOCKS = int(os.environ.get('VPS_SPLITK_TARGET', '256'))
 SPLITK_LAST_BLOCK = os.environ.get('VPS_SPLITK_LAST_BLOCK', '0') == '1'
 # 1: the 3x3 narrow-output layers with >= 64 input channels on large maps run on the MFMA tile kernel (a second packed copy). It won
 # against the first vector kernel (predict_flow2 0.133 -> 0.080 ms); the round-3 vector kernel does 0.059 ms in exact fp32: default off.
@@ -736,8 +740,13 @@ def tcea_temporal(emb, emb_ref, fea0, fea1, out):
 
 
 def tcea_modulate(fea, att, att_add, out):
-    for m in (fea, att, att_add, out):
-        assert m.coff == 0 and m.C == m.ld
-    hip.check(hip.load().vps_tcea_modulate(fea.ptr(), att.ptr(), att_add.ptr(), out.ptr(), out.t.numel(), hip.stream_ptr()),
-              'vps_tcea_modulate')
+    if all(m.coff == 0 and m.C == m.ld for m in (fea, att, att_add, out)):
+        hip.check(hip.load().vps_tcea_modulate(fea.ptr(), att.ptr(), att_add.ptr(), out.ptr(), out.t.numel(), hip.stream_ptr()),
+                  'vps_tcea_modulate')
+        return out
+    # channel windows (the fused feature is one half of the merged fea_fusion | sAtt_1 output)
+    w = lambda m: c_void_p(m.t.data_ptr() + 4 * m.coff)
+    assert fea.C == att.C == att_add.C == out.C and all(m.coff % 4 == 0 for m in (fea, att, att_add, out))
+    hip.check(hip.load().vps_tcea_modulate_ld(w(fea), fea.ld, w(att), att.ld, w(att_add), att_add.ld, w(out), out.ld, out.npix, out.C,
+                                              hip.stream_ptr()), 'vps_tcea_modulate_ld')
     return out
