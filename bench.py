@@ -552,7 +552,7 @@ def main():
                     conv_ms_per_frame=round(ms, 3), avg_launch_us=round(1e3 * ms / max(nl, 1), 2))
         # HBM traffic of the conv kernels per frame: separate rocprofv3 --pmc passes (tools/pmc_traffic.py), not collectable from
         # inside this process; the newest committed measurement for this arithmetic mode is attached
-        for rnd in ('r04', 'r03', 'r02', 'r01'):
+        for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
             pmc = os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s.json' % (rnd, args.prec))
             if os.path.exists(pmc):
                 pj = json.load(open(pmc))
@@ -621,7 +621,7 @@ def main():
         if scaling_model is not None:
             scaling_model['measured'] = False
             line['extra'] = {'scaling_model': scaling_model}       # a critical-path MODEL (assumed link rate), kept out of the headline fields
-        line['config']['host_reads_per_frame'] = '2 (the detection list after MaskROI: 8 KB; kept list + track ids + range report at the end: 2 KB)'
+        line['config']['host_reads_per_frame'] = '2 (the detection list after MaskROI: 8 KB; kept list + track ids + range report + status words at the end: 2 KB)'
         line['f16_fallbacks'] = int(nhwc.F16_FALLBACKS[0])        # layers switched from f16x3 to bf16x6 by the fp16 range report (0 here)
         if clip30 is not None:
             line['clip30'] = clip30
