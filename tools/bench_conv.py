@@ -22,6 +22,7 @@ SHAPES = [  # name, cin, cout, k, stride, pad, H, W, transposed, deform
     ('fusion conv0 11->64 3x3 @1024x2048', 11, 64, 3, 1, 1, 1024, 2048, False, False),
     ('flownetS conv1 12->64 7x7s2 @1024x2048', 12, 64, 7, 2, 3, 1024, 2048, False, False),
     ('flownet conv2 64->128 5x5s2 @512x1024', 64, 128, 5, 2, 2, 512, 1024, False, False),
+    ('fusion conv1_1 64->128 3x3 @512x1024', 64, 128, 3, 1, 1, 512, 1024, False, False),
     ('flownet conv3 128->256 5x5s2 @256x512', 128, 256, 5, 2, 2, 256, 512, False, False),
     ('flownet conv3_1 256->256 3x3 @128x256', 256, 256, 3, 1, 1, 128, 256, False, False),
     ('flownet conv4_1 512->512 3x3 @64x128', 512, 512, 3, 1, 1, 64, 128, False, False),
