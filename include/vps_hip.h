@@ -152,6 +152,13 @@ int vps_correlation(const float* in1, int ld1, int coff1, const float* in2, int 
                     float* out, int out_ld, int out_coff,
                     int N, int H, int W, int C, int max_disp, int stride2,
                     int act, float slope, void* stream);
+/* the same operator in SPLIT fp16 on the matrix cores (round 5; the two configurations of the path with C = 256: max_disp 20 / stride2 2
+ * and max_disp 4 / stride2 1; every other shape runs the exact kernels): operands as fp16 pairs with a scaled residual (22 significand
+ * bits), a*b ~ h0 k0 + 2^-11 (h0 k1 + h1 k0), fp32 accumulate - fp32-grade like VPS_PREC_F16X3 for 2^-14 <= |x| <= 65504. status: device
+ * word that receives bit 0 when an operand lies beyond the fp16 range: the caller then repeats the call with vps_correlation. */
+int vps_correlation_f16(const float* in1, int ld1, int coff1, const float* in2, int ld2, int coff2,
+                        float* out, int out_ld, int out_coff, int N, int H, int W, int C,
+                        int max_disp, int stride2, int act, float slope, int32_t* status, void* stream);
 
 /* ref: flow_modules/flow_modules.py:126-148 (WarpingLayer): grid = linspace(-1,1) + flow/((W-1)/2),
  * F.grid_sample(bilinear, zeros padding, align_corners=False). NHWC in/out, flow NHWC [N,H,W,flow_ld] (ch0=x,1=y) */
@@ -385,6 +392,12 @@ int vps_maskroi_finish(const float* dets, const int32_t* cand, const int32_t* m_
 int vps_track_assign(const float* comp, int K, int M, const float* emb, int E, const float* box, int ldb, const int64_t* label,
                      float* prev_emb, float* prev_box, int64_t* prev_label, int32_t* scratch, int32_t* ids, int32_t* m_out,
                      void* stream);
+
+/* the end-of-frame record a host reads once per frame, gathered in one launch: tail int32 [8 + 2*kcap] =
+ * [kinfo[0..3] (k, masks valid, status, -), mem_count[0] or 0, max over f16_status[0..nslots) or 0, -, -, keep[0..K), ids[0..K) at 8 + kcap]
+ * (ids, mem_count, f16_status may be NULL / nslots 0) */
+int vps_frame_tail(const int32_t* kinfo, const int32_t* keep, const int32_t* ids, const int32_t* mem_count, const int32_t* f16_status,
+                   int nslots, int K, int kcap, int32_t* tail, void* stream);
 
 /* ref: models/utils/mask_removal.py:81-91 (kept list; nothing kept -> [0] with zero logits) + utils/unary_logits.py:96-106
  * (SegTerm crop of boxes*4*0.25). order [n] / flags [n] / tbox [n][4]: MaskRemoval's walk (vps_mask_level), rows [n][8]:

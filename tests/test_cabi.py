@@ -94,6 +94,8 @@ def test_kernel_resource_budget():
     assert len(res) > 100 and any('conv_mfma_h8_kernel' in n for n in res), len(res)
     for name, r in res.items():
         assert r['vgpr_spill'] == 0, (name, r)
-        assert r['lds_bytes'] <= 160 * 1024 and r['vgpr'] <= 256 and r['agpr'] == 0, (name, r)
+        # (the correlation kernel's two accumulator tiles live in AGPRs - the compiler's choice for accumulators no VALU instruction
+        # touches inside the loop; 164 + 32 registers, one wave per SIMD)
+        assert r['lds_bytes'] <= 160 * 1024 and r['vgpr'] <= 256 and (r['agpr'] == 0 or ('corr_mfma' in name and r['vgpr'] + r['agpr'] <= 256)), (name, r)
         if 'conv_mfma' in name:
             assert r['scratch_bytes'] == 0, (name, r)

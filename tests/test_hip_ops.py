@@ -683,3 +683,68 @@ def test_mask_removal_one_launch_equals_the_level_launches(dev, n, seed):
         assert np.array_equal(res['dep'][1], res[mode][1]) and res['dep'][2] == res[mode][2], mode
         assert np.array_equal(res['dep'][3], res[mode][3]), mode                   # the occupancy planes (as "occupied or not")
     assert 1 <= res['dep'][0] <= n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W,md,s2,act', [(128, 256, 20, 2, hip.ACT_LEAKY), (256, 512, 4, 1, hip.ACT_NONE), (6, 128, 20, 2, hip.ACT_NONE),
+                                           (5, 64, 4, 1, hip.ACT_LEAKY), (3, 192, 4, 1, hip.ACT_NONE)])
+def test_correlation_split_fp16_on_mfma_equals_the_exact_kernels(dev, H, W, md, s2, act):
+    """vps_correlation_f16 (csrc/corr_mfma.hip: banded Gram matrices on the matrix cores, fp16 pairs with a scaled residual, round 5)
+    against the exact fp32 kernels at the two BASELINE shapes (441 channels @128x256, 81 channels @256x512) and on ragged ones (first /
+    last rows and columns see out-of-image displacements; 3 segments per row; both column parities): fp32-grade - within 2e-6 of the
+    largest output, the tolerance the exact kernels themselves are held to against the reference's own kernel
+    (tests/test_ref_native_gpu.py)"""
+    C = 256
+    g = torch.Generator().manual_seed(H * 7 + W)
+    # feature-like operands: mixed magnitudes per channel, some large values, exact zeros (ReLU-like)
+    scale = torch.exp(torch.randn(C, generator=g) * 1.5)
+    a = (torch.randn(1, H, W, C, generator=g) * scale).clamp_min(-0.3 * scale.max())
+    b = (torch.randn(1, H, W, C, generator=g) * scale)
+    b[..., ::7] = 0
+    x1, x2 = nhwc.FMap(a.to(dev).contiguous()), nhwc.FMap(b.to(dev).contiguous())
+    D = 2 * (md // s2) + 1
+    ld = (D * D + 3) // 4 * 4 + 4
+    o_exact = nhwc.FMap(torch.zeros(1, H, W, ld, device=dev), D * D, 4)
+    o_f16 = nhwc.FMap(torch.full((1, H, W, ld), 7.0, device=dev), D * D, 4)
+    nhwc.correlation(x1, x2, o_exact, md, s2, act, 0.1)
+    st = nhwc.f16_status(dev); st.zero_()
+    old = nhwc.CORR_F16[0]
+    nhwc.CORR_F16[0] = True
+    try:
+        nhwc.correlation(x1, x2, o_f16, md, s2, act, 0.1, prec=hip.PREC_F16X3)
+    finally:
+        nhwc.CORR_F16[0] = old
+    torch.cuda.synchronize()
+    assert int(st[nhwc.F16_CORR_SLOT].item()) == 0
+    e, f = o_exact.t[..., 4:4 + D * D].cpu(), o_f16.t[..., 4:4 + D * D].cpu()
+    err = float((e - f).abs().max() / e.abs().max())
+    print('correlation f16-split vs exact %dx%d md %d s2 %d: max err %.2e of max |out| %.3g' % (H, W, md, s2, err, float(e.abs().max())))
+    assert err < 2e-6, err
+    assert torch.equal(o_f16.t[..., :4].cpu(), torch.full((1, H, W, 4), 7.0)) and torch.equal(o_f16.t[..., 4 + D * D:].cpu(), torch.full((1, H, W, ld - 4 - D * D), 7.0))
+    # out-of-image displacements are exact zeros like the exact kernels'
+    assert torch.equal(e == 0, f == 0) or float(((e == 0) != (f == 0)).float().mean()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_correlation_split_fp16_reports_the_fp16_range(dev):
+    """an operand beyond 65504 raises the correlations' status slot; nhwc.f16_fallback then switches them to the exact kernels for good"""
+    H, W, C = 4, 64, 256
+    a = torch.randn(1, H, W, C); b = torch.randn(1, H, W, C)
+    b[0, 2, 17, 5] = 1.0e5
+    x1, x2 = nhwc.FMap(a.to(dev)), nhwc.FMap(b.to(dev))
+    out = nhwc.FMap(torch.zeros(1, H, W, 84, device=dev), 81, 0)
+    st = nhwc.f16_status(dev); st.zero_()
+    old = nhwc.CORR_F16[0]
+    nhwc.CORR_F16[0] = True
+    try:
+        nhwc.correlation(x1, x2, out, 4, 1, prec=hip.PREC_F16X3)
+        torch.cuda.synchronize()
+        assert int(st[nhwc.F16_CORR_SLOT].item()) == 1
+        assert nhwc.f16_fallback(dev) == 1 and nhwc.CORR_F16[0] is False and int(st.amax().item()) == 0
+        ref = nhwc.FMap(torch.zeros(1, H, W, 84, device=dev), 81, 0)
+        nhwc.correlation(x1, x2, ref, 4, 1)
+        nhwc.correlation(x1, x2, out, 4, 1, prec=hip.PREC_F16X3)          # now the exact kernel
+        assert torch.equal(out.t, ref.t)
+    finally:
+        nhwc.CORR_F16[0] = old
+        nhwc.F16_FALLBACKS[0] = 0

@@ -77,6 +77,26 @@ class _RecordingLib:
         (ctypes.c_int32 * 1).from_address(m_out.value)[0] = max(M, K)
         return 0
 
+    def _vps_frame_tail(self, kinfo, keep, ids, mem_count, f16_status, nslots, K, kcap, tail, stream):
+        t = (ctypes.c_int32 * (8 + 2 * kcap)).from_address(tail.value)
+        ki = (ctypes.c_int32 * 4).from_address(kinfo.value)
+        for i in range(4):
+            t[i] = ki[i]
+        t[4] = (ctypes.c_int32 * 1).from_address(mem_count.value)[0] if mem_count is not None and mem_count.value else 0
+        t[5] = 0
+        kp = (ctypes.c_int32 * max(K, 1)).from_address(keep.value)
+        for i in range(K):
+            t[8 + i] = kp[i]
+            if ids is not None and ids.value:
+                t[8 + kcap + i] = (ctypes.c_int32 * 1).from_address(ids.value + 4 * i)[0]
+        return 0
+
+    def _vps_mask_removal_dep(self, *a):
+        flags, n = a[11], a[5]
+        for i in range(n):
+            (ctypes.c_int32 * 1).from_address(flags.value + 4 * i)[0] = 1
+        return 0
+
     def _vps_mask_level(self, *a):
         flags, nlevel, level = a[-2], a[6], a[5]
         lv = (ctypes.c_int32 * nlevel).from_address(level.value)

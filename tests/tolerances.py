@@ -8,7 +8,7 @@ fp32-grade arithmetic mode (f32, bf16x6, f16x3). Measured values: profiles/r0[34
   flow (FlowNet2, full res)   5e-5      1.5e-6 .. 7.1e-6         5 networks, 60 convolutions: plain summation-order noise
   FPN levels P2..P6           5e-5      1.0e-6 .. 2.9e-6         (same for ResNet-101)
   fusion-neck outputs         2e-3      2.1e-5 .. 4.5e-4         the TCEA fusion is ill-conditioned on the synthetic weights: the fp32 ORACLE
-                                                                 itself is 0.5 .. 1.3e-4 from its float64 evaluation at this stage
+                                                                 itself is 1.9e-4 (1024x2048) from its float64 evaluation at this stage
                                                                  (tools/neck_isolation.py, profiles/r05_neck_*), everything behind inherits it
   semantic logits fcn_score   2e-3      6.2e-5 .. 7.5e-4
   cls_score / bbox_pred       2e-3      5.0e-5 .. 9e-4

@@ -36,6 +36,7 @@ def main():
             for r in csv.DictReader(f):
                 rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
     rows.sort()
+    short = lambda n: n.split('(')[0].replace('void ', '').replace('(anonymous namespace)::', '')[:60]
     st = np.array([r[0] for r in rows], np.int64); en = np.array([r[1] for r in rows], np.int64)
     marks = np.array([r[1] for r in rows if args.marker in r[2]], np.int64)
     assert marks.size > 4, 'marker kernel %s not found' % args.marker
@@ -50,19 +51,22 @@ def main():
         s = np.clip(st[sel], a, b); e = np.clip(en[sel], a, b)
         order = np.argsort(s)
         s, e = s[order], e[order]
-        busy, gaps, cur = 0, [], a
-        for x, y in zip(s, e):
+        names = [rows[k][2] for k in np.nonzero(sel)[0][order]]
+        busy, gaps, cur, big, last = 0, [], a, [], 'frame start'
+        for x, y, nm in zip(s, e, names):
             if x > cur:
                 gaps.append(x - cur)
+                if x - cur >= 20e3:
+                    big.append((float(x - cur) / 1e3, round(float(cur - a) / 1e6, 3), short(last), short(nm)))
                 busy += y - x
-                cur = y
+                cur = y; last = nm
             elif y > cur:
                 busy += y - cur
-                cur = y
+                cur = y; last = nm
         if b > cur:
             gaps.append(b - cur)
         g = np.array(gaps, np.float64)
-        res.append(dict(period=(b - a) / 1e6, busy=busy / 1e6, work=float((e - s).sum()) / 1e6, launches=int(sel.sum()),
+        res.append(dict(big=sorted(big, reverse=True)[:8], period=(b - a) / 1e6, busy=busy / 1e6, work=float((e - s).sum()) / 1e6, launches=int(sel.sum()),
                         gaps=[[int(((g >= lo) & (g < hi)).sum()), float(g[(g >= lo) & (g < hi)].sum()) / 1e6] for lo, hi in classes]))
     m = lambda k: round(float(np.median([r[k] for r in res])), 3)
     out = dict(frames=len(res), period_ms=m('period'), busy_ms=m('busy'), idle_ms=round(m('period') - m('busy'), 3), work_ms=m('work'),
@@ -71,6 +75,10 @@ def main():
                note='median over the kept frame intervals; gaps: [count, total ms] per frame (median)')
     for j, k in enumerate(out['idle_gaps']):
         out['idle_gaps'][k] = [int(np.median([r['gaps'][j][0] for r in res])), round(float(np.median([r['gaps'][j][1] for r in res])), 3)]
+    # where the idle time sits: the largest gaps of the median-period frame, [us, ms after the frame start, kernel that ended before it,
+    # kernel that started after it]
+    mid = sorted(res, key=lambda r: r['period'])[len(res) // 2]
+    out['largest_gaps_of_a_median_frame'] = [[round(g[0], 1), g[1], g[2], g[3]] for g in mid['big']]
     line = json.dumps(out)
     print(line)
     if args.out:

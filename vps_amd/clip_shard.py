@@ -202,8 +202,14 @@ class ClipShardRunner:
                 ref_feature = recv_buf
             if getattr(be, 'supports_prefetch', False):
                 # the next frame of this shard is known: its image-only stages are enqueued behind this frame's (detector.simple_test)
-                rec = be.process(img, ref_img, ref_feature, video_id * 10000 + t + 1, is_first,
-                                 next_img=load_frame(t + 1) if t + 1 < e else None)
+                nxt = load_frame(t + 1) if t + 1 < e else None
+                if getattr(be, 'prefetch_depth', 1) >= 2:
+                    # the frame after next is announced too: the detector enqueues its image-only stages before it blocks on this frame's
+                    # end-of-frame read, so the GPU never runs out of queued work at a frame boundary
+                    rec = be.process(img, ref_img, ref_feature, video_id * 10000 + t + 1, is_first, next_img=nxt,
+                                     next2_img=load_frame(t + 2) if t + 2 < e else None)
+                else:
+                    rec = be.process(img, ref_img, ref_feature, video_id * 10000 + t + 1, is_first, next_img=nxt)
             else:
                 rec = be.process(img, ref_img, ref_feature, video_id * 10000 + t + 1, is_first)
             rec['t'] = t
@@ -259,6 +265,7 @@ class DetectorBackend:
     """adapts vps_amd.detector.PanopticFuseTrack to the ClipShardRunner protocol"""
 
     supports_prefetch = True
+    prefetch_depth = int(os.environ.get('VPS_PREFETCH_DEPTH', '2'))      # 2: the frame after next is announced as well (see ClipShardRunner.run)
     inline_ids = True
 
     def __init__(self, detector, H, W, prefetch=True):
@@ -296,10 +303,14 @@ class DetectorBackend:
         C = self.det.extra_neck.in_channels
         return torch.empty(1, self.H // 4, self.W // 4, C, dtype=torch.float32, device=img.device)
 
-    def process(self, img, ref_img, ref_feature, iid, is_first, next_img=None):
+    def process(self, img, ref_img, ref_feature, iid, is_first, next_img=None, next2_img=None):
         from . import synth
         meta = synth.img_meta(self.H, self.W, iid)
-        pf = (next_img, img) if (self.prefetch and next_img is not None) else None      # the next frame's reference is this frame
+        pf = None
+        if self.prefetch and next_img is not None:
+            pf = [(next_img, img)]                                # the next frame's reference is this frame
+            if next2_img is not None:
+                pf.append((next2_img, next_img))
         keep, self.det.verify_ref_frame = self.det.verify_ref_frame, False
         try:
             out = self.det.simple_test(img, [meta], ref_img=[ref_img], ref_feature=ref_feature, defer_tracking=not self.inline_ids, prefetch=pf)

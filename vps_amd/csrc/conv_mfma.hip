@@ -1966,9 +1966,10 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
     // 8-wave variant (256-row tiles, weights through LDS): 128-column layers in the modes whose two activation planes leave room
     // for the weight buffers, when the 8 x 32 patches waste little and there are enough tiles to give every CU one
     const long tiles2d8 = (long)d.N * ((d.Qh + 7) / 8) * ((d.Qw + 31) / 32);
-    // VPS_H8_MIN_CHUNKS=n (A/B): layers with fewer than n 32-channel chunks stay on the 4-wave halo kernel (two blocks per CU: one
+    // VPS_H8_MIN_CHUNKS=n: layers with fewer than n 32-channel chunks stay on the 4-wave halo kernel (two blocks per CU: one
     // block's store drain overlaps the other's k loop; the 8-wave kernel holds a CU alone and its short-K tiles are mostly drain)
-    static const int h8_min_chunks = getenv("VPS_H8_MIN_CHUNKS") ? atoi(getenv("VPS_H8_MIN_CHUNKS")) : 0;
+    // round 5, measured: `64->128 3x3 @512x1024` 0.303 -> 0.264 ms on the 4-wave kernel, layers with >= 4 chunks unchanged -> 3
+    static const int h8_min_chunks = getenv("VPS_H8_MIN_CHUNKS") ? atoi(getenv("VPS_H8_MIN_CHUNKS")) : 3;
     const bool h8 = halo && BN == 128 && (d.prec == VPS_PREC_F16X3 || d.prec == VPS_PREC_BF16X3 || d.prec == VPS_PREC_BF16) &&
                     tiles2d8 * 256 * 2 <= (long)M * 3 && tiles2d8 * tiles_n * d.nclass * d.ksplit >= 256 && ksteps / ntap >= h8_min_chunks;
     // stride-2 3x3 / 5x5 layers on the phase-split 8-wave halo kernel (VPS_S2_HALO=0 in the environment switches it off: A/B runs)

@@ -700,6 +700,24 @@ extern "C" int vps_channelnorm(vps_tensor4 in, vps_tensor4 out, int B, int C, in
     return vps_launch_status();
 }
 
+int vpsi_launch_corr_mfma(const float* in1, int ld1, int coff1, const float* in2, int ld2, int coff2, float* out, int out_ld, int out_coff,
+                          int N, int H, int W, int C, int max_disp, int stride2, int act, float slope, int32_t* status, hipStream_t s);
+
+// the same operator in split fp16 on the matrix cores where an instance exists (corr_mfma.hip: the two configurations of the path),
+// else the exact kernels below. status: device word that receives bit 0 when an operand lies beyond the fp16 range (|x| > 65504) -
+// the result is then not fp32-grade and the caller repeats the call with vps_correlation.
+extern "C" int vps_correlation_f16(const float* in1, int ld1, int coff1, const float* in2, int ld2, int coff2,
+                                   float* out, int out_ld, int out_coff, int N, int H, int W, int C,
+                                   int max_disp, int stride2, int act, float slope, int32_t* status, void* stream) {
+    if (!in1 || !in2 || !out || !status || N <= 0 || H <= 0 || W <= 0) return VPS_EARG(1);
+    if (C <= 0 || (C & 3) || C > 1024 || (ld1 & 3) || (ld2 & 3) || (coff1 & 3) || (coff2 & 3)) return VPS_EARG(2);
+    if (stride2 <= 0 || max_disp < 0) return VPS_EARG(3);
+    if (vpsi_launch_corr_mfma(in1, ld1, coff1, in2, ld2, coff2, out, out_ld, out_coff, N, H, W, C, max_disp, stride2, act, slope, status,
+                              (hipStream_t)stream))
+        return vps_launch_status();
+    return vps_correlation(in1, ld1, coff1, in2, ld2, coff2, out, out_ld, out_coff, N, H, W, C, max_disp, stride2, act, slope, stream);
+}
+
 extern "C" int vps_correlation(const float* in1, int ld1, int coff1, const float* in2, int ld2, int coff2,
                                float* out, int out_ld, int out_coff, int N, int H, int W, int C,
                                int max_disp, int stride2, int act, float slope, void* stream) {

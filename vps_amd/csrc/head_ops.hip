@@ -557,7 +557,40 @@ void pan_instances_kernel(const int* __restrict__ order, const int* __restrict__
     k_out[0] = k;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The frame's end-of-frame record in ONE launch (round 5; was six tiny copy / reduce launches behind the combine kernel, on an
+// otherwise idle GPU): tail = [k, masks_valid, status, -, mem_count, f16 range report, -, -, keep[kcap], ids[kcap]] (int32).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void frame_tail_kernel(const int* __restrict__ kinfo, const int* __restrict__ keep, const int* __restrict__ ids, const int* __restrict__ mem_count,
+                       const int* __restrict__ f16_status, int nslots, int K, int kcap, int* __restrict__ tail) {
+    __shared__ int red[256];
+    int m = 0;
+    for (int i = threadIdx.x; i < nslots; i += 256) m = max(m, f16_status[i]);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) tail[threadIdx.x] = kinfo[threadIdx.x];
+    if (threadIdx.x == 4) tail[4] = mem_count ? mem_count[0] : 0;
+    if (threadIdx.x == 5) tail[5] = f16_status ? red[0] : 0;
+    for (int i = threadIdx.x; i < K; i += 256) {
+        tail[8 + i] = keep[i];
+        if (ids) tail[8 + kcap + i] = ids[i];
+    }
+}
+
 }  // namespace
+
+extern "C" int vps_frame_tail(const int32_t* kinfo, const int32_t* keep, const int32_t* ids, const int32_t* mem_count, const int32_t* f16_status,
+                              int nslots, int K, int kcap, int32_t* tail, void* stream) {
+    if (!kinfo || !keep || !tail || K < 0 || K > kcap || nslots < 0 || (nslots > 0 && !f16_status)) return VPS_EARG(1);
+    hipLaunchKernelGGL(frame_tail_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, kinfo, keep, ids, mem_count, nslots > 0 ? f16_status : nullptr,
+                       nslots, K, kcap, tail);
+    return vps_launch_status();
+}
 
 extern "C" int vps_rpn_collect(const float* boxes, const int32_t* keep, const int32_t* nkeep, int nlv, int nmax, int nms_post,
                                int max_num, float* out, int32_t* n_out, void* stream) {

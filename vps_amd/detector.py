@@ -237,8 +237,8 @@ class PanopticFuseTrack(HipModule):
             if snap is not None:
                 self._tracker_restore(snap)
             pf, self._pf = self._pf, None
-            if pf is not None:
-                pf['event'].synchronize()
+            for r in pf or []:
+                r['event'].synchronize()
             self._cache = None
             self._handoff = None
         raise hip.VpsHipError('f16x3: the frame still overflows the fp16 range after three rounds of per-layer bf16x6 fallback')
@@ -298,6 +298,7 @@ class PanopticFuseTrack(HipModule):
                 self._side = torch.cuda.Stream(device=dev)
             side = self._side
         flow = cat = aux = levels = None
+        late = []
         if inject is not None and 'neck_out' in inject:
             # tests: the neck output itself is injected (five NCHW levels) — the image-only stages and the neck are skipped
             x = [nhwc.from_nchw(l.to(dev), ws, 'inj.neck%d' % i) for i, l in enumerate(inject['neck_out'])]
@@ -308,27 +309,40 @@ class PanopticFuseTrack(HipModule):
             x = levels
             self._mark('backbone_fpn')
         else:
-            pf, self._pf = self._pf, None
+            pending, self._pf = self._pf or [], None
+            late = []
             if side is not None:
-                # (1) flow + (2) backbone / FPN / gather of THIS frame: enqueued on the prefetch streams during the previous call
+                # (1) flow + (2) backbone / FPN / gather of THIS frame: enqueued on the prefetch streams during an earlier call
                 # (matched by tensor identity), or now - through the same machinery (the image-stage streams, the lane workspace
-                # whose temporaries all ring slots share, a ring slot for the outputs), ahead of the next frame's
-                hit = pf is not None and pf['img'] is img and pf['ref'] is ref_img and pf['version'] == (img._version, ref_img._version)
-                if not hit:
-                    if pf is not None:
+                # whose temporaries all ring slots share, a ring slot for the outputs), ahead of the announced frames'.
+                # `prefetch`: one (next_img, its ref) pair or a list of them in frame order. The FIRST announced frame is enqueued
+                # here, at the start of the call; a SECOND one behind this frame's neck, so that the GPU has the next
+                # frames' image-only stages queued through the tail of this frame and across the frame boundary (round 5: the
+                # frame's last third ran on one or two streams and the boundary was a 0.2 - 0.3 ms bubble; ring of three slots: frame t+2 goes where frame t-1 was, whose
+                # gathered feature neck(t) has read by then).
+                same = lambda r, a, b: r['img'] is a and r['ref'] is b and r['version'] == (a._version, b._version)
+                announced = [] if prefetch is None else ([prefetch] if torch.is_tensor(prefetch[0]) else list(prefetch))
+                pf = next((r for r in pending if same(r, img, ref_img)), None)
+                keep = [r for r in pending if r is not pf and any(same(r, a, b) for a, b in announced)]
+                for r in pending:
+                    if r is not pf and r not in keep:
                         # an unused prefetch (the caller announced other tensors than it now passes): the prefetch streams may still be
                         # reading those tensors, which the caller is now free to rewrite on the main stream - so the main stream orders
                         # itself behind them. Its results sit in a ring slot nobody reads.
-                        main.wait_event(pf['event'])
+                        main.wait_event(r['event'])
+                if pf is None:
                     pf = self._enqueue_image_stages(img, ref_img, main)
-                if prefetch is not None:
-                    self._pf = self._enqueue_image_stages(prefetch[0], prefetch[1], main)
+                is_pending = lambda a, b: any(same(r, a, b) for r in keep)
+                if announced and not is_pending(*announced[0]):
+                    keep.append(self._enqueue_image_stages(announced[0][0], announced[0][1], main))       # the NEXT frame: now
+                late = [(a, b) for a, b in announced[1:2] if not is_pending(a, b)]                        # the one after: before the tail read
+                self._pf = keep or None
                 main.wait_event(pf['event'])
                 flow, levels, cat = pf['flow'], pf['levels'], pf['cat']
                 self._mark('flownet2')
             else:
-                if pf is not None:
-                    pf['event'].synchronize()
+                for r in pending:
+                    r['event'].synchronize()
                 # one stream (profiling, overlap_streams off): the serial schedule in the main workspace
                 flow = self.flownet2.run(img, ref_img, self._mean_t, self._std_t, ws)
                 self._mark('flownet2')
@@ -368,6 +382,13 @@ class PanopticFuseTrack(HipModule):
         if inject is not None and 'fcn_score' in inject:
             fcn_score = nhwc.from_nchw(inject['fcn_score'].to(dev), ws, 'inj.fcn_score')
         self._mark('semantic_head')
+        if self.with_fusion and late and main is not None:
+            # the frame after next (see `prefetch` above): its image-only stages go out HERE, behind the neck - the prefetch streams
+            # order themselves behind what the main stream holds now (the neck: the last reader of the ring slot they rewrite) and then
+            # run beside everything that follows: the RPN / box head / MaskROI chain of mostly single-workgroup kernels, the two host
+            # reads, the mask head, MaskRemoval's dependency chain, the combine and the next call's first launches - the two thirds of
+            # a frame in which the GPU had least to do (idle 0.72 -> 0.38 ms per traced frame, profiles/r05_frame_occupancy_traced.json)
+            self._pf = (self._pf or []) + [self._enqueue_image_stages(late[0][0], late[0][1], main)]
         # (5) RPN ------------------------------------------------------------------------------------------------
         nprop = None                          # device int32 [1]: rows of `proposals` that exist (None = all)
         if inject is not None and 'proposals' in inject:
@@ -378,6 +399,7 @@ class PanopticFuseTrack(HipModule):
         # (6) bbox head + MaskROI + tracking ---------------------------------------------------------------------
         det = self.simple_test_bboxes(x, meta, proposals, im_info, is_first, ws, inject, defer_tracking, nprop)
         self._mark('bbox_track')
+
         det_bboxes, det_labels = det['det_bboxes'], det['det_labels']
         cls_prob, mask_rois, cls_idx = det['cls_prob'], det['det_rois'], det['cls_idx']
         mask_results = [[] for _ in range(self.mask_head.num_classes - 1)]       # simple_test_mask: `or True` stub
@@ -408,13 +430,11 @@ class PanopticFuseTrack(HipModule):
         # ---- the frame's END-OF-FRAME host read: kept list, ids, tracker memory size, fp16-range words (one D2H) ----------
         K = mask_rois.size(0)
         tail = ws.get('frame.tail', (2 * MaskROI.KCAP + 8,), dtype=torch.int32, zero=False)
-        tail[0:4].copy_(removal['kinfo'])
-        tail[8:8 + K].copy_(removal['keep'][:K])
         has_ids = self.with_track and not defer_tracking
-        if has_ids:
-            tail[8 + MaskROI.KCAP:8 + MaskROI.KCAP + K].copy_(det['ids_dev'][:K])
-            tail[4:5].copy_(self._mem_count)
-        tail[5:6].copy_(nhwc.f16_status(dev).amax().view(1))
+        st16 = nhwc.f16_status(dev)
+        hip.check(hip.load().vps_frame_tail(hip.ptr(removal['kinfo']), hip.ptr(removal['keep']), hip.ptr(det['ids_dev']) if has_ids else None,
+                                            hip.ptr(self._mem_count) if has_ids else None, hip.ptr(st16), st16.numel(), K, MaskROI.KCAP,
+                                            hip.ptr(tail), hip.stream_ptr()), 'vps_frame_tail')
         th = tail.cpu().numpy()
         if th[5]:
             return None              # f16x3: a layer overflowed the fp16 range -> simple_test falls back and recomputes the frame
@@ -517,9 +537,9 @@ class PanopticFuseTrack(HipModule):
             return False
         self.ensure_packed(img.device)
         pf, self._pf = self._pf, None
-        if pf is not None:
-            pf['event'].synchronize()
-        self._pf = self._enqueue_image_stages(img, ref_img, torch.cuda.current_stream(img.device))
+        for r in pf or []:
+            r['event'].synchronize()
+        self._pf = [self._enqueue_image_stages(img, ref_img, torch.cuda.current_stream(img.device))]
         return True
 
     def _sd_stream(self, dev):

@@ -109,7 +109,7 @@ class FlowNetC(_RefineS):
         ws.release(c2b)
         in31 = ws.fmap(tag + 'in31', N, c3a.H, c3a.W, 473)
         p['conv_redir'](c3a, out=in31.window(0, 32), ws=ws)
-        nhwc.correlation(c3a, c3b, in31.window(32, 441), 20, 2, hip.ACT_LEAKY, 0.1)   # corr + corr_activation
+        nhwc.correlation(c3a, c3b, in31.window(32, 441), 20, 2, hip.ACT_LEAKY, 0.1, prec=p['conv_redir'].prec)   # corr + corr_activation
         ws.release(c3a, c3b)
         p['conv3_1'](in31, out=cat3.window(0, 256), ws=ws)
         t = p['conv4'](cat3.window(0, 256), ws=ws, name=tag + 'c4', temp=True)

@@ -24,8 +24,8 @@ SYMBOLS = [
     'vps_abi_version', 'vps_build_info', 'vps_conv2d', 'vps_resample2d', 'vps_channelnorm', 'vps_correlation',
     'vps_flow_warp', 'vps_nchw_to_nhwc', 'vps_nhwc_to_nchw', 'vps_resize', 'vps_pool3x3s2', 'vps_bfp_gather',
     'vps_bfp_scatter', 'vps_axpb', 'vps_flow_prep', 'vps_flow_prep_pad', 'vps_flow_stage', 'vps_flow_stage_full', 'vps_groupnorm_relu', 'vps_groupnorm_apply', 'vps_tcea_temporal',
-    'vps_tcea_modulate', 'vps_tcea_modulate_ld', 'vps_roi_align', 'vps_nms_batched', 'vps_delta2bbox', 'vps_bbox_overlaps',
-    'vps_row_softmax', 'vps_mask_count', 'vps_mask_commit', 'vps_mask_removal', 'vps_mask_removal_dep', 'vps_mask_level', 'vps_panoptic_combine',
+    'vps_tcea_modulate', 'vps_tcea_modulate_ld', 'vps_correlation_f16', 'vps_roi_align', 'vps_nms_batched', 'vps_delta2bbox', 'vps_bbox_overlaps',
+    'vps_row_softmax', 'vps_mask_count', 'vps_mask_commit', 'vps_mask_removal', 'vps_mask_removal_dep', 'vps_frame_tail', 'vps_mask_level', 'vps_panoptic_combine',
     'vps_panoptic_combine_dev', 'vps_rpn_select', 'vps_rpn_collect', 'vps_maskroi_select', 'vps_maskroi_finish', 'vps_track_assign', 'vps_pan_instances',
     'vps_unify_hist', 'vps_unify_tables', 'vps_unify_write', 'vps_image_prep', 'vps_resize_u8', 'vps_segment_stats', 'vps_segment_paint', 'vps_pair_count',
     'vps_png_info', 'vps_png_decode_bgr8',
@@ -120,6 +120,8 @@ def load():
     lib.vps_channelnorm.argtypes = [Tensor4, Tensor4, c_int, c_int, c_int, c_int, c_void_p]
     lib.vps_correlation.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]
+    lib.vps_correlation_f16.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
+                                        c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]
     lib.vps_flow_warp.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_void_p]
     lib.vps_nchw_to_nhwc.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]

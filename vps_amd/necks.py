@@ -142,7 +142,7 @@ class BFPTcea(HipModule):
         # when pooling is on - tools that inspect them switch `ws.pooling` off)
         T = lambda nm, c: ws.fmap(tag + nm, N, H, W, c, temp=True)
         warp1 = nhwc.flow_warp(ref_bsf, flow_init, T('warp1', C))
-        nhwc.correlation(bsf, warp1, cat.window(C, 81), 4, 1)
+        nhwc.correlation(bsf, warp1, cat.window(C, 81), 4, 1, prec=self._refine.prec)
         x = cat
         for i, pc in enumerate(self._est):
             y = pc(x, ws=ws, name='%sest%d' % (tag, i), temp=True)

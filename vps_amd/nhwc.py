@@ -58,6 +58,11 @@ def f16_fallback(device):
     flagged = torch.nonzero(st).flatten().cpu().tolist()
     st.zero_()
     n = 0
+    if F16_CORR_SLOT in flagged:
+        # a correlation operand left the fp16 range: the exact kernels from now on
+        flagged.remove(F16_CORR_SLOT)
+        CORR_F16[0] = False
+        n += 1
     for slot in flagged:
         ref = _F16_LAYERS.get(slot)
         pc = ref() if ref is not None else None
@@ -371,7 +376,7 @@ class PackedConv:
         if self.prec == hip.PREC_F16X3:
             # what `use_fallback` needs to re-pack this layer for bf16x6: the fp32 weights in packed layout (host) — the epilogue
             # scale without the f16x3 pre-scaling is restored below
-            self.f16_slot = _F16_NEXT[0] if _F16_NEXT[0] < F16_SLOTS else 0
+            self.f16_slot = _F16_NEXT[0] if _F16_NEXT[0] < F16_SLOTS - 1 else 0        # (the last slot is the correlations')
             if self.f16_slot:
                 _F16_NEXT[0] += 1
                 _F16_LAYERS[self.f16_slot] = weakref.ref(self)
@@ -666,8 +671,23 @@ def pool3x3s2(x, out, mode='max'):
     return out
 
 
-def correlation(x1, x2, out, max_disp, stride2, act=hip.ACT_NONE, slope=0.1):
+# f16x3 mode: the two correlations of the path run in split fp16 on the matrix cores (vps_correlation_f16, csrc/corr_mfma.hip) and
+# report operands beyond the fp16 range in their own status slot; `f16_fallback` then switches them to the exact kernels for good.
+# VPS_CORR_F16=0: always the exact vector-ALU kernels.
+CORR_F16 = [os.environ.get('VPS_CORR_F16', '1') != '0']
+F16_CORR_SLOT = F16_SLOTS - 1
+
+
+def correlation(x1, x2, out, max_disp, stride2, act=hip.ACT_NONE, slope=0.1, prec=None):
+    """prec: the arithmetic of the calling model's contractions (hip.PREC_*); PREC_F16X3 selects the split-fp16 MFMA kernel where one
+    exists, everything else the exact fp32 kernels"""
     assert x1.C == x2.C
+    if prec == hip.PREC_F16X3 and CORR_F16[0]:
+        st = c_void_p(f16_status(x1.t.device).data_ptr() + 4 * F16_CORR_SLOT)
+        hip.check(hip.load().vps_correlation_f16(x1.ptr(), x1.ld, x1.coff, x2.ptr(), x2.ld, x2.coff, out.ptr(), out.ld, out.coff,
+                                                 x1.N, x1.H, x1.W, x1.C, max_disp, stride2, act, float(slope), st, hip.stream_ptr()),
+                  'vps_correlation_f16')
+        return out
     hip.check(hip.load().vps_correlation(x1.ptr(), x1.ld, x1.coff, x2.ptr(), x2.ld, x2.coff, out.ptr(), out.ld, out.coff,
                                          x1.N, x1.H, x1.W, x1.C, max_disp, stride2, act, float(slope), hip.stream_ptr()),
               'vps_correlation')

@@ -130,21 +130,25 @@ class MaskRemoval(nn.Module):
         sc = cls0[sorted_inds]
         x0 = np.maximum(sb[:, 0], 0); x1 = np.minimum(sb[:, 2] + 1, W); y0 = np.maximum(sb[:, 1], 0); y1 = np.minimum(sb[:, 3] + 1, H)
         area = np.maximum(x1 - x0, 0) * np.maximum(y1 - y0, 0)
+        dep_mode = MASK_REMOVAL_MODE == 'dep' and W % 4 == 0 and n <= MaskROI.KCAP
         lvl = np.zeros(n, dtype=np.int64)
-        for i in range(1, n):
-            dep = (sc[:i] == sc[i]) & (x0[:i] < x1[i]) & (x0[i] < x1[:i]) & (y0[:i] < y1[i]) & (y0[i] < y1[:i])
-            if dep.any():
-                lvl[i] = lvl[:i][dep].max() + 1
+        if not dep_mode and not MASK_REMOVAL_SINGLE_LAUNCH:
+            # (the one-launch kernel finds a box's dependencies itself: this O(n^2) host loop sat on the frame's critical path with the
+            # GPU idle - 0.26 ms in the traced frame, profiles/r05_frame_occupancy_traced.json before / after)
+            for i in range(1, n):
+                dep = (sc[:i] == sc[i]) & (x0[:i] < x1[i]) & (x0[i] < x1[:i]) & (y0[:i] < y1[i]) & (y0[i] < y1[:i])
+                if dep.any():
+                    lvl[i] = lvl[:i][dep].max() + 1
         order = np.argsort(lvl, kind='stable')
         nlv = int(lvl.max()) + 1
         starts = np.searchsorted(lvl[order], np.arange(nlv + 1))
         host = np.concatenate([sb.reshape(-1), sc, sorted_inds, order]).astype(np.int32)
         meta = torch.from_numpy(host).to(dev, non_blocking=True)
         counts = ws.get('mr.counts', (max(n, 1), 2), dtype=torch.int32, zero=False)
-        if not (MASK_REMOVAL_MODE == 'dep' and W % 4 == 0):
+        if not dep_mode:
             occ.zero_(); counts.zero_()             # (the one-launch entries zero what they use themselves)
         base = meta.data_ptr()
-        if MASK_REMOVAL_MODE == 'dep' and W % 4 == 0 and n <= MaskROI.KCAP:
+        if dep_mode:
             done = ws.get('mr.done', (MaskROI.KCAP,), dtype=torch.int32, zero=False)
             # status word = kinfo[2] (read with the frame's end-of-frame read; bit 2: a dependency wait expired)
             hip.check(lib.vps_mask_removal_dep(hip.ptr(mp), S, ctypes.c_void_p(base), ctypes.c_void_p(base + 16 * n), ctypes.c_void_p(base + 20 * n),
