@@ -273,16 +273,17 @@ def test_clip_shard_backend_and_handoff_feature(setup):
 def test_image_stage_stream_fan_out_is_bitwise_the_single_prefetch_stream(setup):
     """detector.pre_streams (VPS_PRE_STREAMS): the next frame's image-only stages on one prefetch stream (1), with ResNet + FPN + gather
     beside FlowNet2 (2), with FlowNetSD beside the FlowNetC -> S -> S chain as well (3, the default), the main chain on a
-    high-priority stream (main_priority), one or two frames announced ahead (prefetch_depth) - all bitwise equal, over a clip long enough to reuse every ring slot (10 frames, ring of 3)"""
+    high-priority stream (main_priority), one or two frames announced ahead (prefetch_depth), the second one's backbone deferred to the end of the frame (defer_backbone) - all bitwise equal, over a clip long enough to reuse every ring slot (10 frames, ring of 3)"""
     from vps_amd.clip_shard import ClipShardRunner, DetectorBackend
     m, fr, dev = setup['model'], setup['frames'], setup['dev']
     H, W, n = setup['H'], setup['W'], setup['n']
     frd = [fr[t % n].to(dev).clone() for t in range(10)]
     runs = []
-    old, oldp = m.pre_streams, m.main_priority
+    old, oldp, oldd = m.pre_streams, m.main_priority, m.defer_backbone
     try:
-        for streams, prio, depth in ((1, False, 1), (2, False, 1), (3, False, 1), (3, True, 2), (3, False, 2)):
-            m.pre_streams, m.main_priority = streams, prio
+        for streams, prio, depth, defer in ((1, False, 1, False), (2, False, 1, False), (3, False, 1, False), (3, True, 2, False), (3, False, 2, False),
+                                            (3, False, 2, True), (1, False, 2, True)):
+            m.pre_streams, m.main_priority, m.defer_backbone = streams, prio, defer
             m._cache = None; m._pf = None; m.reset_tracker()
             be = DetectorBackend(m, H, W, prefetch=True)
             be.prefetch_depth = depth          # 2: the frame after next is announced too and enqueued before the end-of-frame read
@@ -291,7 +292,7 @@ def test_image_stage_stream_fan_out_is_bitwise_the_single_prefetch_stream(setup)
             runs.append([{k: (v.cpu().numpy().copy() if torch.is_tensor(v) else np.asarray(v).copy()) for k, v in o.items()
                           if k in ('panoptic_det_obj_ids', 'panoptic_outputs', 'fcn_outputs', 'panoptic_cls_prob')} for o in outs])
     finally:
-        m.pre_streams, m.main_priority = old, oldp
+        m.pre_streams, m.main_priority, m.defer_backbone = old, oldp, oldd
     for r in runs[1:]:
         for t in range(len(frd)):
             for k in runs[0][t]:

@@ -180,11 +180,16 @@ class ClipShardRunner:
             self.max_posted = 0
 
             def fill():
-                for j in range(max(b - a for a, b in parts)):
+                # round robin over the peers, lowest position first: on RCCL a rank's point-to-point operations run in posting order
+                more = True
+                while more:
+                    more = False
+                    lo = min((posted[r] for r in posted if posted[r] < parts[r][1] - parts[r][0] and posted[r] - taken[r] < window), default=None)
                     for r in range(1, world):
-                        if posted[r] == j and j < parts[r][1] - parts[r][0] and j - taken[r] < window:
-                            post_recv(r, j)
-                            posted[r] = j + 1
+                        if posted[r] == lo and lo < parts[r][1] - parts[r][0] and lo - taken[r] < window:
+                            post_recv(r, lo)
+                            posted[r] = lo + 1
+                            more = True
                 self.max_posted = max(self.max_posted, max(posted[r] - taken[r] for r in posted))
             fill()
         # 3) this rank's frames

@@ -122,6 +122,10 @@ class PanopticFuseTrack(HipModule):
         self.main_priority = os.environ.get('VPS_MAIN_PRIO', '0') != '0'
         self._hp = None
         self._sd = None
+        # 1: ResNet + FPN of the frame after next are enqueued in front of the end-of-frame read instead of behind the neck (they then
+        # carry the GPU across the frame boundary: idle 0.57 -> 0.28 ms in the traced frame) - measured SLOWER untraced (52.6 against
+        # 53.2 frames/s in one call: they compete with the next frame's neck): off
+        self.defer_backbone = os.environ.get('VPS_DEFER_BACKBONE', '0') != '0'
         self._pre_aux = []                 # the extra prefetch streams (pre_streams > 1)
         self._pre = None                   # prefetch stream + its ring of workspaces (clip pipelines)
         self._ring = None
@@ -238,7 +242,10 @@ class PanopticFuseTrack(HipModule):
                 self._tracker_restore(snap)
             pf, self._pf = self._pf, None
             for r in pf or []:
+                self._finish_backbone(r)
                 r['event'].synchronize()
+                if r['event2'] is not None:
+                    r['event2'].synchronize()
             self._cache = None
             self._handoff = None
         raise hip.VpsHipError('f16x3: the frame still overflows the fp16 range after three rounds of per-layer bf16x6 fallback')
@@ -329,7 +336,10 @@ class PanopticFuseTrack(HipModule):
                         # an unused prefetch (the caller announced other tensors than it now passes): the prefetch streams may still be
                         # reading those tensors, which the caller is now free to rewrite on the main stream - so the main stream orders
                         # itself behind them. Its results sit in a ring slot nobody reads.
+                        self._finish_backbone(r)
                         main.wait_event(r['event'])
+                        if r['event2'] is not None:
+                            main.wait_event(r['event2'])
                 if pf is None:
                     pf = self._enqueue_image_stages(img, ref_img, main)
                 is_pending = lambda a, b: any(same(r, a, b) for r in keep)
@@ -337,12 +347,18 @@ class PanopticFuseTrack(HipModule):
                     keep.append(self._enqueue_image_stages(announced[0][0], announced[0][1], main))       # the NEXT frame: now
                 late = [(a, b) for a, b in announced[1:2] if not is_pending(a, b)]                        # the one after: before the tail read
                 self._pf = keep or None
+                self._finish_backbone(pf)                 # (a record whose backbone was deferred and never placed: now)
                 main.wait_event(pf['event'])
+                if pf['event2'] is not None:
+                    main.wait_event(pf['event2'])
                 flow, levels, cat = pf['flow'], pf['levels'], pf['cat']
                 self._mark('flownet2')
             else:
                 for r in pending:
+                    self._finish_backbone(r)
                     r['event'].synchronize()
+                    if r['event2'] is not None:
+                        r['event2'].synchronize()
                 # one stream (profiling, overlap_streams off): the serial schedule in the main workspace
                 flow = self.flownet2.run(img, ref_img, self._mean_t, self._std_t, ws)
                 self._mark('flownet2')
@@ -388,7 +404,9 @@ class PanopticFuseTrack(HipModule):
             # run beside everything that follows: the RPN / box head / MaskROI chain of mostly single-workgroup kernels, the two host
             # reads, the mask head, MaskRemoval's dependency chain, the combine and the next call's first launches - the two thirds of
             # a frame in which the GPU had least to do (idle 0.72 -> 0.38 ms per traced frame, profiles/r05_frame_occupancy_traced.json)
-            self._pf = (self._pf or []) + [self._enqueue_image_stages(late[0][0], late[0][1], main)]
+            # ... FlowNet2 (the long chain) here; its ResNet + FPN + gather (~4 ms on one stream) are placed in front of the end-of-frame read
+            # instead: they carry the GPU across the frame boundary (host read, result assembly, the next call's first launches)
+            self._pf = (self._pf or []) + [self._enqueue_image_stages(late[0][0], late[0][1], main, defer_backbone=self.defer_backbone)]
         # (5) RPN ------------------------------------------------------------------------------------------------
         nprop = None                          # device int32 [1]: rows of `proposals` that exist (None = all)
         if inject is not None and 'proposals' in inject:
@@ -430,6 +448,8 @@ class PanopticFuseTrack(HipModule):
         # ---- the frame's END-OF-FRAME host read: kept list, ids, tracker memory size, fp16-range words (one D2H) ----------
         K = mask_rois.size(0)
         tail = ws.get('frame.tail', (2 * MaskROI.KCAP + 8,), dtype=torch.int32, zero=False)
+        for r in self._pf or []:
+            self._finish_backbone(r)
         has_ids = self.with_track and not defer_tracking
         st16 = nhwc.f16_status(dev)
         hip.check(hip.load().vps_frame_tail(hip.ptr(removal['kinfo']), hip.ptr(removal['keep']), hip.ptr(det['ids_dev']) if has_ids else None,
@@ -492,7 +512,7 @@ class PanopticFuseTrack(HipModule):
             return 0
         return sum(w.nbytes() for w in [self._ws, self._lane] + self._ring) + self._ws.pool.total
 
-    def _enqueue_image_stages(self, nimg, nref, main):
+    def _enqueue_image_stages(self, nimg, nref, main, defer_backbone=False):
         """The image-only stages (FlowNet2, ResNet + FPN + gather) of a frame go to the prefetch streams: for the frame the NEXT call
         will be made with, before anything of the current frame is enqueued, so they run beside the current frame's neck and heads, not
         behind its semantic head - they are the longest chain (~16 ms of the frame's ~22 ms of kernel time) and the main / side
@@ -502,7 +522,10 @@ class PanopticFuseTrack(HipModule):
         written for frame t-2, whose flow / levels were read by neck(t-2) and whose gathered feature was last read by neck(t-1) as
         ref_bsf - both enqueued on the main stream in earlier calls, which the waits below order every prefetch stream behind. The
         images may have been produced on the main stream too. Every auxiliary stream is joined into the first one before the event the
-        consumer waits for is recorded. -> the record the consuming call matches by tensor identity."""
+        consumer waits for is recorded. -> the record the consuming call matches by tensor identity.
+        defer_backbone: only FlowNet2 (the long chain) is enqueued now; ResNet + FPN + gather of that frame follow with
+        `_finish_backbone` - the caller places them where the GPU would otherwise run dry (the end of the current frame). They wait for
+        an EVENT recorded on the main stream now, not for whatever the main stream holds when they are enqueued."""
         dev = nimg.device
         self._workspace(dev)
         if self._pre is None or self._pre.device != dev:
@@ -513,19 +536,39 @@ class PanopticFuseTrack(HipModule):
         lws = self._lane.with_out(self._ring[self._slot])
         bb_stream = self._pre_aux[0] if self.pre_streams >= 2 else self._pre
         sd_stream = self._pre_aux[1] if self.pre_streams >= 3 else None
-        if bb_stream is not self._pre:
+        defer_backbone = defer_backbone and bb_stream is not self._pre
+        rec = dict(img=nimg, ref=nref, version=(nimg._version, nref._version), levels=None, cat=None, event2=None, bb_pending=None)
+        if defer_backbone:
+            after = torch.cuda.Event()
+            after.record(main)
+            rec['bb_pending'] = (lws, after)
+        elif bb_stream is not self._pre:
             bb_stream.wait_stream(main)
             with torch.cuda.stream(bb_stream):
-                nlevels, ncat = self._backbone_fpn_gather(nimg, lws, ring=True)
+                rec['levels'], rec['cat'] = self._backbone_fpn_gather(nimg, lws, ring=True)
         with torch.cuda.stream(self._pre):
-            nflow = self.flownet2.run(nimg, nref, self._mean_t, self._std_t, lws, sd_stream=sd_stream)
+            rec['flow'] = self.flownet2.run(nimg, nref, self._mean_t, self._std_t, lws, sd_stream=sd_stream)
             if bb_stream is self._pre:
-                nlevels, ncat = self._backbone_fpn_gather(nimg, lws, ring=True)
-            else:
+                rec['levels'], rec['cat'] = self._backbone_fpn_gather(nimg, lws, ring=True)
+            elif not defer_backbone:
                 self._pre.wait_stream(bb_stream)
             ev = torch.cuda.Event()
             ev.record(self._pre)
-        return dict(img=nimg, ref=nref, version=(nimg._version, nref._version), event=ev, flow=nflow, levels=nlevels, cat=ncat)
+        rec['event'] = ev
+        return rec
+
+    def _finish_backbone(self, rec):
+        """ResNet + FPN + gather of a record whose backbone was deferred (`_enqueue_image_stages(defer_backbone=True)`)"""
+        if rec.get('bb_pending') is None:
+            return
+        lws, after = rec['bb_pending']
+        rec['bb_pending'] = None
+        bb_stream = self._pre_aux[0]
+        bb_stream.wait_event(after)
+        with torch.cuda.stream(bb_stream):
+            rec['levels'], rec['cat'] = self._backbone_fpn_gather(rec['img'], lws, ring=True)
+            rec['event2'] = torch.cuda.Event()
+            rec['event2'].record(bb_stream)
 
     @torch.no_grad()
     def prime(self, img, ref_img):
@@ -538,7 +581,10 @@ class PanopticFuseTrack(HipModule):
         self.ensure_packed(img.device)
         pf, self._pf = self._pf, None
         for r in pf or []:
+            self._finish_backbone(r)
             r['event'].synchronize()
+            if r['event2'] is not None:
+                r['event2'].synchronize()
         self._pf = [self._enqueue_image_stages(img, ref_img, torch.cuda.current_stream(img.device))]
         return True
 
