@@ -149,6 +149,8 @@ def hbm_kernels(dev):
     h8, w8 = H // 8, W // 8
     a8 = fm('a8', h8, w8, 256); b8 = fm('b8', h8, w8, 256); c441 = ws.fmap('c441', 1, h8, w8, 441)
     add('correlation_flownetc_441ch', 4.0 * h8 * w8 * (512 + 441), lambda: nhwc.correlation(a8, b8, c441, 20, 2), '2x256ch -> 441ch @%dx%d' % (h8, w8))
+    add('correlation_flownetc_441ch_split_fp16_mfma', 4.0 * h8 * w8 * (512 + 441), lambda: nhwc.correlation(a8, b8, c441, 20, 2, prec=hip.PREC_F16X3),
+        '2x256ch -> 441ch @%dx%d, vps_correlation_f16 (what the f16x3 frame runs)' % (h8, w8))
     # FlowNet2 stage kernel (upsample x4 + resample2d + 2x channelnorm + concat, flownet2.py:142-187), whole-pixel form: the 8-float
     # image pixel + the quarter-resolution flow read, the 12-float pixel of the next network's input written @full res
     lib = hip.load()
@@ -568,8 +570,9 @@ def main():
         if not args.no_extras and (Hh, Ww) == (H, W):
             hbm = hbm_kernels(dev)
             # the same kernels INSIDE the frame (real operands, neighbours in the caches): achieved GB/s from the in-frame duration
-            frame_calls = {'flow_warp': ('vps_flow_warp', 0), 'correlation_flownetc_441ch': ('vps_correlation', 0),
-                           'correlation_lite_81ch': ('vps_correlation', 1), 'flow_stage': ('vps_flow_stage_full', 0),
+            csym = 'vps_correlation_f16' if 'vps_correlation_f16' in in_frame else 'vps_correlation'       # f16x3 mode: split fp16 on MFMA where an instance exists
+            frame_calls = {'flow_warp': ('vps_flow_warp', 0), 'correlation_flownetc_441ch': (csym, 0),
+                           'correlation_lite_81ch': (csym, 1), 'flow_stage': ('vps_flow_stage_full', 0),
                            'panoptic_combine': ('vps_panoptic_combine_dev', 0), 'roi_align_1000x7x7': ('vps_roi_align', 0),
                            'bfp_gather': ('vps_bfp_gather', 0)}
             for k, (sym, idx) in frame_calls.items():
@@ -599,9 +602,9 @@ def main():
                        'detections_per_frame': round(ndet / max(total_frames, 1), 1),
                        'parallelism': ('clip-shard x%d (contiguous shards of %d frames), 1 p2p feature hand-off per shard boundary, tracker replay '
                                        'on rank 0 + result gather inside the timed region' % (world, args.steps)) if use_runner else 'single GPU',
-                       'pipelining': ('two HIP streams per frame (neck + detection heads || semantic head) + %d for the image-only stages of the NEXT frame of the clip '
-                                      '(FlowNetC-S-S chain | ResNet + FPN + gather | FlowNetSD; ring of three workspaces), enqueued before the current frame\'s neck'
-                                      % getattr(model, 'pre_streams', 1)) if (use_runner and not args.no_prefetch and not args.single_stream) else 'two HIP streams per frame' if not args.single_stream else 'one stream',
+                       'pipelining': ('two HIP streams per frame (neck + detection heads || semantic head) + %d for the image-only stages of the frames ahead '
+                                      '(FlowNetC-S-S chain | ResNet + FPN + gather | FlowNetSD; ring of three output slots); %d frame(s) announced: frame t+1 at the start of call t '
+                                      'if not in flight, frame t+2 behind neck(t)' % (getattr(model, 'pre_streams', 1), DetectorBackend.prefetch_depth)) if (use_runner and not args.no_prefetch and not args.single_stream) else 'two HIP streams per frame' if not args.single_stream else 'one stream',
                        'workspace_GB': ws_timed_gb,
                        'workspace_GB_after_the_untimed_extras': round(model.workspace_bytes() / 1e9, 2),       # + the one-stream instrumented frame, the per-call loop
                        'timed_region': 'inputs resident in HBM; excludes the H2D of the two 25 MB frames and the D2H of the two uint8 maps that '

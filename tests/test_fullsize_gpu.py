@@ -24,13 +24,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 H, W, NFR = 1024, 2048, 3
 
 
-def _model(prec):
+SEP_HEAD = os.path.join(ROOT, 'tests', 'golden', 'separated_fc_cls.npz')
+
+
+def _model(prec, separated=False):
+    """separated: the fitted box-classification layer of the `separated` strict fixture (tests/test_fullsize_sep_gpu.py; fitted on this
+    very clip, seed 0): every listing decision then has a margin 20x the arithmetic error, so two arithmetic modes / schedules must
+    agree on every detection - with the default synthetic heads ~100 scores sit in a narrow band and a comparison of two modes has to
+    tolerate flips whose number depends on the summation order (split-K partition) of both"""
     old = nhwc.DEFAULT_PREC
     nhwc.DEFAULT_PREC = prec
     try:
         cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', 'fusetrack.py'))
         m = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
-        synth.load_synth(m, 0)
+        synth.load_synth(m, 0, overrides=synth.separated_overrides(SEP_HEAD) if separated else None)
         m.ensure_packed(torch.device('cuda:0'))
     finally:
         nhwc.DEFAULT_PREC = old
@@ -65,11 +72,11 @@ def clip(dev):
 
 @pytest.fixture(scope='module')
 def default_run(dev, clip):
-    return _run(_model(hip.PREC_BF16X6), clip, dev, keep_stages=True)
+    return _run(_model(hip.PREC_BF16X6, separated=True), clip, dev, keep_stages=True)
 
 
 def test_split_bf16_kernels_agree_with_exact_fp32_kernels_at_full_size(dev, clip, default_run):
-    ref = _run(_model(hip.PREC_F32), clip, dev, keep_stages=True)
+    ref = _run(_model(hip.PREC_F32, separated=True), clip, dev, keep_stages=True)
     id_map, id_back, consistent = {}, {}, True
     for t, (a, b) in enumerate(zip(default_run, ref)):
         for k, tol in (('_flow', 2e-3), ('_p2', 2e-3), ('_neck', 2e-3), ('_fcn', 2e-3)):       # the fp32 tolerance of DESIGN.md §4
@@ -93,7 +100,7 @@ def test_split_bf16_kernels_agree_with_exact_fp32_kernels_at_full_size(dev, clip
                 ia, ib = int(a['panoptic_det_obj_ids'][i]), int(b['panoptic_det_obj_ids'][j])
                 assert id_map.setdefault(ia, ib) == ib and id_back.setdefault(ib, ia) == ia, (t, i, ia, ib)
         unmatched += len(b['boxes']) - len(used)
-        assert unmatched <= 1, (t, unmatched)
+        assert unmatched == 0, (t, unmatched)             # decidable heads (see _model): no borderline detection to disagree on
         consistent = consistent and unmatched == 0          # a kept / dropped box changes the tracker memory of later frames
         nstuff = 11
 
@@ -106,7 +113,7 @@ def test_split_bf16_kernels_agree_with_exact_fp32_kernels_at_full_size(dev, clip
 
 
 def test_full_size_run_is_deterministic_and_stream_schedule_invariant(dev, clip, default_run):
-    m = _model(hip.PREC_BF16X6)
+    m = _model(hip.PREC_BF16X6, separated=True)
     m.overlap_streams = False
     again = _run(m, clip, dev)
     for t, (a, b) in enumerate(zip(default_run, again)):
@@ -142,7 +149,7 @@ def test_full_size_workspace_fits_12_GB_in_the_pipelined_schedule(dev, clip):
 
 
 def test_full_size_reference_feature_cache_equals_recompute(dev, clip, default_run):
-    m = _model(hip.PREC_BF16X6)
+    m = _model(hip.PREC_BF16X6, separated=True)
     m.reuse_ref_features = False
     rec = _run(m, clip, dev)
     for t, (a, b) in enumerate(zip(default_run, rec)):

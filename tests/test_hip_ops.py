@@ -728,22 +728,22 @@ def test_correlation_split_fp16_on_mfma_equals_the_exact_kernels(dev, H, W, md, 
 @pytest.mark.gpu
 def test_correlation_split_fp16_reports_the_fp16_range(dev):
     """an operand beyond 65504 raises the correlations' status slot; nhwc.f16_fallback then switches them to the exact kernels for good"""
-    H, W, C = 4, 64, 256
+    H, W, C = 4, 128, 256                  # the FlowNetC configuration (stride-2 displacements, radius 10): the shape that runs on MFMA
     a = torch.randn(1, H, W, C); b = torch.randn(1, H, W, C)
     b[0, 2, 17, 5] = 1.0e5
     x1, x2 = nhwc.FMap(a.to(dev)), nhwc.FMap(b.to(dev))
-    out = nhwc.FMap(torch.zeros(1, H, W, 84, device=dev), 81, 0)
+    out = nhwc.FMap(torch.zeros(1, H, W, 444, device=dev), 441, 0)
     st = nhwc.f16_status(dev); st.zero_()
     old = nhwc.CORR_F16[0]
     nhwc.CORR_F16[0] = True
     try:
-        nhwc.correlation(x1, x2, out, 4, 1, prec=hip.PREC_F16X3)
+        nhwc.correlation(x1, x2, out, 20, 2, prec=hip.PREC_F16X3)
         torch.cuda.synchronize()
         assert int(st[nhwc.F16_CORR_SLOT].item()) == 1
         assert nhwc.f16_fallback(dev) == 1 and nhwc.CORR_F16[0] is False and int(st.amax().item()) == 0
-        ref = nhwc.FMap(torch.zeros(1, H, W, 84, device=dev), 81, 0)
-        nhwc.correlation(x1, x2, ref, 4, 1)
-        nhwc.correlation(x1, x2, out, 4, 1, prec=hip.PREC_F16X3)          # now the exact kernel
+        ref = nhwc.FMap(torch.zeros(1, H, W, 444, device=dev), 441, 0)
+        nhwc.correlation(x1, x2, ref, 20, 2)
+        nhwc.correlation(x1, x2, out, 20, 2, prec=hip.PREC_F16X3)          # now the exact kernel
         assert torch.equal(out.t, ref.t)
     finally:
         nhwc.CORR_F16[0] = old

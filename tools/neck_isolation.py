@@ -75,6 +75,7 @@ def main():
     for name, lv, rlv, fl in (('hip_levels+hip_flow', lv_h, ref_h, flow_h), ('hip_levels+oracle_flow', lv_h, ref_h, flow_o),
                               ('oracle_levels+hip_flow', lv_o, ref_o, flow_h), ('oracle_levels+oracle_flow', lv_o, ref_o, flow_o)):
         ws = nhwc.Workspace(dev)
+        ws.pooling = False                # the intermediates (warp, fused, refined) are read back: plain buffers
         L = [nhwc.from_nchw(t.to(dev), ws, 'l%d' % i) for i, t in enumerate(lv)]
         R = [nhwc.from_nchw(t.to(dev), ws, 'r%d' % i) for i, t in enumerate(rlv)]
         cat = en.gather(L, ws, 'cat'); refcat = en.gather(R, ws, 'refcat')
