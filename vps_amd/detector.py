@@ -433,11 +433,12 @@ class PanopticFuseTrack(HipModule):
         S = all_scores.shape[1]
         mask_score = all_scores.gather(3, cls_idx.view(-1, 1, 1, 1).expand(-1, S, S, 1)).squeeze(3).contiguous()
         self._mark('mask_head')
-        if side is not None:
-            main.wait_event(sem_done)      # the combine kernel reads fcn_score (prefetched work behind it is not waited for)
         # (9)-(11) MaskRemoval + SegTerm + combine: the kept list stays on the device -------------------------------
         last = self.mask_roi_panoptic.last
         removal = self.mask_removal(last['rows_h'], last['rows_d'], mask_score, (H, W), ws, self.class_mapping)
+        if side is not None:
+            main.wait_event(sem_done)      # the combine kernel reads fcn_score; MaskRemoval's dependency chain above does not: it may
+                                           # run beside the end of the semantic head (prefetched work behind the event is not waited for)
         pan, sem = panoptic_combine(fcn_score, removal, mask_score, self.panopticFPN.num_stuff_classes, self.panopticFPN.num_classes,
                                     (H, W), ws)
         h0, w0 = meta['img_shape'][0], meta['img_shape'][1]
