@@ -96,6 +96,11 @@ def test_kernel_resource_budget():
         assert r['vgpr_spill'] == 0, (name, r)
         # (the correlation kernel's two accumulator tiles live in AGPRs - the compiler's choice for accumulators no VALU instruction
         # touches inside the loop; 164 + 32 registers, one wave per SIMD)
+        # (the 256-column deformable instance is built for ONE block per CU: 2 x 4 accumulator tiles = 128 registers per lane in AGPRs,
+        # 512 registers per lane in all)
+        if 'conv_mfma_bf16p_kernel<2, 4, 2, 2' in name:
+            assert r['lds_bytes'] <= 160 * 1024 and r['vgpr'] <= 512 and r['scratch_bytes'] == 0, (name, r)
+            continue
         assert r['lds_bytes'] <= 160 * 1024 and r['vgpr'] <= 256 and (r['agpr'] == 0 or ('corr_mfma' in name and r['vgpr'] + r['agpr'] <= 256)), (name, r)
         if 'conv_mfma' in name:
             assert r['scratch_bytes'] == 0, (name, r)

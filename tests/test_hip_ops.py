@@ -214,6 +214,34 @@ def test_deform_conv_matches_oracle(dev, cin, cout, H, W, prec, tol):
     _cmp(out.to_nchw(), ref, rtol=tol, atol=tol * max(1.0, float(ref.abs().max()) / 4), what='deform conv')
 
 
+def test_deform_conv_256_column_tile_equals_the_128_column_tile(dev, monkeypatch):
+    monkeypatch.setattr(nhwc, 'DCN256', [True])
+    """Deformable layers with 256 output channels on maps of >= 256 pixel tiles run as ONE 128 x 256 block per pixel tile
+    (vps_conv_desc.tile_n 256: the bilinear loader works once per pixel tile instead of twice). Every output element is the same
+    chain of MFMA accumulations in either tiling -> bitwise equal to the 128-column launch, the GroupNorm sums of the epilogue too;
+    against the oracle (dcn/functions/deform_conv.py:10-80 semantics) on a ragged map."""
+    H, W = 181, 187                                    # 33847 pixels = 265 tiles of 128, the last one ragged
+    x = _rand(1, 256, H, W, seed=1)
+    off = _rand(1, 18, H, W, seed=2, scale=1.5)
+    w = _rand(256, 256, 3, 3, seed=3, scale=(2.0 / (256 * 9)) ** 0.5)
+    pc = nhwc.PackedConv(w, None, None, 1, 1, device=dev, deform=True, prec=hip.PREC_F16X3)
+    xs, offs = nhwc.from_nchw(x.to(dev)), nhwc.from_nchw(off.to(dev))
+    got = []
+    for wide in (False, True):
+        nhwc.DCN256[0] = wide
+        ws = nhwc.Workspace(dev)
+        slot = ws.get('gn', (nhwc.GN_REP, 64), dtype=torch.float64); slot.zero_()
+        trace = []
+        monkeypatch.setattr(nhwc, 'CONV_TRACE', trace)
+        o = pc(xs, ws=ws, name='o', offset=offs, gn=(slot, 32))
+        monkeypatch.setattr(nhwc, 'CONV_TRACE', None)
+        assert pc.gn_fused and ('tile%d ' % (256 if wide else 128)) in trace[0][3], trace[0][3]
+        got.append((o.t.clone(), slot.sum(dim=0).clone()))
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+    ref = O.deform_conv(x, off, w, 1, 1)
+    _cmp(nhwc.FMap(got[1][0], 256, 0).to_nchw(), ref, rtol=2e-5, atol=2e-5 * max(1.0, float(ref.abs().max()) / 4), what='deform conv, 256-column tile')
+
+
 @pytest.mark.parametrize('prec', [hip.PREC_F16X3, hip.PREC_BF16X6], ids=['f16x3', 'bf16x6'])
 @pytest.mark.parametrize('cin,cout,H,W', [(256, 256, 128, 160), (256, 128, 157, 211)])
 def test_deform_conv_epilogue_takes_the_groupnorm_sums(dev, cin, cout, H, W, prec):

@@ -509,7 +509,7 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
 // staged (between the MFMAs, like every other work item). Versus conv_mfma_bf16s_kernel (load | MFMAs | barrier | blend + stage |
 // barrier, weights through LDS): one barrier per k-step, staging interleaved with the matrix work, weights straight to registers.
 template <int TM, int TN, int WAVES_M, int WAVES_N, int MODE, bool TAPMAJOR, bool DEFORM = false>
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__(256, (TN >= 4 ? 1 : 2))            // the 256-column deformable instance: one block per CU, 512 registers per lane
 void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_m, const int tiles_n,
                             const int ksteps_per_split) {
     constexpr int BN = WAVES_N * TN * 32;
@@ -2078,7 +2078,7 @@ extern "C" int vps_conv2d(const vps_conv_desc* dp, void* stream) {
     if ((d.in_ld & 3) || (d.in_coff & 3) || (d.cin_pad & 3) || d.cin_pad <= 0) return VPS_EARG(3);
     if ((d.kpad % BK) || d.kpad < d.KH * d.KW * d.cin_pad || (d.korder != 0 && d.korder != 1)) return VPS_EARG(4);
     if (d.korder == 1 && d.kpad != d.KH * d.KW * ((d.cin_pad + BK - 1) / BK) * BK) return VPS_EARG(14);
-    if (d.tile_n != 32 && d.tile_n != 64 && d.tile_n != 128) return VPS_EARG(5);
+    if (d.tile_n != 32 && d.tile_n != 64 && d.tile_n != 128 && !(d.tile_n == 256 && d.offset && d.prec == VPS_PREC_F16X3 && d.korder == 1)) return VPS_EARG(5);
     if (d.cout_pad % d.tile_n || d.cout > d.cout_pad || d.cout <= 0) return VPS_EARG(6);
     if (d.nclass != d.os_y * d.os_x || d.nclass < 1 || d.os_y > 2 || d.os_x > 2) return VPS_EARG(7);
     if (d.ksplit < 1 || (d.ksplit > 1 && !d.ws)) return VPS_EARG(8);
@@ -2132,6 +2132,21 @@ extern "C" int vps_conv2d(const vps_conv_desc* dp, void* stream) {
     // tiles 2x2 waves of 64 rows x 32 columns beat 4x1 waves of 32 x 64 (half the weight loads: +8..18 %); for 128-column tiles
     // the 64 x 64 wave tile stays: 1x4 waves of 128 x 32 halve the weight loads again but double the fragment reads of the halo
     // tile, whose 18-row pitch costs a 2-way bank conflict (-7..13 %).
+    if (d.tile_n == 256) {
+        // deformable layers with >= 256 output channels (round 5): ONE block computes all 256 columns of its 128 pixels - the bilinear
+        // loader (4 corner loads + 16 multiply-adds + the fp16 split per staged float4: 8.3 VALU per MFMA with 128 columns) runs once
+        // instead of twice. 2 x 2 waves of 64 x 128, accumulators in AGPRs, one block per CU.
+        const int tiles_m = cdiv(M, BM), tiles_n = d.cout_pad / 256, ksteps = d.kpad / BK;
+        const int per_split = cdiv(ksteps, d.ksplit);
+        if (cdiv(ksteps, per_split) != d.ksplit) return VPS_EARG(20);
+        const long nblk = (long)tiles_m * tiles_n * d.ksplit;
+        hipLaunchKernelGGL((conv_mfma_bf16p_kernel<2, 4, 2, 2, VPS_PREC_F16X3, false, true>), dim3((unsigned)nblk), dim3(256), 0, s, d, M, tiles_m, tiles_n, per_split);
+        int st = vps_launch_status();
+        if (st || d.ksplit == 1 || d.tile_counter) return st;
+        const size_t total = (size_t)M * d.cout;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel<4>, dim3(stream_grid((long)(total / 4), 256)), dim3(256), 0, s, d, M);
+        return vps_launch_status();
+    }
     switch (d.tile_n) {
         case 128: return launch_conv<2, 2, 2, 2>(d, M, s);
         case 64: return launch_conv<2, 1, 2, 2>(d, M, s);

@@ -296,6 +296,11 @@ def pack_thin(g, KS, C4):
     return w.view(2, 2, 32, KS, nk, 2, 8).permute(3, 0, 4, 1, 5, 2, 6).contiguous()
 
 
+# 256-column tile of the deformable layers (VPS_DCN256=0 keeps the 128-column tile); only where it still gives >= this many blocks
+DCN256 = [os.environ.get('VPS_DCN256', '1') != '0']
+DCN256_MIN_TILES = int(os.environ.get('VPS_DCN256_MIN_TILES', '256'))
+
+
 def _tile_n(cout):
     return 32 if cout <= 32 else (64 if cout <= 64 else 128)
 
@@ -553,11 +558,17 @@ class PackedConv:
             assert offset is not None and offset.coff == 0 and offset.C >= 2 * self.KH * self.KW
             d.offset = offset.t.data_ptr(); d.off_ld = offset.ld
         d.tile_n = self.tile_n
+        M = x.N * d.Qh * d.Qw
+        # deformable layers with a multiple of 256 output channels on the large maps: one block computes all 256 columns of its
+        # 128 pixels, so the bilinear loader runs once per pixel tile instead of once per 128 columns (conv_mfma.hip, tile_n 256)
+        wide = (DCN256[0] and self.deform and self.prec == hip.PREC_F16X3 and self.korder == 1 and self.cout_pad % 256 == 0
+                and (M + 127) // 128 * (self.cout_pad // 256) >= DCN256_MIN_TILES)
+        tile_n = 256 if wide else self.tile_n
+        d.tile_n = tile_n
         if self.prec == hip.PREC_F16X3:
             d.status = f16_status(x.t.device).data_ptr() + 4 * getattr(self, 'f16_slot', 0)
         # split-K for launches that cannot fill 256 CUs
-        M = x.N * d.Qh * d.Qw
-        tiles = ((M + 127) // 128) * (self.cout_pad // self.tile_n) * d.nclass
+        tiles = ((M + 127) // 128) * (self.cout_pad // tile_n) * d.nclass
         ksteps = self.kpad // 32
         ksplit = 1
         if tiles < 256 and ksteps >= 8 and not getattr(self, 'small', False):
@@ -583,7 +594,7 @@ class PackedConv:
         if ksplit > 1:
             need = ksplit * d.nclass * M * self.cout_pad
             # tickets of the last-block reduction (vps_conv_desc.tile_counter): an upper bound of the tile count of every kernel family
-            ntick = d.nclass * (self.cout_pad // self.tile_n) * max((M + 127) // 128, x.N * ((d.Qh + 7) // 8) * ((d.Qw + 15) // 16))
+            ntick = d.nclass * (self.cout_pad // tile_n) * max((M + 127) // 128, x.N * ((d.Qh + 7) // 8) * ((d.Qw + 15) // 16))
             if ws is not None:
                 # one scratch buffer per stream: branches of the frame graph that run concurrently must not share it
                 key = '__splitk_ws_%x' % (getattr(hip.stream_ptr(), 'value', None) or 0)
@@ -610,7 +621,7 @@ class PackedConv:
             CONV_TRACE.append((self.flops(x.N, x.H, x.W), e0, e1,
                                '%d->%d k%dx%d s%d %s%s n%d %dx%d tile%d ksplit%d p%d' % (self.cin, self.cout, self.KH, self.KW, self.stride,
                                                                                    'T' if self.transposed else '', 'D' if self.deform else '',
-                                                                                   x.N, x.H, x.W, self.tile_n, ksplit, self.prec),
+                                                                                   x.N, x.H, x.W, tile_n, ksplit, self.prec),
                                self.bytes(x.N, x.H, x.W, res is not None)))
         else:
             hip.conv2d(d)
