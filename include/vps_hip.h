@@ -87,7 +87,7 @@ typedef struct vps_conv_desc {
     const float* offset;
     int32_t off_ld;
     /* tiling */
-    int32_t tile_n;     /* 32, 64 or 128 */
+    int32_t tile_n;     /* 32, 64 or 128; 256 for a deformable layer (offset set) in VPS_PREC_F16X3 with korder 1 and 256 | cout_pad */
     int32_t ksplit;     /* >=1; >1 needs ws of ksplit*M*cout_pad floats (M = nclass*N*Qh*Qw) */
     float* ws;
     /* split modes: 16-bit weight planes, no `w`. P planes: bf16 1, bf16x3 2, bf16x6 3 (plane p = bf16 RNE of the residual after p

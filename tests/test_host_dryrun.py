@@ -166,7 +166,7 @@ def test_semantic_head_hands_groupnorm_sums_to_the_unsplit_deformable_layers(mon
     monkeypatch.setattr(hip, 'load', lambda: lib)
     monkeypatch.setattr(hip, 'ptr', lambda t: None if t is None else ctypes.c_void_p(t.data_ptr()))
     monkeypatch.setattr(hip, 'stream_ptr', lambda: None)
-    monkeypatch.setattr(hip, 'conv2d', lambda d: log.append(('conv', bool(d.offset), d.ksplit, d.gn_stats, d.gn_cpg, d.gn_rep, d.cout)))
+    monkeypatch.setattr(hip, 'conv2d', lambda d: log.append(('conv', bool(d.offset), d.ksplit, d.gn_stats, d.gn_cpg, d.gn_rep, d.cout, d.tile_n, d.N * d.Ho * d.Wo)))
     monkeypatch.setattr(_RecordingLib, '_vps_groupnorm_apply', lambda self, *a: log.append(('apply', a[-3].value, a[-2])) or 0, raising=False)
     monkeypatch.setattr(_RecordingLib, '_vps_groupnorm_relu', lambda self, *a: log.append(('relu', a[-2].value)) or 0, raising=False)
     monkeypatch.setattr(nhwc, 'DEFAULT_PREC', nhwc.PREC_NAMES[prec])
@@ -177,10 +177,13 @@ def test_semantic_head_hands_groupnorm_sums_to_the_unsplit_deformable_layers(mon
     levels = [nhwc.FMap(torch.zeros(1, 128 >> l, 256 >> l, 256)) for l in range(4)]       # P2 128x256 (256 tiles x 2: unsplit) ... P5 16x32
     head.run(levels, ws)
     dcn = [(i, e) for i, e in enumerate(log) if e[0] == 'conv' and e[1]]
-    assert len(dcn) == 12
+    assert len(dcn) == 12 and any(e[7] == 256 for _, e in dcn) == (prec == 'f16x3')
     slots = set()
-    for i, (_, _, ksplit, gn_stats, gn_cpg, gn_rep, cout) in dcn:
+    for i, (_, _, ksplit, gn_stats, gn_cpg, gn_rep, cout, tile_n, M) in dcn:
         nxt = log[i + 1]
+        # 256 output channels on >= 256 pixel tiles: the 128 x 256 block of the split-fp16 mode (nhwc.DCN256); the exact mode and the
+        # 128-channel layers keep the 128-column tile
+        assert tile_n == (256 if (prec == 'f16x3' and cout == 256 and (M + 127) // 128 >= 256) else 128), (cout, M, tile_n)
         if expect_fused and ksplit == 1:
             assert gn_stats and gn_cpg == cout // 32 and gn_rep == nhwc.GN_REP
             assert nxt[0] == 'apply' and nxt[1] == gn_stats and nxt[2] == nhwc.GN_REP
