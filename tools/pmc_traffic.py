@@ -8,7 +8,9 @@
 (separate passes, no other trace domain: MI355X_MICROARCH.md "HBM" / "rocprofv3 PMC slots"). FETCH_SIZE / WRITE_SIZE are
 in KiB; on gfx950 FETCH_SIZE counts 128-byte requests of wide (16 B/lane) coalesced reads as 64 bytes, so it is doubled
 (all loads of the conv kernels are global_load_dwordx4 / buffer_load_dwordx4); WRITE_SIZE is taken as reported (uncalibrated, see the guide).
-The third argument is the number of frames the profiled command ran (warmup + steps + 1 instrumented frame)."""
+The third argument is the number of frames the profiled command ran: warmup + steps + the 2 set-up frames and the 3 instrumented
+frames of bench.py's single-stream section (7 for `--steps 1 --warmup 1`; 5 up to round 5's committed measurement, which ran one
+instrumented frame)."""
 import csv
 import glob
 import json

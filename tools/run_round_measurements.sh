@@ -28,11 +28,12 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -o pmc -- python $R/bench.py --steps 1 --warmup 1 --single-stream --no-cpu-baseline --no-extras --conv-table $R/gpurun_out/conv_table_pmc.txt > /dev/null 2> $R/gpurun_out/pmc_fetch.err
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -o pmc -- python $R/bench.py --steps 1 --warmup 1 --single-stream --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/pmc_write.err
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_mfma -o pmc -- python $R/bench.py --steps 1 --warmup 1 --single-stream --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/pmc_mfma.err
+# (7 = frames of that command: 1 warm-up + 1 timed + 2 set-up frames + bench.py's 3 instrumented frames)
 # occupancy of the timed frames (three streams): union and sum of the kernel intervals per frame interval, steady state only
 timeout 400 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/trace.err
 cd $R
 timeout 120 python tools/trace_gaps.py gpurun_out/trace --out gpurun_out/${T}_frame_occupancy_traced.json
-timeout 120 python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 5 > gpurun_out/${T}_pmc_traffic_f16x3.json 2> gpurun_out/pmc_traffic.err
+timeout 120 python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 7 > gpurun_out/${T}_pmc_traffic_f16x3.json 2> gpurun_out/pmc_traffic.err
 timeout 120 python tools/pmc_mfma.py gpurun_out/pmc_mfma > gpurun_out/${T}_pmc_mfma_busy_f16x3.json 2> gpurun_out/pmc_mfma_tool.err
 timeout 120 python tools/pmc_per_layer.py gpurun_out/conv_table_pmc.txt.ordered.json gpurun_out/pmc_fetch gpurun_out/pmc_write > gpurun_out/${T}_traffic_per_layer_f16x3.txt 2>> gpurun_out/pmc_traffic.err
 cp $(find gpurun_out/prof_ss -name "*kernel_stats.csv" | head -1) gpurun_out/${T}_fusetrack_kernel_stats_single_stream_f16x3.csv
