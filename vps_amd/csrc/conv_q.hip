@@ -298,10 +298,14 @@ void conv_mfma_bf16q_kernel(const vps_conv_desc d, const int M, const int tiles_
 
 }  // namespace
 
+int vpsi_launch_conv_pw(const vps_conv_desc& d, int M, int tiles_m, int tiles_n, hipStream_t s);
+
 // -> 1 if a uniform-lead instance exists for this launch and was enqueued, 0 if the caller has to use another kernel
 __attribute__((visibility("hidden")))
 int vpsi_launch_conv_q(const vps_conv_desc& d_in, int M, int tiles_m, int tiles_n, int per_split, long nblk, bool tapmajor, hipStream_t s) {
     const vps_conv_desc& d = d_in;
+    // 1x1 layers with at least two rounds of resident blocks: the persistent pointwise kernel (conv_pw.hip)
+    if (!tapmajor && vpsi_launch_conv_pw(d, M, tiles_m, tiles_n, s)) return 1;
     // VPS_UNIFORM_LEAD in the environment (A/B runs): bit 0 = chunk-major layers (default on), bit 1 = tap-major layers (default off:
     // the thin first layers measured 12 .. 23 % slower here than on the pipelined kernel - 3 .. 7 k-steps per tile, the longer prologue
     // is not paid back)
