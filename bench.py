@@ -392,23 +392,55 @@ def main():
         del m2, r2
         torch.cuda.empty_cache()
 
-    # ---- untimed: what an UNMODIFIED tools/test_vpq.py:41-63 loop gets: one model(...) call per frame, no `prefetch=`, the two maps
-    # and the instance vectors fetched to the host after every frame -------------------------------------------------------------
+    # ---- untimed: what the UNMODIFIED tools/test_vpq.py:41-63 loop gets after the import switch of INTEGRATION.md Level 1 (build_detector,
+    # build_dataloader and MMDataParallel from vps_amd): one model(...) call per frame over a data loader, the two maps and the instance
+    # vectors fetched to the host after every frame. The loader stand-in yields the reference's test batches (img / img_meta in a
+    # cpu_only DataContainer / ref_img, ref_img a tensor of its own like cityscapes_vps.py:137-148 loads it); vps_amd.LookaheadLoader
+    # keeps two batches ahead and announces them to the detector (round 6). `no_lookahead`: the same loop over the bare loader (round 5).
     plain = None
     if rank == 0 and not args.no_extras and args.variant == 'fusetrack':
-        reset()
-        for t in range(3):
-            plain_step(t, 7)
-        torch.cuda.synchronize()
-        c0 = time.perf_counter()
+        import vps_amd as _va
         nfr = 20
-        for t in range(3, 3 + nfr):
-            r = plain_step(t, 7)
-            r[2]['fcn_outputs'].cpu(); r[2]['panoptic_outputs'].cpu(); r[2]['panoptic_cls_inds'].cpu(); r[2]['panoptic_det_obj_ids'].cpu()
-        c1 = time.perf_counter() - c0
+
+        class _Loader:
+            dataset = list(range(3 + nfr))
+
+            def __init__(self, lo, hi, vid):
+                self.lo, self.hi, self.vid = lo, hi, vid
+
+            def __len__(self):
+                return self.hi - self.lo
+
+            def __iter__(self):
+                for t in range(self.lo, self.hi):
+                    img = load_frame(t)
+                    ref = (load_frame(t - 1) if t else img).clone()         # the dataset loads the reference frame again: another tensor
+                    yield dict(img=[img], img_meta=[_va.DataContainer([[synth.img_meta(Hh, Ww, 10000 * self.vid + t + 1)]], cpu_only=True)], ref_img=[ref])
+
+        def vpq_loop(loader):
+            n = 0
+            for data in loader:                                             # tools/test_vpq.py:41-63
+                with torch.no_grad():
+                    r = wrapped(return_loss=False, rescale=True, **data)
+                r[2]['fcn_outputs'].cpu(); r[2]['panoptic_outputs'].cpu(); r[2]['panoptic_cls_inds'].cpu(); r[2]['panoptic_det_obj_ids'].cpu()
+                n += 1
+            return n
+        wrapped = _va.MMDataParallel(model, device_ids=[dev.index or 0])
+        res = {}
+        for name, wrap in (('lookahead', lambda l: _va.LookaheadLoader(l, depth=2, device=dev)), ('no_lookahead', lambda l: l)):
+            reset()
+            vpq_loop(wrap(_Loader(0, 3, 7)))
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            vpq_loop(wrap(_Loader(3, 3 + nfr, 7)))
+            torch.cuda.synchronize()
+            res[name] = time.perf_counter() - c0
+        c1 = res['lookahead']
         plain = dict(frames=nfr, frames_per_s=round(nfr / c1, 3), ms_per_frame=round(1e3 * c1 / nfr, 3),
-                     note='per-frame model(...) calls as tools/test_vpq.py:41-63 makes them (no prefetch hint), D2H of the two uint8 maps and '
-                          'the instance vectors after every frame; 1 mid-frame + 1 end-of-frame host read inside the detector')
+                     no_lookahead_frames_per_s=round(nfr / res['no_lookahead'], 3),
+                     note='per-frame model(...) calls as tools/test_vpq.py:41-63 makes them, over vps_amd.LookaheadLoader + vps_amd.MMDataParallel '
+                          '(the import switch of INTEGRATION.md Level 1: the loader announces the next two frames to the detector), D2H of the two '
+                          'uint8 maps and the instance vectors after every frame; no_lookahead: the same loop over the bare loader')
         reset()
 
     # ---- untimed: the same clip pipeline fed from PNG FILES: vps_amd.pipeline.ClipFeeder decodes with a pool of host

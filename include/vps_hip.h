@@ -303,8 +303,10 @@ int vps_mask_removal(const float* logits, int S, const int32_t* boxes, const int
 /* the same loop in ONE launch with one workgroup PER BOX of the score-sorted walk (round 5): a box finds the earlier same-class boxes
  * whose rectangles intersect its own, waits (bounded) until each has published its decision, then counts, decides (flags[i]) and
  * commits - independent boxes run side by side, dependent ones back to back without a launch in between. Arguments as above
- * (n <= 256, W % 4 == 0, occ 4-byte aligned; occ and `done` [n] are zeroed by the call). status: bit 2 (value 4) is OR-ed in when a
- * wait expired (never expected: boxes wait for lower workgroup indices only) - the caller must treat the frame as failed. */
+ * (n <= 256, 2 <= S <= 32, W % 4 == 0, occ 4-byte aligned; occ and `done` [n] are zeroed by the call). status: bit 2 (value 4) is OR-ed in
+ * when a wait expired (boxes wait for lower workgroup indices only, but HIP promises neither dispatch order nor progress): the flags of
+ * that call are not valid - the caller repeats the walk with vps_mask_level (vps_amd/detector.py does, counted in
+ * panoptic_ops.MR_RECOVERIES). VPS_MR_SPIN_LIMIT in the environment overrides the number of polls per dependency (tests). */
 int vps_mask_removal_dep(const float* logits, int S, const int32_t* boxes, const int32_t* cls0, const int32_t* mask_idx,
                          int n, int ncls, int H, int W, uint8_t* occ, double thr, int32_t* flags, int32_t* done,
                          int32_t* status, void* stream);

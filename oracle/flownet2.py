@@ -128,6 +128,27 @@ def flownetfusion(sd, p, x):
     return _pred(sd, p + 'predict_flow0', _iconv(sd, p + 'inter_conv0', cat0))
 
 
+def flow_input(img, ref_img, mean, std, rgb_max=255.0):
+    """The 6-channel tensor FlowNetC / FlowNetSD see, from the detector's normalised frames:
+    utils/flow_utils.py:5-10 `denormalize` (x * std + mean per channel, both frames), panoptic_fusetrack.py:119-128 (stack, zero pad
+    bottom / right of the two special sizes - in 0..255 RGB space, i.e. BEFORE the mean is taken), flow_modules/flownet2.py:135-139
+    (mean over both frames and all padded pixels, / rgb_max, frames concatenated along the channels). -> [B, 6, Hp, Wp]"""
+    def denorm(t):
+        t = t.clone()
+        for c in range(3):
+            t[:, c] = t[:, c] * std[c] + mean[c]
+        return t
+    rgbs = torch.stack([denorm(img), denorm(ref_img)], dim=2)
+    H, W = rgbs.size(-2), rgbs.size(-1)
+    if H == 800 and W == 1600:
+        rgbs = F.pad(rgbs, (0, 64, 0, 32))
+    elif H == 200 and W == 400:
+        rgbs = F.pad(rgbs, (0, 48, 0, 56))
+    rgb_mean = rgbs.contiguous().view(rgbs.shape[:2] + (-1,)).mean(dim=-1).view(rgbs.shape[:2] + (1, 1, 1))
+    x = (rgbs - rgb_mean) / rgb_max
+    return torch.cat((x[:, :, 0], x[:, :, 1]), dim=1)
+
+
 def flownet2(sd, p, inputs, rgb_max=255.0, div_flow=20.0, return_stages=False):
     """flownet2.py:133-198. inputs [B,3,2,H,W] RGB 0..255."""
     b = inputs.shape[0]

@@ -27,6 +27,10 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(lib, s), 'libvpship.so does not export %s' % s
     assert sorted(hip.SYMBOLS) == declared
+    # every entry point has its ctypes signature (a call through ctypes' default conversions truncates 64-bit arguments)
+    for s in hip.SYMBOLS:
+        f = getattr(lib, s)
+        assert f.argtypes is not None or s in ('vps_abi_version', 'vps_build_info'), '%s has no argtypes in vps_amd/hip.py' % s
 
 
 def test_abi_version_and_info():

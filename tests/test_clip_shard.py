@@ -298,6 +298,8 @@ def _worker_chain(rank, world, port, q, nframes, cap=None):
         # rank 0 never holds more posted receives per peer than its window (memory cap / bytes per frame / peers, at least recv_window)
         per_frame = 4 * runner._layout()[2] + 2 * cb.Hm * cb.Wm
         assert 1 <= runner.max_posted <= max(runner.recv_window, runner.recv_bytes_cap // (per_frame * (world - 1))), runner.max_posted
+        # ... and posted buffers + early-unpacked records TOGETHER stay inside the cap, up to the guaranteed minimum window
+        assert runner.max_held <= max(runner.recv_bytes_cap // per_frame, 1) + runner.recv_window * (world - 1), (runner.max_held, per_frame)
     assert (cb.primed is not None) == (rank > 0 and e > s), (rank, cb.primed is not None)      # later shards announce their first frame
     # every frame of the shard (and the reference of its first frame) is loaded exactly once
     assert sorted(loads) == list(range(max(s - 1, 0), e)) if e > s else loads == [], (rank, loads)

@@ -168,7 +168,8 @@ def _ref_caller_main():
                 yield dict(img=[frames[t]], img_meta=[DataContainer([[meta]], cpu_only=True)], ref_img=[frames[t - 1 if t else 0]])
 
     wrapped = ref.MMDataParallel(model, device_ids=[0], to_device=lambda t: t.as_subclass(_FakeCuda))      # test_vpq.py:149
-    results, pano = ref.single_gpu_test(wrapped, Loader())                                                # test_vpq.py:28-69
+    # (the loader wrapped the way vps_amd.build_dataloader does it: the reference's loop iterates the look-ahead loader unchanged)
+    results, pano = ref.single_gpu_test(wrapped, vps_amd.LookaheadLoader(Loader(), depth=2, device=None))       # test_vpq.py:28-69
     assert len(results) == 3 and all(len(r) == 2 for r in results)
     assert pano['all_names'] == ['0000_%04d_frankfurt_000000_%06d_newImg8bit.png' % (t, t) for t in range(3)]
     for k in ('all_ssegs', 'all_panos'):

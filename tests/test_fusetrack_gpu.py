@@ -191,7 +191,7 @@ def test_operator_api_matches_reference_signatures(setup):
     flow, _ = m.compute_flow(fr[1].to(dev), fr[0].to(dev), scale_factor=0.25)
     with torch.no_grad():
         rf = o.compute_flow(fr[1], fr[0], 0.25)
-    assert _relmax(flow.cpu(), rf) < 2e-3
+    assert _relmax(flow.cpu(), rf) < 2 * T.STAGE['flow']
 
 
 def test_cached_reference_features_are_only_used_for_the_previous_frame(setup):
@@ -228,9 +228,9 @@ def test_compute_flow_pads_and_trims_like_the_reference(setup):
         full = o.last_flow_full
     flow, _ = m.compute_flow(fr[1].to(dev), fr[0].to(dev), scale_factor=0.25)
     assert tuple(flow.shape) == (1, 2, 50, 100) == tuple(ref.shape) and tuple(full.shape) == (1, 2, 200, 400)
-    assert _relmax(flow.cpu(), ref) < 2e-3
+    assert _relmax(flow.cpu(), ref) < 2 * T.STAGE['flow']
     flow1, _ = m.compute_flow(fr[1].to(dev), fr[0].to(dev))
-    assert _relmax(flow1.cpu(), full) < 2e-3
+    assert _relmax(flow1.cpu(), full) < 2 * T.STAGE['flow']
     with pytest.raises(AssertionError):
         m.compute_flow(fr[1][..., :200, :336].to(dev), fr[0][..., :200, :336].to(dev))      # 200x336: not a special case, not /64
 
@@ -297,6 +297,41 @@ def test_image_stage_stream_fan_out_is_bitwise_the_single_prefetch_stream(setup)
         for t in range(len(frd)):
             for k in runs[0][t]:
                 assert np.array_equal(runs[0][t][k], r[t][k]), (t, k)
+
+
+def test_unmatched_announcements_do_not_overwrite_the_cached_reference_feature(setup):
+    """a caller that announces tensors it then does NOT pass (it re-uploads per call: here the announced pair is a clone)
+    makes every call enqueue its own frame, the announced next frame and the one after - three ring slots in one call, while the
+    slot of frame t-1 still holds the cached reference feature neck(t) reads. The slot chooser must leave that slot (and the slots
+    of records still to be consumed) alone - the ring grows instead - and the outputs must be bitwise the serial schedule's."""
+    m, fr, dev = setup['model'], setup['frames'], setup['dev']
+    H, W, n = setup['H'], setup['W'], setup['n']
+    nf = 7
+    frd = [fr[t % n].to(dev).clone() for t in range(nf)]
+
+    def run(announce):
+        m._cache = None; m._pf = None; m.reset_tracker()
+        outs = []
+        for t in range(nf):
+            pf = None
+            if announce:
+                # the next two frames, as tensors the following calls will NOT be made with
+                pf = [(frd[min(t + 1 + j, nf - 1)].clone(), frd[min(t + j, nf - 1)].clone()) for j in range(2)]
+            out = m.simple_test(frd[t], [synth.img_meta(H, W, 10000 + t + 1)], ref_img=[frd[t - 1 if t else 0]], prefetch=pf)
+            outs.append({k: v.cpu().numpy().copy() for k, v in out[2].items()})
+        torch.cuda.synchronize()
+        return outs
+
+    serial = run(False)
+    assert m._ring is not None and len(m._ring) == 3
+    noisy = run(True)
+    for t in range(nf):
+        for k in ('panoptic_det_obj_ids', 'panoptic_outputs', 'fcn_outputs', 'panoptic_cls_prob'):
+            assert np.array_equal(serial[t][k], noisy[t][k]), (t, k)
+    # every record that is waiting names a slot of its own, none of them the cached feature's
+    slots = [r['slot'] for r in (m._pf or [])] + [m._cache['slot']]
+    assert len(set(slots)) == len(slots), slots
+    m._cache = None; m._pf = None; m._ws = None; m.reset_tracker()          # fresh (three-slot) workspaces for the tests that follow
 
 
 def test_pooled_workspace_is_bitwise_the_buffer_per_activation_workspace(setup):

@@ -336,3 +336,25 @@ def test_config5_oracle_matches_reference():
             pan = r['panoptic_outputs'].numpy().astype(np.uint8)[..., ::ms, ::ms]; sem = r['fcn_outputs'].numpy().astype(np.uint8)[..., ::ms, ::ms]
             assert (pan != g[p + 'panoptic_outputs']).mean() < 1e-4
             assert (sem != g[p + 'fcn_outputs']).mean() < 1e-4
+
+
+@pytest.mark.parametrize('case', ['plain', 'pad200', 'pad800'])
+def test_flow_input_restatement_against_the_real_compute_flow(case):
+    """SURVEY 8(a) row a1 in isolation: oracle.flownet2.flow_input (denormalize x2 + zero pad + FlowNet2's input normalisation) against
+    the tensor the REAL `compute_flow` / `FlowNet2.forward` hand to flownetc (tests/golden/make_flow_prep_golden.py: captured by a hook
+    on the reference module). Same fp32 operations in the same order -> equal to rounding (1e-6 of a value range of +-0.5)."""
+    from oracle.flownet2 import flow_input
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD)))
+    from make_flow_prep_golden import sample_index
+    g = np.load(os.path.join(os.path.dirname(GOLD), 'flow_prep.npz'))
+    H, W, Hp, Wp = [int(v) for v in g[case + '.shape']]
+    fr = synth.synth_clip(H, W, 2, int(g['seed'][0]))
+    cfg = vps_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'cityscapes', 'fusetrack.py'))
+    norm = cfg.img_norm_cfg
+    x = flow_input(fr[1], fr[0], norm['mean'], norm['std'])[0].numpy()
+    assert x.shape == (6, Hp, Wp)
+    ri, ci = sample_index(H, Hp), sample_index(W, Wp)
+    assert np.abs(x[:, ri][:, :, ci] - g[case + '.sample']).max() < 1e-6
+    if (Hp, Wp) != (H, W):
+        assert np.ptp(x[:, H:, :].reshape(6, -1), axis=1).max() == 0        # the pad is a constant (0 - mean) / 255

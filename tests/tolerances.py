@@ -7,26 +7,28 @@ fp32-grade arithmetic mode (f32, bf16x6, f16x3). Measured values: profiles/r0[34
   stage                     tolerance   measured (ResNet-50)     why it is what it is
   flow (FlowNet2, full res)   5e-5      1.5e-6 .. 7.1e-6         5 networks, 60 convolutions: plain summation-order noise
   FPN levels P2..P6           5e-5      1.0e-6 .. 2.9e-6         (same for ResNet-101)
-  fusion-neck outputs         2e-3      2.1e-5 .. 4.5e-4         the TCEA fusion is ill-conditioned on the synthetic weights: the fp32 ORACLE
+  fusion-neck outputs         1e-3      2.1e-5 .. 5.3e-4         the TCEA fusion is ill-conditioned on the synthetic weights: the fp32 ORACLE
                                                                  itself is 1.9e-4 (1024x2048) from its float64 evaluation at this stage
                                                                  (tools/neck_isolation.py, profiles/r05_neck_*), everything behind inherits it
-  semantic logits fcn_score   2e-3      6.2e-5 .. 7.5e-4
-  cls_score / bbox_pred       2e-3      5.0e-5 .. 9e-4
-  detection scores            2e-3      <= 9e-4 (absolute: they are probabilities)
-  ResNet-101 (config 5): the stages BEHIND the FPN x5 (1e-2): the 101-layer synthetic network amplifies the same fp32 noise ~5x, in the
+  semantic logits fcn_score   1e-3      6.2e-5 .. 7.5e-4
+  cls_score / bbox_pred       1.5e-3    5.0e-5 .. 9e-4
+  detection scores            2e-3      <= 1.54e-3 on the dense fixture (absolute: they are probabilities behind a softmax)
+  (round 6: 2e-3 -> 1e-3 for the neck and the semantic logits, 1.5e-3 for the box-head logits - the gate had 4x slack over the measured
+  worst case and would not have caught a 2x regression; the scores stay: 1.54e-3 is measured, in every mode)
+  ResNet-101 (config 5), the stages BEHIND the FPN: neck 5e-3, fcn_score 9e-3, the rest 1e-2 (was 1e-2 throughout): the 101-layer
+  synthetic network amplifies the same fp32 noise ~5x, in the
   exact-fp32 kernels as much as in the split modes (neck 8.7e-4 .. 4.3e-3, fcn_score 2.5e-3 .. 8.0e-3, scores 4 .. 6e-3)
 
 Maps (fraction of differing pixels): semantic 1e-3; panoptic 1e-3, except the two fixtures whose margins cover every LISTING decision but
 not which source proposal stands behind a detection - a boundary strip of single instances differs there in every mode, the exact-fp32
 kernels included: dense 5e-3 (measured <= 2.6e-3), config5 1e-2 (measured <= 6e-3)."""
 
-STAGE = dict(flow=5e-5, fpn=5e-5, neck=2e-3, fcn_score=2e-3, cls_score=2e-3, bbox_pred=2e-3, score=2e-3)
-R101_FACTOR = 5.0                         # applied to the stages behind the FPN of the 101-layer model
+STAGE = dict(flow=5e-5, fpn=5e-5, neck=1e-3, fcn_score=1e-3, cls_score=1.5e-3, bbox_pred=1.5e-3, score=2e-3)
+STAGE_R101 = dict(neck=5e-3, fcn_score=9e-3, cls_score=1e-2, bbox_pred=1e-2, score=1e-2)      # the stages behind the FPN of the 101-layer model
 MAP = dict(sem=1e-3, pan=1e-3, pan_dense=5e-3, pan_config5=1e-2)
 
 
 def stage_tol(name, depth=50):
     """tolerance of a stage tensor by the name the tests report it under (flow, fpn_p2, neck_p6, fcn_score, cls_score, ...)"""
     key = name.split('_p')[0] if name.startswith(('fpn', 'neck')) else name
-    tol = STAGE[key]
-    return tol * R101_FACTOR if depth > 50 and key not in ('flow', 'fpn') else tol
+    return STAGE_R101[key] if depth > 50 and key in STAGE_R101 else STAGE[key]

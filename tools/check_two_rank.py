@@ -4,11 +4,16 @@
         tools/check_two_rank.py [--height 128 --width 256 --frames 6] [--separated]
 
 Two processes (sharing the GPU when the box has one: gloo, NOT RCCL) run ClipShardRunner over a synthetic clip; rank 0 then runs
-the same clip sequentially in one process and compares every frame: track ids, classes, both maps. Exit code 1 on a difference.
+the same clip sequentially in one process and compares every frame: track ids, classes, scores, both maps (array_equal) and the feature
+rank 1 received at the shard boundary against gathered_feature(last frame of rank 0) (bitwise). Exit code 1 on a difference.
+  --withhold R   rank R computes nothing and sends nothing (a stalled peer): the ranks that wait for it must give up after
+                 VPS_CLIP_TIMEOUT_S seconds with ONE JSON line {"error": ...} on stdout and exit code 3 - not hang (tests/test_two_rank_gpu.py)
 """
 import argparse
+import json
 import os
 import sys
+import time
 
 import numpy as np
 import torch
@@ -24,6 +29,7 @@ def main():
     ap.add_argument('--frames', type=int, default=6)
     ap.add_argument('--prec', default='f16x3')
     ap.add_argument('--separated', action='store_true')
+    ap.add_argument('--withhold', type=int, default=-1)
     args = ap.parse_args()
     import torch.distributed as dist
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
@@ -46,11 +52,30 @@ def main():
     synth.load_synth(model, 0, overrides=over)
     frames = [f.to(dev) for f in synth.synth_clip(H, W, n, 0)]
     runner = ClipShardRunner(DetectorBackend(model, H, W), rank, world, dist, dev)
-    outs = runner.run(lambda t: frames[t], n, video_id=1)
+    if rank == args.withhold:
+        time.sleep(3 * runner.wait_timeout_s + 30)           # a stalled peer: alive, silent (the launcher ends it when another rank fails)
+        sys.exit(4)
+    from vps_amd.clip_shard import ClipShardError, partition
+    try:
+        outs = runner.run(lambda t: frames[t], n, video_id=1)
+    except ClipShardError as ex:
+        print(json.dumps({'error': str(ex), 'rank': rank, 'world': world}), flush=True)
+        os._exit(3)                                          # no collective teardown with a peer that does not answer
     torch.cuda.synchronize()
+    # the feature every later rank received at its shard boundary -> rank 0 (gathered on the host side of the check, not the data path)
+    got = [None] * world
+    dist.all_gather_object(got, runner.last_ref_feature.cpu() if rank > 0 and getattr(runner, 'last_ref_feature', None) is not None else None)
     dist.barrier()
     bad = 0
     if rank == 0:
+        parts = partition(n, world)
+        for r in range(1, world):
+            if got[r] is None:
+                continue
+            want = model.gathered_feature(frames[parts[r][0] - 1]).cpu()
+            same = bool(torch.equal(want.reshape(-1), got[r].reshape(-1)))
+            print('hand-off feature rank %d -> %d (frame %d, %.1f MB): %s' % (r - 1, r, parts[r][0] - 1, want.numel() * 4 / 1e6, 'bitwise equal' if same else 'DIFFERENT'), flush=True)
+            bad += not same
         model._cache = None; model._pf = None; model._handoff = None; model.reset_tracker()
         for t in range(n):
             out = model(return_loss=False, rescale=True, img=[frames[t]], img_meta=[[synth.img_meta(H, W, 10000 + t + 1)]],

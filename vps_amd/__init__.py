@@ -12,5 +12,6 @@ from .registry import (BACKBONES, DETECTORS, EXTRA_NECKS, HEADS, NECKS, PANOPTIC
 from . import backbones, necks, heads, flownet2, panoptic_ops, detector  # noqa: F401,E402  (registration side effects)
 from .detector import PanopticFuse, PanopticFuseTrack, PanopticTrack  # noqa: F401,E402
 from .checkpoint import load_checkpoint  # noqa: F401,E402
+from .dataloader import DataContainer, LookaheadLoader, MMDataParallel, build_dataloader  # noqa: F401,E402
 
 __version__ = '0.1.0'

@@ -42,6 +42,10 @@ def partition(nframes, world):
     return out
 
 
+class ClipShardError(RuntimeError):
+    """a peer of the clip pipeline did not deliver (died, stalled) - raised instead of waiting forever"""
+
+
 class ClipShardRunner:
     """Streams the clip: every rank works through its contiguous shard; a finished frame's detection record (ONE fixed-layout fp32
     tensor) and its two maps (ONE uint8 tensor) go to rank 0 point-to-point as soon as the frame is done; rank 0 assigns the
@@ -49,6 +53,9 @@ class ClipShardRunner:
     receives up front) — and assembles the outputs. No object collectives, no pickling, no barrier between "compute" and
     "replay": the only serial work is the tracker step itself (two small kernels per frame)."""
 
+    # seconds a rank waits for ONE point-to-point operation of a peer (hand-off feature, a frame's record) before it gives up with a
+    # ClipShardError naming the peer and the frame - a peer that died or stalled must end the clip with an error, not hang the node
+    wait_timeout_s = float(os.environ.get('VPS_CLIP_TIMEOUT_S', '600'))
     recv_window = 3        # positions per peer whose receives rank 0 keeps posted, at least (see `_window`)
     recv_bytes_cap = 2 << 30      # memory rank 0 may hold in posted receive buffers + early-unpacked records of the other ranks
 
@@ -56,6 +63,15 @@ class ClipShardRunner:
         self.backend, self.rank, self.world, self.dist = backend, rank, world, dist
         self.device = device
         self.track_keys = track_keys
+
+    def _wait(self, q, what):
+        """wait for one posted point-to-point operation, bounded by `wait_timeout_s`"""
+        import datetime
+        try:
+            q.wait(datetime.timedelta(seconds=self.wait_timeout_s))
+        except Exception as ex:           # gloo / RCCL raise RuntimeError (timeout, connection closed by a dead peer)
+            raise ClipShardError('rank %d: %s did not complete within %.0f s (%s: %s)' % (
+                self.rank, what, self.wait_timeout_s, type(ex).__name__, str(ex).splitlines()[0][:200] if str(ex) else '')) from ex
 
     # ---- fixed record layout: [K, k, keep_inds[cap], per-instance vectors [cap] x3, then the tracker columns [cap, width] ...]
     VEC_KEYS = ('panoptic_cls_inds', 'panoptic_cls_prob', 'panoptic_det_labels')
@@ -174,23 +190,32 @@ class ClipShardRunner:
             # shard that fits is posted completely (no send of a peer ever waits for its receive: an unmatched RCCL send spins on CUs
             # of the sender beside its compute); a longer one is topped up while rank 0 works through its own shard (step 3) and in step 4
             per_frame = 4 * n + 2 * Hm * Wm
-            window = max(self.recv_window, int(self.recv_bytes_cap // (per_frame * max(world - 1, 1))))
+            # `recv_bytes_cap` bounds what rank 0 holds for the other shards ALTOGETHER: posted receive buffers plus the records that
+            # were unpacked early into the stash (the two used to be budgeted separately, i.e. up to twice the cap). Each
+            # peer keeps at least `recv_window` positions posted whatever the cap says (its sends complete in order: progress).
+            budget = max(int(self.recv_bytes_cap // per_frame), 1)
+            window = max(self.recv_window, budget // max(world - 1, 1))
             posted = {r: 0 for r in range(1, world)}          # positions posted so far, per peer
             taken = {r: 0 for r in range(1, world)}           # positions unpacked so far, per peer
             self.max_posted = 0
+            self.max_held = 0                                  # posted + stashed frames, high-water mark (tests)
+            held = lambda: sum(posted[r] - taken[r] for r in posted) + len(stash)
 
             def fill():
                 # round robin over the peers, lowest position first: on RCCL a rank's point-to-point operations run in posting order
                 more = True
                 while more:
                     more = False
-                    lo = min((posted[r] for r in posted if posted[r] < parts[r][1] - parts[r][0] and posted[r] - taken[r] < window), default=None)
+                    ok = lambda r: (posted[r] < parts[r][1] - parts[r][0] and posted[r] - taken[r] < window and
+                                    (held() < budget or posted[r] - taken[r] < self.recv_window))
+                    lo = min((posted[r] for r in posted if ok(r)), default=None)
                     for r in range(1, world):
-                        if posted[r] == lo and lo < parts[r][1] - parts[r][0] and lo - taken[r] < window:
+                        if posted[r] == lo and ok(r):
                             post_recv(r, lo)
                             posted[r] = lo + 1
                             more = True
                 self.max_posted = max(self.max_posted, max(posted[r] - taken[r] for r in posted))
+                self.max_held = max(self.max_held, held())
             fill()
         # 3) this rank's frames
         outs, sent = [], []
@@ -202,9 +227,10 @@ class ClipShardRunner:
             ref_feature = None
             if t == s and rank > 0:
                 for rq in reqs:
-                    rq.wait()
+                    self._wait(rq, 'the feature hand-off with rank %d / %d (frame %d)' % (rank - 1, rank + 1, s - 1))
                 reqs = []
                 ref_feature = recv_buf
+                self.last_ref_feature = recv_buf        # (tests compare it with the sender's gathered feature)
             if getattr(be, 'supports_prefetch', False):
                 # the next frame of this shard is known: its image-only stages are enqueued behind this frame's (detector.simple_test)
                 nxt = load_frame(t + 1) if t + 1 < e else None
@@ -231,18 +257,20 @@ class ClipShardRunner:
                 # records that have arrived meanwhile are unpacked (copied out of the pooled buffers) and their buffers reposted, so a
                 # peer whose shard is longer than the window is never left with unmatched sends until step 4
                 for r in range(1, world):
-                    while taken[r] < posted[r] and len(stash) * per_frame < self.recv_bytes_cap:
+                    while taken[r] < posted[r]:
                         tt = parts[r][0] + taken[r]
                         buf, maps, rq = inbox[tt]
                         if not all(q.is_completed() for q in rq):
                             break
+                        for q in rq:
+                            self._wait(q, 'the record of frame %d from rank %d' % (tt, r))             # completed: returns at once, and orders the unpack behind the receive on every backend
                         inbox.pop(tt)
                         stash[tt] = self._unpack(buf, maps, tt)
                         pool.append((buf, maps))
                         taken[r] += 1
                 fill()
         for rq in reqs:
-            rq.wait()
+            self._wait(rq, 'the feature hand-off to rank %d' % (rank + 1))
         # 4) rank 0: the other shards' frames in clip order, each as soon as its record has arrived
         if rank == 0:
             for r in range(1, world):
@@ -253,7 +281,7 @@ class ClipShardRunner:
                     else:
                         buf, maps, rq = inbox.pop(t)
                         for q in rq:
-                            q.wait()
+                            self._wait(q, 'the record of frame %d from rank %d' % (t, r))
                         rec = self._unpack(buf, maps, t)       # copies everything it keeps: the buffers go back to the pool
                         pool.append((buf, maps))
                         taken[r] += 1
@@ -262,7 +290,7 @@ class ClipShardRunner:
             return outs
         for buf, maps, rq in sent:
             for q in rq:
-                q.wait()
+                self._wait(q, 'sending a frame record to rank 0')
         return []
 
 

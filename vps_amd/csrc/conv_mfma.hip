@@ -26,6 +26,8 @@
 
 int vpsi_launch_conv_q(const vps_conv_desc& d, int M, int tiles_m, int tiles_n, int per_split, long nblk, bool tapmajor, hipStream_t s);
 int vpsi_launch_conv_thin(const vps_conv_desc& d, hipStream_t s);
+void vpsi_launch_conv_h8(const vps_conv_desc& d, int tiles_m8, int tiles_n, int chunks_per_split, long nblk8, hipStream_t s);
+void vpsi_launch_conv_h8s2(const vps_conv_desc& d, int tiles_m8, int tiles_n, int chunks_per_split, long nblk8, int bn, hipStream_t s);
 
 
 namespace {
@@ -231,255 +233,6 @@ void conv_mfma_f32_kernel(const vps_conv_desc d, const int M, const int tiles_m,
     conv_epilogue<TM, TN, BN>(d, acc, M, tile_m, tile_n, cls, split, py, px, wm, wn, lane, (cls * tiles_m + tile_m) * tiles_n + tile_n);
 }
 
-template <int TM, int TN, int WAVES_M, int WAVES_N, int MODE, bool DEFORM>
-__global__ __launch_bounds__(256, 2)
-void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_m, const int tiles_n,
-                            const int ksteps_per_split) {
-    constexpr int BN = WAVES_N * TN * 32;
-    static_assert(WAVES_M * TM * 32 == BM, "block M tile must be 128");
-    static_assert(WAVES_M * WAVES_N == 4, "4 wavefronts per block");
-    constexpr int NBCH = (BN * 4 + 255) / 256;   // 16-byte weight chunks per thread per plane per k-step
-    typedef Split<MODE> SM;
-    typedef typename SM::elem elem_t;
-    typedef vec8<elem_t> x8;
-    typedef vec4<elem_t> x4;
-    constexpr int NSA = SM::NSA, NSB = SM::NSB;
-
-    __shared__ __attribute__((aligned(16))) elem_t As[NSA][BM * LDS_LDH];
-    __shared__ __attribute__((aligned(16))) elem_t Bs[NSB][BN * LDS_LDH];
-    // DEFORM: the bilinear sampling of (tile row, tap) - 4 corner weights, 4 clamped corner coordinates - depends on neither the
-    // channel chunk nor the column tile: computed ONCE per block into this table (24 bytes per entry) instead of once per k-step
-    // (~45 VALU instructions per staged row and step: more than the 24-48 MFMAs of a step leave room for).
-    constexpr int DTAP = 9;
-    __shared__ __attribute__((aligned(16))) float cw[DEFORM ? BM * DTAP * 4 : 4];
-    __shared__ __attribute__((aligned(8))) unsigned short cc[DEFORM ? BM * DTAP * 4 : 4];
-
-    const int t = threadIdx.x;
-    int swz = xcd_swizzle(blockIdx.x, gridDim.x);
-    int tile_n, tile_m, cls, split;
-    decode_tile(d, swz, tiles_n, tiles_m, tile_n, tile_m, cls, split);
-
-    const int py = cls / d.os_x, px = cls - py * d.os_x;
-    const int pad_y = d.pad_y[py], pad_x = d.pad_x[px];
-    const size_t plane = (size_t)d.nclass * d.cout_pad * d.kpad;   // elements per weight plane
-    const elem_t* __restrict__ wcls = reinterpret_cast<const elem_t*>(d.w_split) + (size_t)cls * d.cout_pad * d.kpad;
-
-    const int H = d.H, W = d.W, KH = d.KH, KW = d.KW, cin_pad = d.cin_pad;
-    const int k4 = t & 7;
-    const int r0 = t >> 3;
-
-    RowInfo ri[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = tile_m * BM + r0 + 32 * i;
-        if (m < M) {
-            const int qx = m % d.Qw;
-            const int tq = m / d.Qw;
-            const int qy = tq % d.Qh;
-            const int n = tq / d.Qh;
-            ri[i].iy0 = qy * d.stride - pad_y;
-            ri[i].ix0 = qx * d.stride - pad_x;
-            ri[i].pixbase = n * H * W;
-            ri[i].moff = m;
-        } else {
-            ri[i].iy0 = -(1 << 24);
-            ri[i].ix0 = 0;
-            ri[i].pixbase = 0;
-            ri[i].moff = -1;
-        }
-    }
-
-    const int kstep0 = split * ksteps_per_split;
-    int nsteps = d.kpad / BK - kstep0;
-    if (nsteps > ksteps_per_split) nsteps = ksteps_per_split;
-    // k ordering. korder 0 (tap-major): k = tap*cin_pad + ci. korder 1 (chunk-major): k = (chunk*ntap + tap)*32 + c with
-    // ci = chunk*32 + c: all taps of one 32-channel slab are consecutive k-steps, so the 9 (25, 49) shifted reads of the same
-    // 128-byte activation lines happen within a few steps of each other and hit L1/L2 instead of the Infinity Cache / HBM.
-    const int korder = d.korder, ntap = KH * KW;
-    int ky, kx, ci;
-    if (korder == 0) {
-        const int kk = kstep0 * BK + k4 * 4;
-        const int tap = kk / cin_pad;
-        ci = kk - tap * cin_pad;
-        ky = tap / KW;
-        kx = tap - ky * KW;
-    } else {
-        const int chunk = kstep0 / ntap, tap = kstep0 - chunk * ntap;
-        ci = chunk * BK + k4 * 4;
-        ky = tap / KW;
-        kx = tap - ky * KW;
-    }
-    // weight chunk of this thread: row bw_r (+64 per extra chunk), 8 bf16 starting at k = 8*bw_c
-    const int bw_c = t & 3, bw_r = t >> 2;
-    const elem_t* __restrict__ wrow = wcls + (size_t)(tile_n * BN + bw_r) * d.kpad + (size_t)kstep0 * BK + bw_c * 8;
-
-    f32x4 areg[4];
-    unsigned aok = 0;   // bit i: staged row i of the tile in flight is inside the image
-    x8 breg[NSB][NBCH];
-    float amax = 0.f;
-    f32x4 dcv[DEFORM ? 4 : 1][4];
-    float dcw[DEFORM ? 4 : 1][4];
-
-    auto load_tiles = [&](int step) {
-        const bool kval = ky < KH && ci < cin_pad;
-        if constexpr (!DEFORM) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                // branch-free: out-of-image taps read pixel 0 of the image (always mapped) and are zeroed when the tile is
-                // written to LDS, so the load is issued unconditionally and its wait sits at the consumer, one tile later
-                const int iy = ri[i].iy0 + ky, ix = ri[i].ix0 + kx;
-                const bool ok = kval && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                const int pix = ri[i].pixbase + (ok ? iy * W + ix : 0);
-                areg[i] = *reinterpret_cast<const f32x4*>(d.in + ((size_t)pix * d.in_ld + d.in_coff + (ok ? ci : 0)));
-                aok = (aok & ~(1u << i)) | ((ok ? 1u : 0u) << i);
-            }
-        } else {
-            const int tap = min(ky * KW + kx, DTAP - 1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                // table entry of (row, tap): all four float4 corner loads are always issued (clamped coordinates), the weights are
-                // zero where the reference zeroes the corner value or skips the sample, and beyond the last real k-step
-                const int e = ((r0 + 32 * i) * DTAP + tap) * 4;
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(&cw[e]);
-                const vec4<unsigned short> c4 = *reinterpret_cast<const vec4<unsigned short>*>(&cc[e]);
-                dcw[i][0] = kval ? w4[0] : 0.f; dcw[i][1] = kval ? w4[1] : 0.f; dcw[i][2] = kval ? w4[2] : 0.f; dcw[i][3] = kval ? w4[3] : 0.f;
-                const int hlc = c4[0], hhc = c4[1], wlc = c4[2], whc = c4[3];
-                const float* base = d.in + (size_t)ri[i].pixbase * d.in_ld + d.in_coff + (kval ? ci : 0);
-                dcv[i][0] = *reinterpret_cast<const f32x4*>(base + (size_t)(hlc * W + wlc) * d.in_ld);
-                dcv[i][1] = *reinterpret_cast<const f32x4*>(base + (size_t)(hlc * W + whc) * d.in_ld);
-                dcv[i][2] = *reinterpret_cast<const f32x4*>(base + (size_t)(hhc * W + wlc) * d.in_ld);
-                dcv[i][3] = *reinterpret_cast<const f32x4*>(base + (size_t)(hhc * W + whc) * d.in_ld);
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < NSB; ++p)
-#pragma unroll
-            for (int j = 0; j < NBCH; ++j)
-                if (BN * 4 >= 256 || t < BN * 4)
-                    breg[p][j] = *reinterpret_cast<const x8*>(wrow + (size_t)p * plane + (size_t)(64 * j) * d.kpad + (size_t)step * BK);
-        if (korder == 0) {
-            ci += BK;
-            while (ci >= cin_pad) {
-                ci -= cin_pad;
-                if (++kx == KW) { kx = 0; ++ky; }
-            }
-        } else if (++kx == KW) {
-            kx = 0;
-            if (++ky == KH) { ky = 0; ci += BK; }
-        }
-    };
-
-    auto store_tiles = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x4 v;
-            if constexpr (DEFORM) {
-                v = dcw[i][0] * dcv[i][0] + dcw[i][1] * dcv[i][1] + dcw[i][2] * dcv[i][2] + dcw[i][3] * dcv[i][3];
-            } else {
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                v = ((aok >> i) & 1u) ? areg[i] : z;
-            }
-            x4 sp[NSA];
-            split_act<MODE>(v, sp, amax);
-#pragma unroll
-            for (int p = 0; p < NSA; ++p)
-                *reinterpret_cast<x4*>(&As[p][(r0 + 32 * i) * LDS_LDH + (((k4 >> 1) ^ lds_swz(r0 + 32 * i)) << 3) + ((k4 & 1) << 2)]) = sp[p];
-        }
-#pragma unroll
-        for (int p = 0; p < NSB; ++p)
-#pragma unroll
-            for (int j = 0; j < NBCH; ++j)
-                if (BN * 4 >= 256 || t < BN * 4)
-                    *reinterpret_cast<x8*>(&Bs[p][(bw_r + 64 * j) * LDS_LDH + ((bw_c ^ lds_swz(bw_r + 64 * j)) << 3)]) = breg[p][j];
-    };
-
-    const int lane = t & 63, wave = t >> 6;
-    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
-    // fragment of slab m: logical 16-byte chunk 2m + (lane>>5) of row (lane&31), swizzled like the writes
-    const int frag_row = (lane & 31) * LDS_LDH;
-    const int frag_sw = lds_swz(lane & 31);
-    const int frag_chunk[2] = {(((lane >> 5)) ^ frag_sw) << 3, ((2 + (lane >> 5)) ^ frag_sw) << 3};
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    if constexpr (DEFORM) {
-        // deform_conv_cuda_kernel.cu:83-113,205-237: sample position = tap position + (dh, dw) of this output pixel; valid iff
-        // -1 < h < H and -1 < w < W; a corner outside the image contributes 0
-        for (int e = t; e < BM * DTAP; e += 256) {
-            const int row = e / DTAP, tap = e - row * DTAP;
-            const int m = tile_m * BM + row;
-            const bool act = m < M && tap < ntap;
-            const int mm = act ? m : 0;
-            const int qx = mm % d.Qw, tq = mm / d.Qw, qy = tq % d.Qh;
-            const int tky = tap / KW, tkx = tap - tky * KW;
-            const float* op = d.offset + (size_t)mm * d.off_ld + 2 * min(tap, ntap - 1);
-            const float h_im = (float)(qy * d.stride - pad_y + tky) + op[0];
-            const float w_im = (float)(qx * d.stride - pad_x + tkx) + op[1];
-            const bool inside = act && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-            const float hf = floorf(h_im), wf = floorf(w_im);
-            const int h_low = inside ? (int)hf : 0, w_low = inside ? (int)wf : 0;
-            const int h_high = h_low + 1, w_high = w_low + 1;
-            const float lh = h_im - hf, lw = w_im - wf;
-            const float hh = 1.f - lh, hw = 1.f - lw;
-            const bool hl = inside && h_low >= 0, hhv = inside && h_high <= H - 1;
-            const bool wl = w_low >= 0, whv = w_high <= W - 1;
-            const f32x4 w4 = {(hl && wl) ? hh * hw : 0.f, (hl && whv) ? hh * lw : 0.f, (hhv && wl) ? lh * hw : 0.f, (hhv && whv) ? lh * lw : 0.f};
-            *reinterpret_cast<f32x4*>(&cw[e * 4]) = w4;
-            vec4<unsigned short> c4;
-            c4[0] = (unsigned short)min(max(h_low, 0), H - 1); c4[1] = (unsigned short)min(max(h_high, 0), H - 1);
-            c4[2] = (unsigned short)min(max(w_low, 0), W - 1); c4[3] = (unsigned short)min(max(w_high, 0), W - 1);
-            *reinterpret_cast<vec4<unsigned short>*>(&cc[e * 4]) = c4;
-        }
-        __syncthreads();
-    }
-    if (nsteps > 0) {
-        load_tiles(0);
-        store_tiles();
-    }
-    __syncthreads();
-
-    for (int step = 0; step < nsteps; ++step) {
-        const bool more = step + 1 < nsteps;
-        if (more) load_tiles(step + 1);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {            // two K=16 MFMA slabs per 32-wide k-step
-            const int frag_off = frag_row + frag_chunk[m];
-            x8 af[NSA][TM], bf[NSB][TN];
-#pragma unroll
-            for (int p = 0; p < NSA; ++p)
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-                    af[p][a] = *reinterpret_cast<const x8*>(&As[p][(wm * TM * 32 + a * 32) * LDS_LDH + frag_off]);
-#pragma unroll
-            for (int p = 0; p < NSB; ++p)
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    bf[p][b] = *reinterpret_cast<const x8*>(&Bs[p][(wn * TN * 32 + b * 32) * LDS_LDH + frag_off]);
-            // product terms outermost (smallest first), accumulators innermost: consecutive MFMAs never depend on each other
-#pragma unroll
-            for (int q = 0; q < SM::NT; ++q)
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int b = 0; b < TN; ++b)
-                        acc[a][b] = split_mfma<MODE>(bf[SM::PB[q]][b], af[SM::PA[q]][a], acc[a][b]);
-        }
-        __syncthreads();
-        if (more) {
-            store_tiles();
-            __syncthreads();
-        }
-    }
-    report_range<MODE>(d, amax);
-    conv_epilogue<TM, TN, BN, false, 4, DEFORM>(d, acc, M, tile_m, tile_n, cls, split, py, px, wm, wn, lane, (cls * tiles_m + tile_m) * tiles_n + tile_n);
-}
-
 // ================================================================================================
 // Split-bf16, software-pipelined ("bf16p"): the kernel every non-deformable layer runs in the bf16x3 / bf16x6 modes.
 //
@@ -506,8 +259,9 @@ void conv_mfma_bf16s_kernel(const vps_conv_desc d, const int M, const int tiles_
 // one-tap case), and the step's part of the byte offset is scalar.
 // DEFORM (round 3): the deformable layers on the same pipeline. The four bilinear corners of a staged (row, tap) group are four
 // buffer loads issued one k-step ahead; they are blended with the corner weights of the per-block coefficient table when the row is
-// staged (between the MFMAs, like every other work item). Versus conv_mfma_bf16s_kernel (load | MFMAs | barrier | blend + stage |
-// barrier, weights through LDS): one barrier per k-step, staging interleaved with the matrix work, weights straight to registers.
+// staged (between the MFMAs, like every other work item). Versus the two-barrier kernel of rounds 1-2 (load | MFMAs | barrier | blend +
+// stage | barrier, weights through LDS; deleted in round 6 - no layer of the path used it): one barrier per k-step, staging interleaved
+// with the matrix work, weights straight to registers.
 template <int TM, int TN, int WAVES_M, int WAVES_N, int MODE, bool TAPMAJOR, bool DEFORM = false>
 __global__ __launch_bounds__(256, (TN >= 4 ? 1 : 2))            // the 256-column deformable instance: one block per CU, 512 registers per lane
 void conv_mfma_bf16p_kernel(const vps_conv_desc d, const int M, const int tiles_m, const int tiles_n,
@@ -1019,459 +773,6 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
 }
 
 // ================================================================================================
-// Halo-staged, 8 wavefronts, weights shared through LDS ("h8"): the 128-column stride-1 3x3 / 2x2 layers in the 3-product
-// modes (f16x3, bf16x3) and plain bf16, when the layer fills the chip with 256-row tiles.
-// tools/gapbench.hip: a 1 KB global load occupies the CU's vector-memory pipe for 64 cycles, a 1 KB LDS read for 4-16. In the
-// 4-wave kernel above every wave loads the 12 fragments (12 KB) of its 64 columns per tap from global memory: 2 blocks x 4 waves
-// x 12 KB = 1536 vector-memory cycles per tap and CU - exactly the 2 x 24 x 32 MFMA cycles a SIMD spends on the tap in the
-// 3-product modes (measured: matrix pipe 0.45 busy). Here ONE block of 8 waves (256 rows = an 8 x 32 patch, 128 columns) owns
-// the CU: the 24 weight fragments of a tap are loaded once (3 x 16 bytes per thread) into a double-buffered LDS region and read
-// by all 8 waves (lane-contiguous, conflict-free); a quarter of the global weight traffic. The 32-wide patch rows also make
-// the activation-fragment reads conflict-free (32 consecutive halo rows per sub-tile instead of 2 x 16 rows 18 apart).
-// Price: one barrier per tap (the weight buffers alternate per tap) instead of one per chunk.
-// ================================================================================================
-template <int MODE, int KH, int KW>
-__global__ __launch_bounds__(512, 2)
-void conv_mfma_h8_kernel(const vps_conv_desc d, const int tiles_m, const int tiles_n, const int chunks_per_split) {
-    constexpr int TM = 2, TN = 2, WAVES_N = 2, BN = 128;
-    constexpr int NTAP = KH * KW;
-    constexpr int HW = 32 + KW - 1, HH = 8 + KH - 1;   // halo tile of an 8 x 32 patch
-    constexpr int HROWS = HH * HW;                      // <= 340
-    constexpr int NLD = (HROWS + 63) / 64;              // staged rows per thread (64 rows per pass of the 512 threads)
-    typedef Split<MODE> SM;
-    typedef typename SM::elem elem_t;
-    typedef vec8<elem_t> x8;
-    typedef vec4<elem_t> x4;
-    constexpr int NSA = SM::NSA, NSB = SM::NSB;
-    constexpr int PLANE = NLD * 64 * LDS_LDH;           // 16-bit elements of one plane of one activation buffer
-    constexpr int ABUF = NSA * PLANE;
-    // all packed planes are loaded and staged: deriving the f16x3 mode's third plane in registers (derive_weight_plane) saves a third
-    // of the weight traffic but measured slower here (256->256 3x3 @256x512: 2.81 -> 2.88 ms; the tap loop is not short of load slots)
-    constexpr int NLB = NSB;
-    constexpr int NFRAG = NLB * 2 * (BN / 32);          // 1 KB weight fragments of one tap of the block tile
-    constexpr int BBUF = NFRAG * 512;
-    static_assert((NFRAG * 64) % 512 == 0, "whole 16-byte chunks per thread");
-    constexpr int NBL = NFRAG * 64 / 512;               // 16-byte weight chunks per thread and tap
-    static_assert(2 * (ABUF + BBUF) * 2 <= 160 * 1024, "LDS budget of the CU");
-
-    __shared__ __attribute__((aligned(16))) elem_t As[2 * ABUF];
-    __shared__ __attribute__((aligned(16))) elem_t Bs[2 * BBUF];
-
-    const int t = threadIdx.x;
-    int swz = xcd_swizzle(blockIdx.x, gridDim.x);
-    int tile_n, tile_m, cls, split;             // split: split-K over whole 32-channel chunks
-    decode_tile(d, swz, tiles_n, tiles_m, tile_n, tile_m, cls, split);
-
-    const int py = cls / d.os_x, px = cls - py * d.os_x;
-    const int H = d.H, W = d.W, cin_pad = d.cin_pad;
-    const int tiles_x = (d.Qw + 31) >> 5, tiles_y = (d.Qh + 7) >> 3;
-    const int tx = tile_m % tiles_x, tq = tile_m / tiles_x;
-    const int ty = tq % tiles_y, n = tq / tiles_y;
-    const int iy_org = ty * 8 - d.pad_y[py], ix_org = tx * 32 - d.pad_x[px];   // input position of halo row 0, column 0
-
-    const int k4 = t & 7;      // 4-channel group staged by this thread (8 lanes = one 128-byte line)
-    const int r0 = t >> 3;     // halo rows r0 + 64 i
-    const int chunk0 = split * chunks_per_split;
-    const int nchunks = min(chunks_per_split, d.kpad / (BK * NTAP) - chunk0);
-    const int nsteps = nchunks * NTAP;
-
-    const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;     // wm 0..3: output rows 2 wm, 2 wm + 1 of the patch
-    const int nbt = d.cout_pad >> 5, kst = d.kpad >> 4;
-    const size_t wplane = (size_t)d.nclass * nbt * kst * 512;
-    // buffer-addressed loads (see the pipelined kernel): scalar weight offsets, zero-fill of the halo by an out-of-range offset
-    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(d.w_split, (unsigned)(wplane * NSB * sizeof(elem_t)));
-    const unsigned wbase = (unsigned)((((size_t)(cls * nbt + tile_n * (BN / 32)) * kst + 2 * (size_t)chunk0 * NTAP) * 512) * sizeof(elem_t));
-    const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(d.in, (unsigned)((size_t)d.N * H * W * d.in_ld * sizeof(float)));
-    const unsigned ld4 = (unsigned)d.in_ld * 4u;
-
-    f32x4 areg[NLD];
-    int achunk = chunk0;       // next chunk to load
-    x8 breg[NBL];
-    float amax = 0.f;
-
-    // byte offset of halo position r0 + 64 i (k-invariant), 0xFFFFFFF0 when it lies outside the halo / the image
-    unsigned hoff[NLD];
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int hp = r0 + 64 * i;
-        const int hy = hp / HW, hx = hp - hy * HW;
-        const int iy = iy_org + hy, ix = ix_org + hx;
-        const bool ok = hp < HROWS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        hoff[i] = ok ? (unsigned)((n * H + iy) * W + ix) * ld4 + (unsigned)(d.in_coff + k4 * 4) * 4u : 0xFFFFFFF0u;
-    }
-
-    auto load_A = [&]() {
-        const bool kv = achunk * BK + k4 * 4 < cin_pad;
-        const unsigned coff = (unsigned)achunk * (BK * 4u);       // scalar
-        ++achunk;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i)
-            areg[i] = buffer_load16<f32x4>(arsrc, (kv && hoff[i] != 0xFFFFFFF0u) ? hoff[i] + coff : 0xFFFFFFF0u, 0u);
-    };
-    auto store_A = [&](int i, int buf) {
-        x4 sp[NSA];
-        split_act<MODE>(areg[i], sp, amax);
-        const int row = r0 + 64 * i;
-#pragma unroll
-        for (int p = 0; p < NSA; ++p)
-            *reinterpret_cast<x4*>(&As[buf * ABUF + p * PLANE + row * LDS_LDH + (((k4 >> 1) ^ lds_swz(row)) << 3) + ((k4 & 1) << 2)]) = sp[p];
-    };
-    // this thread's 16-byte chunks c = t + 512 j of fragment f = c / 64 = (plane * 2 + slab) * (BN/32) + column block.
-    // The fragment index is wave-uniform for a given j (64 chunks per fragment, 64 lanes per wave): scalar offset + lane * 16
-    auto load_B = [&](int step) {
-#pragma unroll
-        for (int j = 0; j < NBL; ++j) {
-            const int f = __builtin_amdgcn_readfirstlane((t + 512 * j) >> 6), bcol = f % (BN / 32), pm = f / (BN / 32);
-            breg[j] = buffer_load16<x8>(wrsrc, (unsigned)lane * 16u,
-                                        wbase + (unsigned)(((size_t)(pm >> 1) * wplane + ((size_t)bcol * kst + 2 * step + (pm & 1)) * 512) * sizeof(elem_t)));
-        }
-    };
-    auto store_B = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < NBL; ++j) *reinterpret_cast<x8*>(&Bs[buf * BBUF + (t + 512 * j) * 8]) = breg[j];
-    };
-
-    // halo row of tile row j = wm*64 + a*32 + (lane&31) = patch row 2 wm + a, column lane&31, for tap (0,0); tap (ky,kx) adds ky*HW + kx
-    int hbase[TM];
-#pragma unroll
-    for (int a = 0; a < TM; ++a) hbase[a] = (wm * TM + a) * HW + (lane & 31);
-    x8 af[2][NSA][TM];
-    auto read_A = [&](int m, int buf, int toff) {
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-            const int hrow = hbase[a] + toff;
-            const int off = buf * ABUF + hrow * LDS_LDH + (((2 * m + (lane >> 5)) ^ lds_swz(hrow)) << 3);
-#pragma unroll
-            for (int p = 0; p < NSA; ++p) af[m][p][a] = *reinterpret_cast<const x8*>(&As[off + p * PLANE]);
-        }
-    };
-    x8 bcur[2][NSB][TN];
-    auto read_B = [&](int m, int buf) {
-#pragma unroll
-        for (int p = 0; p < NLB; ++p)
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-                bcur[m][p][b] = *reinterpret_cast<const x8*>(&Bs[buf * BBUF + (((p * 2 + m) * (BN / 32)) + wn * TN + b) * 512 + lane * 8]);
-        if constexpr (NLB < NSB) {
-#pragma unroll
-            for (int b = 0; b < TN; ++b) bcur[m][2][b] = derive_weight_plane<MODE>(bcur[m][0][b]);
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    // prologue: chunk 0 staged in activation buffer 0, chunk 1 in flight in registers, weights of tap 0 staged in weight buffer 0
-    load_A();
-    load_B(0);
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) store_A(i, 0);
-    store_B(0);
-    load_A();
-    __syncthreads();
-
-    constexpr int NT = SM::NT;
-    constexpr int NMF = 2 * NT * TM * TN;                       // MFMAs per wave and tap
-    constexpr int SPT = (NLD + NTAP - 2) / (NTAP - 1);          // halo rows staged per tap (the last tap issues the loads)
-    constexpr int NW = SPT + 3;                                 // weight loads | slab-1 fragment reads | SPT stagings | weight stores
-
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int cur = chunk & 1;
-#pragma unroll
-        for (int tp = 0; tp < NTAP; ++tp) {
-            const int step = chunk * NTAP + tp;
-            const int bb = step & 1;                            // weight buffer of this tap
-            const int bstep = min(step + 1, nsteps - 1);        // weights of the next tap (clamped: the last prefetch is unused)
-            const int toff = (tp / KW) * HW + (tp % KW);
-            read_A(0, cur, toff);
-            read_B(0, bb);
-            __builtin_amdgcn_sched_barrier(0);
-
-            auto work = [&](const int w) {
-                if (w == 0) load_B(bstep);                               // next tap's weights -> registers (issued first)
-                else if (w == 1) { read_A(1, cur, toff); read_B(1, bb); }   // fragments of the second slab
-                else if (w < SPT + 2) {
-                    const int si = w - 2;                                // 0 .. SPT-1
-                    if (tp < NTAP - 1) {
-                        const int row = tp * SPT + si;
-                        if (row < NLD) store_A(row, cur ^ 1);
-                    } else if (si == 0) load_A();
-                } else store_B(bb ^ 1);                                  // next tap's weights -> LDS (their loads are most of a tap old)
-            };
-
-            int mf = 0;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int q = 0; q < NT; ++q)
-#pragma unroll
-                    for (int a = 0; a < TM; ++a)
-#pragma unroll
-                        for (int b = 0; b < TN; ++b) {
-                            acc[a][b] = split_mfma<MODE>(bcur[m][SM::PB[q]][b], af[m][SM::PA[q]][a], acc[a][b]);
-                            ++mf;
-#pragma unroll
-                            for (int w = 0; w < NW; ++w) {
-                                const int pos = ((w + 1) * NMF) / (NW + 1);
-                                if (mf == (pos < 1 ? 1 : pos)) {
-                                    __builtin_amdgcn_sched_barrier(0);
-                                    work(w);
-                                    __builtin_amdgcn_sched_barrier(0);
-                                }
-                            }
-                        }
-            __syncthreads();                                    // weight buffers alternate per tap (and, after the last tap, the chunk's)
-        }
-    }
-    report_range<MODE>(d, amax);
-    conv_epilogue<TM, TN, BN, true, 5>(d, acc, tiles_m * 256, tile_m, tile_n, cls, split, py, px, wm, wn, lane, (cls * tiles_m + tile_m) * tiles_n + tile_n);
-}
-
-// ================================================================================================
-// Stride-2 K x K layers (K = 3, 5) on the 8-wave halo structure ("h8s2"), phase-split staging. EXPERIMENTAL: dispatched only when
-// the environment variable VPS_S2_HALO is set (launch_conv); not part of the measured configuration of round 2.
-// A stride-2 conv is four stride-1 convs on the (row, column)-parity sub-images of the input: tap (ky, kx) = (2j + a, 2i + b) of
-// output pixel (oy, ox) reads sub-image (a, b) at (oy + j, ox + i) (origin shifted by the padding). One stage of the k loop =
-// (32-channel chunk, phase (a, b)): the 8 x 32 output patch's sub-image patch ((8 + J_a - 1) x (32 + I_b - 1) pixels, J_0 = I_0 =
-// ceil(K/2), J_1 = I_1 = floor(K/2)) is staged ONCE in LDS like the stride-1 halo tile, then the J_a x I_b taps of the phase read
-// their activation fragments from it at the row offset j * HW + i. 5x5: 9 + 6 + 6 + 4 taps on <= 340 staged rows each (54 rows
-// per tap; the pipelined kernel stages 256 rows per tap and re-fetches every input element 6.25 times); 3x3: 4 + 2 + 2 + 1.
-// Everything else - weights through LDS per tap, fragment layouts, interleaving, epilogue - is conv_mfma_h8_kernel's.
-// ================================================================================================
-struct S2Tap { int ph, j, i, idx, t, nt; };    // phase, tap (j, i) inside it, k index ky*K + kx, position t of nt taps of the phase
-constexpr int s2_taps_1d(int K, int a) { return (K - a + 1) / 2; }
-constexpr S2Tap s2_tap(int K, int ts) {
-    int base = 0;
-    for (int ph = 0; ph < 4; ++ph) {
-        const int a = ph >> 1, b = ph & 1, J = s2_taps_1d(K, a), I = s2_taps_1d(K, b);
-        if (ts < base + J * I) {
-            const int t = ts - base, j = t / I, i = t - j * I;
-            return S2Tap{ph, j, i, (2 * j + a) * K + 2 * i + b, t, J * I};
-        }
-        base += J * I;
-    }
-    return S2Tap{0, 0, 0, 0, 0, 1};
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (N > 0) {
-        static_for<N - 1>(f);
-        f(std::integral_constant<int, N - 1>{});
-    }
-}
-
-template <int MODE, int K, int BN = 128>
-__global__ __launch_bounds__(512, 2)
-void conv_mfma_h8s2_kernel(const vps_conv_desc d, const int tiles_m, const int tiles_n, const int chunks_per_split) {
-    static_assert(BN == 128 || BN == 64, "two column waves of 64 or 32 columns");
-    constexpr int TM = 2, TN = BN / 64, WAVES_N = 2;
-    constexpr int NTAP = K * K;
-    constexpr int J0 = s2_taps_1d(K, 0);                // taps per axis of the even phase (the larger one)
-    constexpr int HW = 32 + J0 - 1, HH = 8 + J0 - 1;    // sub-image patch of an 8 x 32 output patch: 10 x 34 (K = 5), 9 x 33 (K = 3)
-    constexpr int HROWS = HH * HW;
-    constexpr int NLD = (HROWS + 63) / 64;
-    typedef Split<MODE> SM;
-    typedef typename SM::elem elem_t;
-    typedef vec8<elem_t> x8;
-    typedef vec4<elem_t> x4;
-    constexpr int NSA = SM::NSA, NSB = SM::NSB;
-    constexpr int PLANE = NLD * 64 * LDS_LDH;
-    constexpr int ABUF = NSA * PLANE;
-    constexpr int NLB = NSB;                            // all packed planes loaded (see the stride-1 kernel above)
-    constexpr int NFRAG = NLB * 2 * (BN / 32);
-    constexpr int NBL = (NFRAG * 64 + 511) / 512;       // 16-byte weight chunks per thread
-    constexpr bool WHOLE = (NFRAG * 64) % 512 == 0;
-    constexpr int BBUF = NBL * 512 * 8;                 // whole rounds of the 512 threads (>= NFRAG * 512)
-    static_assert(2 * (ABUF + BBUF) * 2 <= 160 * 1024, "LDS budget of the CU");
-
-    __shared__ __attribute__((aligned(16))) elem_t As[2 * ABUF];
-    __shared__ __attribute__((aligned(16))) elem_t Bs[2 * BBUF];
-
-    const int t = threadIdx.x;
-    const int swz = xcd_swizzle(blockIdx.x, gridDim.x);
-    int tile_n, tile_m, cls, split;
-    decode_tile(d, swz, tiles_n, tiles_m, tile_n, tile_m, cls, split);
-
-    const int H = d.H, W = d.W, cin_pad = d.cin_pad;
-    const int tiles_x = (d.Qw + 31) >> 5, tiles_y = (d.Qh + 7) >> 3;
-    const int tx = tile_m % tiles_x, tq = tile_m / tiles_x;
-    const int ty = tq % tiles_y, n = tq / tiles_y;
-    const int iy_org = ty * 16 - d.pad_y[0], ix_org = tx * 64 - d.pad_x[0];   // input position of tap (0, 0) of the patch's first output
-
-    const int k4 = t & 7;
-    const int r0 = t >> 3;
-    const int chunk0 = split * chunks_per_split;
-    const int nchunks = min(chunks_per_split, d.kpad / (BK * NTAP) - chunk0);
-
-    const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
-    const int nbt = d.cout_pad >> 5, kst = d.kpad >> 4;
-    const size_t wplane = (size_t)nbt * kst * 512;
-    // buffer-addressed loads (see the pipelined kernel): scalar weight offsets, zero-fill of the patch by an out-of-range offset
-    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(d.w_split, (unsigned)(wplane * NSB * sizeof(elem_t)));
-    const unsigned wbase = (unsigned)((((size_t)(tile_n * (BN / 32)) * kst + 2 * (size_t)chunk0 * NTAP) * 512) * sizeof(elem_t));
-    const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(d.in, (unsigned)((size_t)d.N * H * W * d.in_ld * sizeof(float)));
-    const unsigned ld4 = (unsigned)d.in_ld * 4u;
-
-    f32x4 areg[NLD];
-    int achunk = chunk0, aph = 0;      // next (chunk, phase) stage to load
-    x8 breg[NBL];
-    float amax = 0.f;
-
-    // sub-image patch of the next stage -> registers (sequential: every call advances (chunk, phase))
-    auto load_A = [&]() {
-        const int a = aph >> 1, b = aph & 1;
-        const int rows = 8 + ((K - a + 1) >> 1) - 1, cols = 32 + ((K - b + 1) >> 1) - 1;
-        const int cic = achunk * BK + k4 * 4;
-        const bool kv = cic < cin_pad;
-        const unsigned coff = (unsigned)(d.in_coff + cic) * 4u;
-        if (++aph == 4) { aph = 0; ++achunk; }
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int hp = r0 + 64 * i;
-            const int hy = hp / HW, hx = hp - hy * HW;
-            const int iy = iy_org + a + 2 * hy, ix = ix_org + b + 2 * hx;
-            const bool ok = kv && hy < rows && hx < cols && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            areg[i] = buffer_load16<f32x4>(arsrc, ok ? (unsigned)((n * H + iy) * W + ix) * ld4 + coff : 0xFFFFFFF0u, 0u);
-        }
-    };
-    auto store_A = [&](int i, int buf) {
-        x4 sp[NSA];
-        split_act<MODE>(areg[i], sp, amax);
-        const int row = r0 + 64 * i;
-#pragma unroll
-        for (int p = 0; p < NSA; ++p)
-            *reinterpret_cast<x4*>(&As[buf * ABUF + p * PLANE + row * LDS_LDH + (((k4 >> 1) ^ lds_swz(row)) << 3) + ((k4 & 1) << 2)]) = sp[p];
-    };
-    // wstep = k-step pair index relative to this split: (chunk - chunk0) * NTAP + ky * K + kx
-    auto load_B = [&](int wstep) {
-#pragma unroll
-        for (int j = 0; j < NBL; ++j) {
-            // no branch in here (it would split the interleaved MFMA stream): when the fragments are not a whole number of rounds
-            // (64 columns, 3 weight planes) the surplus waves re-load the last fragment into the padding of the buffer
-            const int fr = __builtin_amdgcn_readfirstlane((t + 512 * j) >> 6), f = WHOLE ? fr : min(fr, NFRAG - 1);
-            const int bcol = f % (BN / 32), pm = f / (BN / 32);
-            breg[j] = buffer_load16<x8>(wrsrc, (unsigned)lane * 16u,
-                                        wbase + (unsigned)(((size_t)(pm >> 1) * wplane + ((size_t)bcol * kst + 2 * wstep + (pm & 1)) * 512) * sizeof(elem_t)));
-        }
-    };
-    auto store_B = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < NBL; ++j)
-            *reinterpret_cast<x8*>(&Bs[buf * BBUF + (t + 512 * j) * 8]) = breg[j];
-    };
-
-    int hbase[TM];
-#pragma unroll
-    for (int a = 0; a < TM; ++a) hbase[a] = (wm * TM + a) * HW + (lane & 31);
-    x8 af[2][NSA][TM];
-    auto read_A = [&](int m, int buf, int toff) {
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-            const int hrow = hbase[a] + toff;
-            const int off = buf * ABUF + hrow * LDS_LDH + (((2 * m + (lane >> 5)) ^ lds_swz(hrow)) << 3);
-#pragma unroll
-            for (int p = 0; p < NSA; ++p) af[m][p][a] = *reinterpret_cast<const x8*>(&As[off + p * PLANE]);
-        }
-    };
-    x8 bcur[2][NSB][TN];
-    auto read_B = [&](int m, int buf) {
-#pragma unroll
-        for (int p = 0; p < NLB; ++p)
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-                bcur[m][p][b] = *reinterpret_cast<const x8*>(&Bs[buf * BBUF + (((p * 2 + m) * (BN / 32)) + wn * TN + b) * 512 + lane * 8]);
-        if constexpr (NLB < NSB) {
-#pragma unroll
-            for (int b = 0; b < TN; ++b) bcur[m][2][b] = derive_weight_plane<MODE>(bcur[m][0][b]);
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    // prologue: stage (chunk 0, phase 0) in activation buffer 0, stage (chunk 0, phase 1) in flight in registers, weights of the
-    // first tap in weight buffer 0
-    load_A();
-    load_B(s2_tap(K, 0).idx);
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) store_A(i, 0);
-    store_B(0);
-    load_A();
-    __syncthreads();
-
-    constexpr int NT = SM::NT;
-    constexpr int NMF = 2 * NT * TM * TN;                       // MFMAs per wave and tap
-
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        static_for<NTAP>([&](auto ts_tag) {
-            constexpr int TS = decltype(ts_tag)::value;         // position of the tap in the chunk's phase-major tap sequence
-            constexpr S2Tap tp = s2_tap(K, TS);
-            constexpr S2Tap nx = s2_tap(K, (TS + 1) % NTAP);
-            constexpr int cur = tp.ph & 1;                      // four stages per chunk: the activation buffer is the phase's parity
-            constexpr bool last_of_phase = tp.t == tp.nt - 1;
-            constexpr int SPT = (NLD + tp.nt - 1) / tp.nt;      // rows of the next stage staged per tap of this phase
-            constexpr int NW = 3 + SPT + (last_of_phase ? 1 : 0);   // weight loads | slab-1 fragment reads | SPT stagings | [next loads] | weight stores
-            const int step = chunk * NTAP + TS;
-            const int bb = step & 1;                            // weight buffer of this tap
-            const int wnext = (TS + 1 < NTAP ? chunk : min(chunk + 1, nchunks - 1)) * NTAP + nx.idx;   // clamped: the last prefetch is unused
-            constexpr int toff = tp.j * HW + tp.i;
-            read_A(0, cur, toff);
-            read_B(0, bb);
-            __builtin_amdgcn_sched_barrier(0);
-
-            auto work = [&](const int w) {
-                if (w == 0) load_B(wnext);
-                else if (w == 1) { read_A(1, cur, toff); read_B(1, bb); }
-                else if (w < SPT + 2) {
-                    const int row = tp.t * SPT + (w - 2);
-                    if (row < NLD) store_A(row, cur ^ 1);
-                } else if (last_of_phase && w == SPT + 2) load_A();          // the stage after next, into the registers just staged
-                else store_B(bb ^ 1);
-            };
-
-            int mf = 0;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int q = 0; q < NT; ++q)
-#pragma unroll
-                    for (int a = 0; a < TM; ++a)
-#pragma unroll
-                        for (int b = 0; b < TN; ++b) {
-                            acc[a][b] = split_mfma<MODE>(bcur[m][SM::PB[q]][b], af[m][SM::PA[q]][a], acc[a][b]);
-                            ++mf;
-#pragma unroll
-                            for (int w = 0; w < NW; ++w) {
-                                const int pos = ((w + 1) * NMF) / (NW + 1);
-                                if (mf == (pos < 1 ? 1 : pos)) {
-                                    __builtin_amdgcn_sched_barrier(0);
-                                    work(w);
-                                    __builtin_amdgcn_sched_barrier(0);
-                                }
-                            }
-                        }
-            __syncthreads();
-        });
-    }
-    report_range<MODE>(d, amax);
-    conv_epilogue<TM, TN, BN, true, 5>(d, acc, tiles_m * 256, tile_m, tile_n, cls, split, 0, 0, wm, wn, lane, (cls * tiles_m + tile_m) * tiles_n + tile_n);
-}
-
-// ================================================================================================
 // Narrow-output layers (5 <= cout <= 16: the full-resolution FlowNetFusion / FlowNetSD interconv and deconv layers) on the
 // 16x16x32 MFMA shape. A 32-column tile of the 32x32x16 shape spends half of every MFMA and of every weight fragment on zero
 // columns; here the WEIGHT fragment (16 output channels x 32 k) is the A operand and 16 consecutive pixels of a patch row
@@ -1951,7 +1252,14 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
     const int tiles_m = cdiv(M, BM);
     const int tiles_n = d.cout_pad / BN;
     const int ksteps = d.kpad / BK;
-    const int per_split = cdiv(ksteps, d.ksplit);
+    // split-K: `ksplit` ranges of ceil(steps / ksplit) k-steps, the last one shorter when the division leaves a rest (every kernel clamps
+    // its range). Chunk-major layers (k = (32-channel chunk, tap)) are split over WHOLE chunks when ceil-division of the chunk count
+    // reproduces ksplit - the halo-staged kernels need that, and since round 6 the ranges may be uneven: FlowNet's 1026- / 770- / 386-
+    // channel decoder layers have 33 / 25 / 13 chunks, no even split exists, and unsplit they filled half of the chip.
+    const int ntap_all = d.KH * d.KW;
+    const int nch = d.korder == 1 ? ksteps / ntap_all : 0;
+    const bool chunk_split = d.ksplit > 1 && d.korder == 1 && nch > 0 && cdiv(nch, cdiv(nch, d.ksplit)) == d.ksplit;
+    const int per_split = chunk_split ? cdiv(nch, d.ksplit) * ntap_all : cdiv(ksteps, d.ksplit);
     const int nsplit_eff = cdiv(ksteps, per_split);
     if (nsplit_eff != d.ksplit) return VPS_EARG(20);  // caller must pick ksplit | ceil-consistent
     const long nblk = (long)tiles_m * tiles_n * d.nclass * d.ksplit;
@@ -1962,7 +1270,7 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
     // split-K there is over whole 32-channel chunks: the k-steps of a split must be a whole number of chunks
     const int ntap = d.KH * d.KW;
     const bool halo = d.prec != VPS_PREC_F32 && !d.offset && d.stride == 1 && d.korder == 1 && d.KH == d.KW && (d.KH == 3 || d.KH == 2) &&
-                      tiles2d * 128 * 2 <= (long)M * 3 && (d.ksplit == 1 || (ksteps % d.ksplit == 0 && per_split % ntap == 0));
+                      tiles2d * 128 * 2 <= (long)M * 3 && (d.ksplit == 1 || chunk_split);
     // 8-wave variant (256-row tiles, weights through LDS): 128-column layers in the modes whose two activation planes leave room
     // for the weight buffers, when the 8 x 32 patches waste little and there are enough tiles to give every CU one
     const long tiles2d8 = (long)d.N * ((d.Qh + 7) / 8) * ((d.Qw + 31) / 32);
@@ -1977,7 +1285,7 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
     const bool h8s2 = s2_enabled && (BN == 128 || BN == 64) && (d.prec == VPS_PREC_F16X3 || d.prec == VPS_PREC_BF16X3 || d.prec == VPS_PREC_BF16) && !d.offset &&
                       d.stride == 2 && d.nclass == 1 && d.korder == 1 && d.KH == d.KW && (d.KH == 3 || d.KH == 5) &&
                       d.pad_y[0] == d.KH / 2 && d.pad_x[0] == d.KW / 2 && tiles2d8 * 256 * 2 <= (long)M * 3 &&
-                      tiles2d8 * tiles_n * d.ksplit >= 256 && (d.ksplit == 1 || (ksteps % d.ksplit == 0 && per_split % ntap == 0));
+                      tiles2d8 * tiles_n * d.ksplit >= 256 && (d.ksplit == 1 || chunk_split);
     // 5..16 output channels, stride-1 3x3 / 2x2-class layers with enough 8 x 32 patches: the 16x16x32 kernel (VPS_N16=0 switches it off)
     static const bool n16_enabled = !(getenv("VPS_N16") && getenv("VPS_N16")[0] == '0');
     const bool n16 = n16_enabled && BN == 32 && d.prec == VPS_PREC_F16X3 && halo && d.cout > 4 && d.cout <= 16 && d.cout_pad == 32 && d.ksplit == 1 &&
@@ -1987,23 +1295,9 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
         if (d.KH == 3) hipLaunchKernelGGL((conv_mfma_n16_kernel<VPS_PREC_F16X3, 3, 3>), dim3((unsigned)nblk8), dim3(512), 0, s, d, (int)tiles2d8);
         else hipLaunchKernelGGL((conv_mfma_n16_kernel<VPS_PREC_F16X3, 2, 2>), dim3((unsigned)nblk8), dim3(512), 0, s, d, (int)tiles2d8);
     } else if (h8s2) {
-        const int tiles_m8 = (int)tiles2d8;
-        const long nblk8 = (long)tiles_m8 * tiles_n * d.ksplit;
-#define VPS_H8S2_LAUNCH(MODE, K)                                                                                                 \
-    hipLaunchKernelGGL((conv_mfma_h8s2_kernel<MODE, K, (BN == 64 ? 64 : 128)>), dim3((unsigned)nblk8), dim3(512), 0, s, d, tiles_m8, tiles_n, per_split / ntap)
-        if (d.prec == VPS_PREC_BF16) { if (d.KH == 3) VPS_H8S2_LAUNCH(VPS_PREC_BF16, 3); else VPS_H8S2_LAUNCH(VPS_PREC_BF16, 5); }
-        else if (d.prec == VPS_PREC_BF16X3) { if (d.KH == 3) VPS_H8S2_LAUNCH(VPS_PREC_BF16X3, 3); else VPS_H8S2_LAUNCH(VPS_PREC_BF16X3, 5); }
-        else { if (d.KH == 3) VPS_H8S2_LAUNCH(VPS_PREC_F16X3, 3); else VPS_H8S2_LAUNCH(VPS_PREC_F16X3, 5); }
-#undef VPS_H8S2_LAUNCH
+        vpsi_launch_conv_h8s2(d, (int)tiles2d8, tiles_n, per_split / ntap, (long)tiles2d8 * tiles_n * d.ksplit, BN == 64 ? 64 : 128, s);
     } else if (h8) {
-        const int tiles_m8 = (int)tiles2d8;
-        const long nblk8 = (long)tiles_m8 * tiles_n * d.nclass * d.ksplit;
-#define VPS_H8_LAUNCH(MODE, K)                                                                                                   \
-    hipLaunchKernelGGL((conv_mfma_h8_kernel<MODE, K, K>), dim3((unsigned)nblk8), dim3(512), 0, s, d, tiles_m8, tiles_n, per_split / ntap)
-        if (d.prec == VPS_PREC_BF16) { if (d.KH == 3) VPS_H8_LAUNCH(VPS_PREC_BF16, 3); else VPS_H8_LAUNCH(VPS_PREC_BF16, 2); }
-        else if (d.prec == VPS_PREC_BF16X3) { if (d.KH == 3) VPS_H8_LAUNCH(VPS_PREC_BF16X3, 3); else VPS_H8_LAUNCH(VPS_PREC_BF16X3, 2); }
-        else { if (d.KH == 3) VPS_H8_LAUNCH(VPS_PREC_F16X3, 3); else VPS_H8_LAUNCH(VPS_PREC_F16X3, 2); }
-#undef VPS_H8_LAUNCH
+        vpsi_launch_conv_h8(d, (int)tiles2d8, tiles_n, per_split / ntap, (long)tiles2d8 * tiles_n * d.nclass * d.ksplit, s);
     } else if (halo) {
         const int tiles_m2 = (int)tiles2d;
         const long nblk2 = (long)tiles_m2 * tiles_n * d.nclass * d.ksplit;
@@ -2019,7 +1313,7 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
     } else {
     // deformable layers: the pipelined kernel when the k order is chunk-major (every layer of the path; weights in fragment order),
     // the two-barrier kernel for the tap-major order (row-major weights: vps_hip.h)
-    const bool dcn_pipe = d.korder == 1;
+    const bool dcn_pipe = true;                            // (tap-major deformable launches are refused by vps_conv2d)
     const bool tapmajor = d.korder == 0 && ntap > 1;      // small channel counts; a 1x1 layer is the one-tap case of the chunk-major order
 #define VPS_CONV_LAUNCH(KERNEL)                                                                              \
     hipLaunchKernelGGL((KERNEL), dim3((unsigned)nblk), dim3(256), 0, s, d, M, tiles_m, tiles_n, per_split)
@@ -2033,22 +1327,18 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
         else VPS_CONV_LAUNCH((conv_mfma_f32_kernel<TM, TN, WAVES_M, WAVES_N, false>));
     } else if (d.prec == VPS_PREC_BF16) {
         if (d.offset && dcn_pipe) VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16, false, true>));
-        else if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16, true>));
         else if (tapmajor) VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16, true>));
         else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16, false>));
     } else if (d.prec == VPS_PREC_BF16X3) {
         if (d.offset && dcn_pipe) VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X3, false, true>));
-        else if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X3, true>));
         else if (tapmajor) VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X3, true>));
         else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X3, false>));
     } else if (d.prec == VPS_PREC_F16X3) {
         if (d.offset && dcn_pipe) VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_F16X3, false, true>));
-        else if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_F16X3, true>));
         else if (tapmajor) VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_F16X3, true>));
         else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_F16X3, false>));
     } else {
         if (d.offset && dcn_pipe) VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X6, false, true>));
-        else if (d.offset) VPS_CONV_LAUNCH((conv_mfma_bf16s_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X6, true>));
         else if (tapmajor) VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X6, true>));
         else VPS_CONV_LAUNCH((conv_mfma_bf16p_kernel<TM, TN, WAVES_M, WAVES_N, VPS_PREC_BF16X6, false>));
     }
@@ -2083,6 +1373,9 @@ extern "C" int vps_conv2d(const vps_conv_desc* dp, void* stream) {
     if (d.nclass != d.os_y * d.os_x || d.nclass < 1 || d.os_y > 2 || d.os_x > 2) return VPS_EARG(7);
     if (d.ksplit < 1 || (d.ksplit > 1 && !d.ws)) return VPS_EARG(8);
     if (d.offset && (d.nclass != 1 || d.off_ld < 2 * d.KH * d.KW || d.KH * d.KW > 9 || d.H > 65535 || d.W > 65535)) return VPS_EARG(9);
+    // deformable layers of the split-operand modes: chunk-major k order only (every layer of the path; the tap-major two-barrier kernel of
+    // rounds 1-2 is gone) - a tap-major deformable layer runs in VPS_PREC_F32 (vps_amd/nhwc.py packs it that way)
+    if (d.offset && d.prec != VPS_PREC_F32 && d.korder != 1) return VPS_EARG(17);
     if (((uintptr_t)d.in & 15) || ((uintptr_t)d.w & 15) || ((uintptr_t)d.w_split & 15)) return VPS_EARG(10);
     // the split-operand kernels address the input and the weights through 32-bit buffer offsets
     if (d.prec != VPS_PREC_F32 && (size_t)d.N * d.H * d.W * d.in_ld * sizeof(float) >= 0xFFFFFFF0ull) return VPS_EARG(16);

@@ -95,6 +95,7 @@ void conv_pw_kernel(const vps_conv_desc d, const int M, const int tiles_m, const
     float amax = 0.f;
 
     auto load_A = [&](const int slot) {
+        if (ko & 32) return;
         const unsigned koff = (unsigned)lk * (BK * 4u);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -107,6 +108,7 @@ void conv_pw_kernel(const vps_conv_desc d, const int M, const int tiles_m, const
     };
     // this thread's 16-byte chunks c = t + 256 j of fragment f = c / 64 = wave + 4 j = (plane * 2 + slab) * (BN/32) + column block
     auto load_B = [&](const int slot) {
+        if (ko & 4) return;
 #pragma unroll
         for (int j = 0; j < NBL; ++j) {
             const int f = wave + 4 * j, bcol = f % (BN / 32), pm = f / (BN / 32);
@@ -116,7 +118,8 @@ void conv_pw_kernel(const vps_conv_desc d, const int M, const int tiles_m, const
     };
     auto store_A = [&](const int i, const int buf, const int slot) {
         x4 sp[NSA];
-        split_act<PMODE>(areg[slot][i], sp, amax);
+        if (ko & 16) { struct two { x4 a, b; }; const two pp = __builtin_bit_cast(two, areg[slot][i]); sp[0] = pp.a; sp[1] = pp.b; }
+        else split_act<PMODE>(areg[slot][i], sp, amax);
         const int row = r0 + 32 * i;
 #pragma unroll
         for (int p = 0; p < NSA; ++p)
@@ -245,7 +248,7 @@ void conv_pw_kernel(const vps_conv_desc d, const int M, const int tiles_m, const
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
-                    acc[a][b] = split_mfma<PMODE>(bf[SM::PB[q]][b], af[1][SM::PA[q]][a], acc[a][b]);
+                    if (!(ko & 8)) acc[a][b] = split_mfma<PMODE>(bf[SM::PB[q]][b], af[1][SM::PA[q]][a], acc[a][b]);
                     ++mf;
 #pragma unroll
                     for (int w = 0; w < NW; ++w) {
@@ -258,7 +261,7 @@ void conv_pw_kernel(const vps_conv_desc d, const int M, const int tiles_m, const
                     }
                 }
         }
-        __syncthreads();
+        if (!(ko & 64)) __syncthreads();
     };
 
     // ---- epilogue on the transposed accumulators (conv_common.h): a lane owns pixel (lane & 31) of its TM sub-tiles and, per

@@ -3,6 +3,7 @@
 // Reference (relative to /root/reference/mmdet/models): utils/mask_removal.py:29-92,
 // utils/unary_logits.py:81-108, panoptic/upsnetFPN.py:81, detectors/panoptic_fusetrack.py:585-597.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -210,7 +211,7 @@ constexpr int MR_SPIN_LIMIT = 1 << 22;
 __global__ __launch_bounds__(MR_THREADS)
 void mask_removal_dep_kernel(const float* __restrict__ logits, int S, const int* __restrict__ boxes, const int* __restrict__ cls0,
                              const int* __restrict__ mask_idx, int n, int H, int W, unsigned* __restrict__ occ_words, double thr,
-                             int* __restrict__ flags, int* __restrict__ done, int* __restrict__ status) {
+                             int* __restrict__ flags, int* __restrict__ done, int* __restrict__ status, const int spin_limit) {
     __shared__ float m28[32 * 32];
     __shared__ short tx0[MR_TAB], tx1[MR_TAB], ty0[MR_TAB], ty1[MR_TAB];
     __shared__ float tfx[MR_TAB], tfy[MR_TAB];
@@ -240,7 +241,7 @@ void mask_removal_dep_kernel(const float* __restrict__ logits, int S, const int*
         int spins = 0;
         while (__hip_atomic_load(&done[deps[t]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > MR_SPIN_LIMIT) { atomicOr(status, 4); break; }
+            if (++spins > spin_limit) { atomicOr(status, 4); break; }
         }
     }
     __syncthreads();
@@ -466,6 +467,11 @@ extern "C" int vps_mask_removal_dep(const float* logits, int S, const int32_t* b
     if (!logits || !boxes || !cls0 || !mask_idx || !occ || !flags || !done || !status || S < 2 || n < 0 || n > 256 || ncls <= 0 || H <= 0 || W <= 0)
         return VPS_EARG(1);
     if ((W & 3) || ((uintptr_t)occ & 3)) return VPS_EARG(2);                     // 4-pixel occupancy words
+    if (S > 32) return VPS_EARG(3);                                              // the kernel keeps the S x S logits of a box in a 32 x 32 LDS array
+    // VPS_MR_SPIN_LIMIT=n in the environment: polls a box spends on one dependency before it gives up with status bit 2 (tests force
+    // the expiry path with 0; read per call)
+    const char* const sl = getenv("VPS_MR_SPIN_LIMIT");
+    const int spin_limit = sl ? atoi(sl) : MR_SPIN_LIMIT;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(occ, 0, (size_t)ncls * H * W, s);
     if (e != hipSuccess) return -(int)e;
@@ -473,7 +479,7 @@ extern "C" int vps_mask_removal_dep(const float* logits, int S, const int32_t* b
     e = hipMemsetAsync(done, 0, sizeof(int32_t) * n, s);
     if (e != hipSuccess) return -(int)e;
     hipLaunchKernelGGL(mask_removal_dep_kernel, dim3(n), dim3(MR_THREADS), 0, s, logits, S, boxes, cls0, mask_idx, n, H, W,
-                       reinterpret_cast<unsigned*>(occ), thr, flags, done, status);
+                       reinterpret_cast<unsigned*>(occ), thr, flags, done, status, spin_limit);
     return vps_launch_status();
 }
 

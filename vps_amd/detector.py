@@ -20,11 +20,22 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import hip, nhwc
+from . import hip, nhwc, panoptic_ops
 from . import registry as R
 from .base import HipModule
 from .flownet2 import FlowNet2
 from .panoptic_ops import MaskRemoval, MaskROI, panoptic_combine
+
+# The announcement board (round 6): the (img, ref_img) device-tensor pairs of the frames that FOLLOW the one the next `simple_test`
+# call is made with, posted by a caller-side component that knows them when the call itself cannot say (`vps_amd.dataloader.
+# LookaheadLoader` around the unmodified tools/test_vpq.py loop). `simple_test(..., prefetch=None)` reads it as its `prefetch`.
+_BOARD = []
+
+
+def announce(pairs):
+    """pairs: list of (img, ref_img) tensors in frame order (at most two are used); [] clears the board"""
+    _BOARD[:] = [(a, b) for a, b in pairs][:2]
+
 
 
 def _np(a):
@@ -277,6 +288,8 @@ class PanopticFuseTrack(HipModule):
         assert proposals is None
         if not img.is_cuda:
             raise hip.VpsHipError('PanopticFuseTrack runs on the device only (no CPU path)')
+        if prefetch is None and _BOARD and inject is None:
+            prefetch = [p for p in _BOARD if p[0].is_cuda and p[0].shape == img.shape] or None        # (module docstring of dataloader.py)
         dev = img.device
         self.ensure_packed(dev)
         ws = self._workspace(dev)
@@ -318,6 +331,7 @@ class PanopticFuseTrack(HipModule):
         else:
             pending, self._pf = self._pf or [], None
             late = []
+            pf = None
             if side is not None:
                 # (1) flow + (2) backbone / FPN / gather of THIS frame: enqueued on the prefetch streams during an earlier call
                 # (matched by tensor identity), or now - through the same machinery (the image-stage streams, the lane workspace
@@ -327,7 +341,10 @@ class PanopticFuseTrack(HipModule):
                 # frames' image-only stages queued through the tail of this frame and across the frame boundary (round 5: the
                 # frame's last third ran on one or two streams and the boundary was a 0.2 - 0.3 ms bubble; ring of three slots: frame t+2 goes where frame t-1 was, whose
                 # gathered feature neck(t) has read by then).
-                same = lambda r, a, b: r['img'] is a and r['ref'] is b and r['version'] == (a._version, b._version)
+                # (the same storage in the same state: a scatter that re-wraps a device tensor keeps the match; a record holds its
+                # tensors, so an address cannot be re-used by another frame while the record waits)
+                same = lambda r, a, b: (r['img'].data_ptr() == a.data_ptr() and r['ref'].data_ptr() == b.data_ptr() and r['img'].shape == a.shape
+                                        and r['version'] == (a._version, b._version))
                 announced = [] if prefetch is None else ([prefetch] if torch.is_tensor(prefetch[0]) else list(prefetch))
                 pf = next((r for r in pending if same(r, img, ref_img)), None)
                 keep = [r for r in pending if r is not pf and any(same(r, a, b) for a, b in announced)]
@@ -340,11 +357,13 @@ class PanopticFuseTrack(HipModule):
                         main.wait_event(r['event'])
                         if r['event2'] is not None:
                             main.wait_event(r['event2'])
+                # (ring slots a new frame must not take: those of the records this call still consumes - `busy` - and the one that
+                # holds the cached reference feature neck(t) reads, `_enqueue_image_stages`)
                 if pf is None:
-                    pf = self._enqueue_image_stages(img, ref_img, main)
+                    pf = self._enqueue_image_stages(img, ref_img, main, busy=keep)
                 is_pending = lambda a, b: any(same(r, a, b) for r in keep)
                 if announced and not is_pending(*announced[0]):
-                    keep.append(self._enqueue_image_stages(announced[0][0], announced[0][1], main))       # the NEXT frame: now
+                    keep.append(self._enqueue_image_stages(announced[0][0], announced[0][1], main, busy=[pf] + keep))       # the NEXT frame: now
                 late = [(a, b) for a, b in announced[1:2] if not is_pending(a, b)]                        # the one after: before the tail read
                 self._pf = keep or None
                 self._finish_backbone(pf)                 # (a record whose backbone was deferred and never placed: now)
@@ -381,7 +400,7 @@ class PanopticFuseTrack(HipModule):
                     rl = self.neck.run(self.backbone.run(nhwc.from_nchw(ref_img, ws, 'ref_nhwc'), ws, 'rbb.'), ws, 'rfpn.')
                 ref_bsf = self.extra_neck.gather(rl, ws, 'neck.refcat').window(0, C)
                 self._mark('ref_backbone_fpn')
-            self._cache = dict(iid=iid, cat=cat, shape=(H, W), probe=self._probe(img))
+            self._cache = dict(iid=iid, cat=cat, shape=(H, W), probe=self._probe(img), slot=None if pf is None else pf.get('slot'))
             # (3) temporal fusion neck -------------------------------------------------------------------------------
             x, aux = self.extra_neck.run(levels, cat, ref_bsf, ws, 'neck.')
             self._mark('extra_neck')
@@ -406,6 +425,7 @@ class PanopticFuseTrack(HipModule):
             # a frame in which the GPU had least to do (idle 0.72 -> 0.38 ms per traced frame, profiles/r05_frame_occupancy_traced.json)
             # ... FlowNet2 (the long chain) here; its ResNet + FPN + gather (~4 ms on one stream) are placed in front of the end-of-frame read
             # instead: they carry the GPU across the frame boundary (host read, result assembly, the next call's first launches)
+            # (the neck is enqueued: the slot of the OLD cached feature is free again; `_cache` already names this frame's slot)
             self._pf = (self._pf or []) + [self._enqueue_image_stages(late[0][0], late[0][1], main, defer_backbone=self.defer_backbone)]
         # (5) RPN ------------------------------------------------------------------------------------------------
         nprop = None                          # device int32 [1]: rows of `proposals` that exist (None = all)
@@ -435,37 +455,45 @@ class PanopticFuseTrack(HipModule):
         self._mark('mask_head')
         # (9)-(11) MaskRemoval + SegTerm + combine: the kept list stays on the device -------------------------------
         last = self.mask_roi_panoptic.last
-        removal = self.mask_removal(last['rows_h'], last['rows_d'], mask_score, (H, W), ws, self.class_mapping)
-        if side is not None:
-            main.wait_event(sem_done)      # the combine kernel reads fcn_score; MaskRemoval's dependency chain above does not: it may
-                                           # run beside the end of the semantic head (prefetched work behind the event is not waited for)
-        pan, sem = panoptic_combine(fcn_score, removal, mask_score, self.panopticFPN.num_stuff_classes, self.panopticFPN.num_classes,
-                                    (H, W), ws)
-        h0, w0 = meta['img_shape'][0], meta['img_shape'][1]
-        pan = pan[:, 0:h0, 0:w0].clone(); sem = sem[:, 0:h0, 0:w0].clone()     # fresh tensors: the workspace is reused next frame
-        if self.int64_outputs:
-            pan, sem = pan.long(), sem.long()
-        self._mark('panoptic_combine')
-        # ---- the frame's END-OF-FRAME host read: kept list, ids, tracker memory size, fp16-range words (one D2H) ----------
         K = mask_rois.size(0)
-        tail = ws.get('frame.tail', (2 * MaskROI.KCAP + 8,), dtype=torch.int32, zero=False)
-        for r in self._pf or []:
-            self._finish_backbone(r)
         has_ids = self.with_track and not defer_tracking
-        st16 = nhwc.f16_status(dev)
-        hip.check(hip.load().vps_frame_tail(hip.ptr(removal['kinfo']), hip.ptr(removal['keep']), hip.ptr(det['ids_dev']) if has_ids else None,
-                                            hip.ptr(self._mem_count) if has_ids else None, hip.ptr(st16), st16.numel(), K, MaskROI.KCAP,
-                                            hip.ptr(tail), hip.stream_ptr()), 'vps_frame_tail')
-        th = tail.cpu().numpy()
-        if th[5]:
-            return None              # f16x3: a layer overflowed the fp16 range -> simple_test falls back and recomputes the frame
-        k, masks_valid, cstat = int(th[0]), bool(th[1]), int(th[2])
-        if cstat & 1:
-            raise hip.VpsHipError('vps_panoptic_combine: %d kept instances do not fit the uint8 panoptic map (at most %d)'
-                                  % (k, 255 - self.panopticFPN.num_stuff_classes))
-        if cstat & 4:
-            raise hip.VpsHipError('vps_mask_removal_dep: a box waited for a box it depends on beyond the spin limit (the frame is not valid); '
-                                  'VPS_MASK_REMOVAL=level selects the per-level launches')
+        for mr_try in (0, 1):
+            # second pass only after an expired dependency wait of the one-launch MaskRemoval (below): the per-level launches
+            removal = self.mask_removal(last['rows_h'], last['rows_d'], mask_score, (H, W), ws, self.class_mapping, force_level=mr_try == 1)
+            if side is not None:
+                main.wait_event(sem_done)  # the combine kernel reads fcn_score; MaskRemoval's dependency chain above does not: it may
+                                           # run beside the end of the semantic head (prefetched work behind the event is not waited for)
+            pan, sem = panoptic_combine(fcn_score, removal, mask_score, self.panopticFPN.num_stuff_classes, self.panopticFPN.num_classes,
+                                        (H, W), ws)
+            h0, w0 = meta['img_shape'][0], meta['img_shape'][1]
+            pan = pan[:, 0:h0, 0:w0].clone(); sem = sem[:, 0:h0, 0:w0].clone()     # fresh tensors: the workspace is reused next frame
+            if self.int64_outputs:
+                pan, sem = pan.long(), sem.long()
+            self._mark('panoptic_combine')
+            # ---- the frame's END-OF-FRAME host read: kept list, ids, tracker memory size, fp16-range words (one D2H) ----------
+            tail = ws.get('frame.tail', (2 * MaskROI.KCAP + 8,), dtype=torch.int32, zero=False)
+            for r in self._pf or []:
+                self._finish_backbone(r)
+            st16 = nhwc.f16_status(dev)
+            hip.check(hip.load().vps_frame_tail(hip.ptr(removal['kinfo']), hip.ptr(removal['keep']), hip.ptr(det['ids_dev']) if has_ids else None,
+                                                hip.ptr(self._mem_count) if has_ids else None, hip.ptr(st16), st16.numel(), K, MaskROI.KCAP,
+                                                hip.ptr(tail), hip.stream_ptr()), 'vps_frame_tail')
+            th = tail.cpu().numpy()
+            if th[5]:
+                return None              # f16x3: a layer overflowed the fp16 range -> simple_test falls back and recomputes the frame
+            k, masks_valid, cstat = int(th[0]), bool(th[1]), int(th[2])
+            if cstat & 1:
+                raise hip.VpsHipError('vps_panoptic_combine: %d kept instances do not fit the uint8 panoptic map (at most %d)'
+                                      % (k, 255 - self.panopticFPN.num_stuff_classes))
+            if not (cstat & 4):
+                break
+            # vps_mask_removal_dep: a box gave up waiting for a box it depends on (bounded spin: a wedged GPU is not an option - the
+            # API promises neither the dispatch order nor progress of the lower workgroups while three prefetch streams hold the CUs).
+            # The kept list of that pass is not valid: MaskRemoval + combine + the read are repeated through the per-level launches,
+            # which need no cross-workgroup waits (nothing else of the frame depends on them; `panoptic_ops.MR_RECOVERIES` counts)
+            if mr_try == 1:
+                raise hip.VpsHipError('MaskRemoval: status %d from the per-level launches' % cstat)
+            panoptic_ops.MR_RECOVERIES[0] += 1
         keep_inds = th[8:8 + k].astype(np.int64)
         det_obj_ids = None
         if has_ids:
@@ -513,7 +541,7 @@ class PanopticFuseTrack(HipModule):
             return 0
         return sum(w.nbytes() for w in [self._ws, self._lane] + self._ring) + self._ws.pool.total
 
-    def _enqueue_image_stages(self, nimg, nref, main, defer_backbone=False):
+    def _enqueue_image_stages(self, nimg, nref, main, defer_backbone=False, busy=()):
         """The image-only stages (FlowNet2, ResNet + FPN + gather) of a frame go to the prefetch streams: for the frame the NEXT call
         will be made with, before anything of the current frame is enqueued, so they run beside the current frame's neck and heads, not
         behind its semantic head - they are the longest chain (~16 ms of the frame's ~22 ms of kernel time) and the main / side
@@ -533,12 +561,25 @@ class PanopticFuseTrack(HipModule):
             self._pre = torch.cuda.Stream(device=dev)
             self._pre_aux = [torch.cuda.Stream(device=dev) for _ in range(2)]
         self._pre.wait_stream(main)
-        self._slot = (self._slot + 1) % 3
+        # the next ring slot that nothing still reads: not the slot of a record that waits for its consumer (`self._pf`, `busy` = the
+        # records the running call holds), and not the slot whose gathered feature is the cached reference feature the next neck reads
+        # (`_cache`: the prefetch streams are ordered behind what the main stream holds NOW - a neck enqueued later is not in that).
+        # The announced-clip schedule never finds its slot taken (ring of three: frame t+2 goes where frame t-1 was, behind neck(t));
+        # a caller whose announcements do not match what it passes can enqueue three frames in one call - the ring then grows.
+        taken = {r.get('slot') for r in list(self._pf or []) + list(busy) if r is not None}
+        if self._cache is not None:
+            taken.add(self._cache.get('slot'))
+        n = len(self._ring)
+        slot = next(((self._slot + i) % n for i in range(1, n + 1) if (self._slot + i) % n not in taken), None)
+        if slot is None:
+            self._ring.append(nhwc.Workspace(dev, pool=self._ws.pool))
+            slot = n
+        self._slot = slot
         lws = self._lane.with_out(self._ring[self._slot])
         bb_stream = self._pre_aux[0] if self.pre_streams >= 2 else self._pre
         sd_stream = self._pre_aux[1] if self.pre_streams >= 3 else None
         defer_backbone = defer_backbone and bb_stream is not self._pre
-        rec = dict(img=nimg, ref=nref, version=(nimg._version, nref._version), levels=None, cat=None, event2=None, bb_pending=None)
+        rec = dict(img=nimg, ref=nref, version=(nimg._version, nref._version), levels=None, cat=None, event2=None, bb_pending=None, slot=self._slot)
         if defer_backbone:
             after = torch.cuda.Event()
             after.record(main)

@@ -167,6 +167,7 @@ def load():
                                      c_double, c_void_p, c_void_p]
     lib.vps_mask_removal_dep.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                          c_double, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.vps_frame_tail.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.vps_mask_level.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                    c_void_p, c_double, c_void_p, c_void_p]
     lib.vps_panoptic_combine.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,

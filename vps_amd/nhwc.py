@@ -341,6 +341,10 @@ class PackedConv:
             self.pad_x = (padding, padding)
             cin_pad = _ceil(I, 4)
             self.korder = 1 if (cin_pad >= 64 or cin_pad % 32 == 0) and kh * kw > 1 else 0
+            if deform and self.korder == 0 and self.prec != hip.PREC_F32:
+                # a deformable layer with few input channels (tap-major k order; none on the path): the split-operand kernels take
+                # deformable layers in the chunk-major order only - such a layer runs on the exact-fp32 kernel (vps_conv2d, VPS_EARG 17)
+                self.prec = hip.PREC_F32
             blocks = [self._pack_taps(w.permute(0, 2, 3, 1).reshape(O, kh * kw, I), cin_pad)]
         else:
             I, O, kh, kw = w.shape
@@ -574,12 +578,11 @@ class PackedConv:
         if tiles < 256 and ksteps >= 8 and not getattr(self, 'small', False):
             ksplit = max(1, min((SPLITK_TARGET_BLOCKS + tiles - 1) // tiles, ksteps // 4, 32))
             ntap = self.KH * self.KW
-            halo = (self.prec != hip.PREC_F32 and not self.deform and self.stride == 1 and self.korder == 1 and self.KH == self.KW
-                    and self.KH in (2, 3) and x.N * ((d.Qh + 7) // 8) * ((d.Qw + 15) // 16) * 256 <= 3 * M)
-            if halo:
-                # the halo-staged kernel splits over whole 32-channel chunks: the largest divisor of the chunk count <= target
+            if self.korder == 1:
+                # chunk-major layers split over whole 32-channel chunks (vps_conv2d: `chunk_split`); the ranges may be uneven (the last
+                # split is shorter) - the largest count <= target that ceil-division of the chunk count reproduces
                 nch = ksteps // ntap
-                ksplit = max(k for k in range(1, ksplit + 1) if nch % k == 0)
+                ksplit = max(k for k in range(1, ksplit + 1) if -(-nch // -(-nch // k)) == k)
             else:
                 per = (ksteps + ksplit - 1) // ksplit
                 ksplit = (ksteps + per - 1) // per

@@ -21,6 +21,8 @@ from . import hip
 # 'single' = one workgroup per class walking its boxes in order (slowest; kept as the simplest statement of the loop)
 MASK_REMOVAL_MODE = os.environ.get('VPS_MASK_REMOVAL', 'dep')
 MASK_REMOVAL_SINGLE_LAUNCH = MASK_REMOVAL_MODE == 'single'
+# frames whose one-launch MaskRemoval reported an expired dependency wait and were finished through the per-level launches (detector.py)
+MR_RECOVERIES = [0]
 
 
 class MaskROI(nn.Module):
@@ -93,7 +95,7 @@ class MaskRemoval(nn.Module):
         super().__init__()
         self.fraction_threshold = fraction_threshold
 
-    def forward(self, rows_h, rows_d, mask_prob, im_shape, ws, class_mapping):
+    def forward(self, rows_h, rows_d, mask_prob, im_shape, ws, class_mapping, force_level=False):
         """rows_h / rows_d: the detection list (host numpy / device, [n,8]: 0,x1,y1,x2,y2,score,class,q), mask_prob [n,S,S] device.
         -> dict(inst: device vps_pan_inst table, kinfo: device int32 [4] = (k, masks_valid, status, -), keep: device int32 [n])"""
         dev = mask_prob.device
@@ -130,9 +132,11 @@ class MaskRemoval(nn.Module):
         sc = cls0[sorted_inds]
         x0 = np.maximum(sb[:, 0], 0); x1 = np.minimum(sb[:, 2] + 1, W); y0 = np.maximum(sb[:, 1], 0); y1 = np.minimum(sb[:, 3] + 1, H)
         area = np.maximum(x1 - x0, 0) * np.maximum(y1 - y0, 0)
-        dep_mode = MASK_REMOVAL_MODE == 'dep' and W % 4 == 0 and n <= MaskROI.KCAP
+        # (force_level: the detector's second pass after an expired dependency wait of the one-launch kernel)
+        dep_mode = MASK_REMOVAL_MODE == 'dep' and W % 4 == 0 and n <= MaskROI.KCAP and S <= 32 and not force_level
         lvl = np.zeros(n, dtype=np.int64)
-        if not dep_mode and not MASK_REMOVAL_SINGLE_LAUNCH:
+        single = MASK_REMOVAL_SINGLE_LAUNCH and not force_level
+        if not dep_mode and not single:
             # (the one-launch kernel finds a box's dependencies itself: this O(n^2) host loop sat on the frame's critical path with the
             # GPU idle - 0.26 ms in the traced frame, profiles/r05_frame_occupancy_traced.json before / after)
             for i in range(1, n):
@@ -155,7 +159,7 @@ class MaskRemoval(nn.Module):
                                                n, ncls, H, W, hip.ptr(occ), float(self.fraction_threshold), hip.ptr(flags), hip.ptr(done),
                                                ctypes.c_void_p(kinfo.data_ptr() + 8), sp), 'vps_mask_removal_dep')
             nlv = 0
-        elif MASK_REMOVAL_SINGLE_LAUNCH:
+        elif single:
             # A/B switch: the whole walk in ONE launch, one workgroup per class walking its boxes in order (csrc/pan_ops.hip)
             hip.check(lib.vps_mask_removal(hip.ptr(mp), S, ctypes.c_void_p(base), ctypes.c_void_p(base + 16 * n), ctypes.c_void_p(base + 20 * n),
                                            n, ncls, H, W, hip.ptr(occ), float(self.fraction_threshold), hip.ptr(flags), sp), 'vps_mask_removal')
