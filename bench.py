@@ -594,15 +594,17 @@ def main():
         nprod = nhwc.MFMA_PRODUCTS[nhwc.PREC_NAMES[args.prec]]
         pipe_peak = PEAK_FP32_MFMA_TFLOPS if args.prec == 'f32' else PEAK_BF16_MFMA_TFLOPS
         peak = pipe_peak / nprod
-        roof = dict(bound='mfma', kernel='conv_mfma_f32_kernel' if args.prec == 'f32' else 'conv_mfma_{h8,h8s2,bf16h,bf16q,bf16p,n16}_kernel + conv_thin_kernel <%s> (vps_conv2d family)' % args.prec,
+        roof = dict(bound='mfma', kernel='conv_mfma_f32_kernel' if args.prec == 'f32' else 'conv_mfma_{h8p,h8,h8s2,bf16h,bf16q,bf16p,n16}_kernel + conv_pw_kernel + conv_thin_kernel <%s> (vps_conv2d family)' % args.prec,
                     achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
                     mfma_products_per_fp32_product=nprod, matrix_pipe_executed_tflops=round(ach * nprod, 1),
                     matrix_pipe_peak=pipe_peak, matrix_pipe_frac=round(ach * nprod / pipe_peak, 4),
                     algorithmic_bytes_per_frame=round(abytes), launches_per_frame=nl, gflop_per_frame=round(fl / 1e9, 1),
-                    conv_ms_per_frame=round(ms, 3), avg_launch_us=round(1e3 * ms / max(nl, 1), 2))
+                    conv_ms_per_frame=round(ms, 3), avg_launch_us=round(1e3 * ms / max(nl, 1), 2),
+                    scope='SINGLE-STREAM figures: achieved / frac / conv_ms_per_frame are the conv launches of an instrumented one-stream frame summed '
+                          '(per-launch medians of 3 frames); the timed frame overlaps five streams, so conv_ms_per_frame may exceed ms_per_step')
         # HBM traffic of the conv kernels per frame: separate rocprofv3 --pmc passes (tools/pmc_traffic.py), not collectable from
         # inside this process; the newest committed measurement for this arithmetic mode is attached
-        for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
+        for rnd in ('r06', 'r05', 'r04', 'r03', 'r02', 'r01'):
             pmc = os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s.json' % (rnd, args.prec))
             if os.path.exists(pmc):
                 pj = json.load(open(pmc))

@@ -15,7 +15,9 @@ fp32-grade arithmetic mode (f32, bf16x6, f16x3). Measured values: profiles/r0[34
   detection scores            2e-3      <= 1.54e-3 on the dense fixture (absolute: they are probabilities behind a softmax)
   (round 6: 2e-3 -> 1e-3 for the neck and the semantic logits, 1.5e-3 for the box-head logits - the gate had 4x slack over the measured
   worst case and would not have caught a 2x regression; the scores stay: 1.54e-3 is measured, in every mode)
-  ResNet-101 (config 5), the stages BEHIND the FPN: neck 5e-3, fcn_score 9e-3, the rest 1e-2 (was 1e-2 throughout): the 101-layer
+  ResNet-101 (config 5), the stages BEHIND the FPN: neck 6e-3 (measured <= 4.5e-3), the rest 1e-2 (fcn_score measured 8.2e-3, scores
+  8.3e-3 - both in bf16x6, the mode with the SMALLEST per-product error: summation-order noise, it moves with every change of a split-K
+  partition): the 101-layer
   synthetic network amplifies the same fp32 noise ~5x, in the
   exact-fp32 kernels as much as in the split modes (neck 8.7e-4 .. 4.3e-3, fcn_score 2.5e-3 .. 8.0e-3, scores 4 .. 6e-3)
 
@@ -24,7 +26,7 @@ not which source proposal stands behind a detection - a boundary strip of single
 kernels included: dense 5e-3 (measured <= 2.6e-3), config5 1e-2 (measured <= 6e-3)."""
 
 STAGE = dict(flow=5e-5, fpn=5e-5, neck=1e-3, fcn_score=1e-3, cls_score=1.5e-3, bbox_pred=1.5e-3, score=2e-3)
-STAGE_R101 = dict(neck=5e-3, fcn_score=9e-3, cls_score=1e-2, bbox_pred=1e-2, score=1e-2)      # the stages behind the FPN of the 101-layer model
+STAGE_R101 = dict(neck=6e-3, fcn_score=1e-2, cls_score=1e-2, bbox_pred=1e-2, score=1e-2)      # the stages behind the FPN of the 101-layer model
 MAP = dict(sem=1e-3, pan=1e-3, pan_dense=5e-3, pan_config5=1e-2)
 
 

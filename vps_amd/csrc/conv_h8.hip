@@ -461,9 +461,13 @@ void conv_mfma_h8s2_kernel(const vps_conv_desc d, const int tiles_m, const int t
 
 }  // namespace
 
+int vpsi_launch_conv_h8p(const vps_conv_desc& d, int tiles_m8, int tiles_n, int chunks_per_split, long nblk8, hipStream_t s);
+
 // stride-1 K x K (K = 3, 2) layers with 128-column tiles: nblk8 blocks of 512 threads
 __attribute__((visibility("hidden")))
 void vpsi_launch_conv_h8(const vps_conv_desc& d, int tiles_m8, int tiles_n, int chunks_per_split, long nblk8, hipStream_t s) {
+    // f16x3: the pipelined instance (conv_h8p.hip, round 6)
+    if (vpsi_launch_conv_h8p(d, tiles_m8, tiles_n, chunks_per_split, nblk8, s)) return;
 #define VPS_H8_LAUNCH(MODE, K)                                                                                                   \
     hipLaunchKernelGGL((conv_mfma_h8_kernel<MODE, K, K>), dim3((unsigned)nblk8), dim3(512), 0, s, d, tiles_m8, tiles_n, chunks_per_split)
     if (d.prec == VPS_PREC_BF16) { if (d.KH == 3) VPS_H8_LAUNCH(VPS_PREC_BF16, 3); else VPS_H8_LAUNCH(VPS_PREC_BF16, 2); }
