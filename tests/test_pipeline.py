@@ -219,3 +219,45 @@ def test_native_png_decoder_equals_pil(tmp_path, mode, shape):
     assert png_decode(bytearray(open(pal, 'rb').read())) is None
     assert imread(pal).shape == (8, 9, 3)
     assert png_decode(bytearray(b'not a png at all, just thirty-three bytes.')) is None
+
+
+@pytest.mark.parametrize('C', [1, 3, 4])
+def test_native_png_decoder_every_filter_type_on_every_row_position(C):
+    """the un-filter loops of csrc/png_host.cpp (round 6: per-channel chains, branch-free Paeth predictor, thread-local scanline buffer)
+    on files written HERE with a chosen filter type per scanline (PNG specification 9.2: None, Sub, Up, Average, Paeth) - every type as
+    the FIRST row (no row above) and behind every other type, on noise (every predictor branch taken). Decoding twice through the same
+    thread re-uses its buffer; a second, larger image grows it."""
+    import struct
+    import zlib
+    from vps_amd.pipeline import png_decode
+
+    def paeth(a, b, c):
+        p = a + b - c
+        pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+        return a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+
+    def encode(img, types):
+        H, W = img.shape[:2]
+        rows = img.reshape(H, W * C).astype(np.int64)
+        raw = bytearray()
+        for y in range(H):
+            ft = types[y % len(types)]
+            cur, up = rows[y], rows[y - 1] if y else np.zeros(W * C, np.int64)
+            left = np.concatenate([np.zeros(C, np.int64), cur[:-C]])
+            ul = np.concatenate([np.zeros(C, np.int64), up[:-C]])
+            pred = {0: 0 * cur, 1: left, 2: up, 3: (left + up) >> 1, 4: np.array([paeth(a, b, c) for a, b, c in zip(left, up, ul)])}[ft]
+            raw.append(ft)
+            raw += ((cur - pred) & 255).astype(np.uint8).tobytes()
+        def chunk(t, d):
+            return struct.pack('>I', len(d)) + t + d + struct.pack('>I', zlib.crc32(t + d) & 0xFFFFFFFF)
+        ctype = {1: 0, 3: 2, 4: 6}[C]
+        return (b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', W, H, 8, ctype, 0, 0, 0)) +
+                chunk(b'IDAT', zlib.compress(bytes(raw), 6)) + chunk(b'IEND', b''))
+
+    rg = np.random.default_rng(C)
+    for (H, W), order in (((11, 19), [0, 1, 2, 3, 4]), ((11, 19), [4, 3, 2, 1, 0]), ((11, 19), [3, 4, 4, 1, 2, 0]), ((40, 70), [2, 4, 1, 3, 0, 4])):
+        img = rg.integers(0, 256, (H, W, C) if C > 1 else (H, W), dtype=np.uint8)
+        want = (np.repeat(img[:, :, None], 3, 2) if C == 1 else img[:, :, 2::-1][:, :, :3] if C == 3 else img[:, :, [2, 1, 0]])
+        for _ in range(2):
+            got = png_decode(encode(img, order))
+            assert got is not None and np.array_equal(got, want), (C, H, W, order)

@@ -17,10 +17,66 @@ namespace {
 
 inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]; }
 
-inline int paeth(int a, int b, int c) {
-    const int p = a + b - c;
-    const int pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
-    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+
+// the scanline buffer of a decoder thread, kept between calls (round 6): a fresh 6 MB malloc per frame is an mmap + 1500 page faults +
+// an munmap, and the decoder threads of a process queue on the address-space lock for them (8 threads decoded no faster than 6)
+struct RawBuf {
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    ~RawBuf() { free(p); }
+    uint8_t* get(size_t n) {
+        if (n > cap) {
+            free(p);
+            p = (uint8_t*)malloc(n);
+            cap = p ? n : 0;
+        }
+        return p;
+    }
+};
+thread_local RawBuf t_raw;
+
+// Paeth / Average rows of a C-byte pixel, C compile-time: the C channel chains are independent (instruction-level parallelism across
+// them; the chain along the row is inherent to the filter), predictor without the branchy three-way comparison
+template <int C>
+inline void unfilter_paeth(uint8_t* cur, const uint8_t* up, size_t stride) {
+    int a[C], c[C];
+    for (int k = 0; k < C; ++k) { a[k] = 0; c[k] = 0; }
+    for (size_t i = 0; i < stride; i += C) {
+        for (int k = 0; k < C; ++k) {
+            const int b = up[i + k];
+            const int p = b - c[k], pc0 = a[k] - c[k];
+            const int pa = abs(p), pb = abs(pc0), pc = abs(p + pc0);
+            int pred = pb < pa ? b : a[k];
+            const int pm = pb < pa ? pb : pa;
+            pred = pc < pm ? c[k] : pred;
+            const int v = (cur[i + k] + pred) & 255;
+            cur[i + k] = (uint8_t)v;
+            a[k] = v;
+            c[k] = b;
+        }
+    }
+}
+template <int C>
+inline void unfilter_avg(uint8_t* cur, const uint8_t* up, size_t stride) {
+    int a[C];
+    for (int k = 0; k < C; ++k) a[k] = 0;
+    for (size_t i = 0; i < stride; i += C)
+        for (int k = 0; k < C; ++k) {
+            const int v = (cur[i + k] + ((a[k] + (up ? up[i + k] : 0)) >> 1)) & 255;
+            cur[i + k] = (uint8_t)v;
+            a[k] = v;
+        }
+}
+template <int C>
+inline void unfilter_sub(uint8_t* cur, size_t stride) {
+    int a[C];
+    for (int k = 0; k < C; ++k) a[k] = 0;
+    for (size_t i = 0; i < stride; i += C)
+        for (int k = 0; k < C; ++k) {
+            const int v = (cur[i + k] + a[k]) & 255;
+            cur[i + k] = (uint8_t)v;
+            a[k] = v;
+        }
 }
 
 }  // namespace
@@ -50,11 +106,11 @@ extern "C" int vps_png_decode_bgr8(const uint8_t* file, int64_t nbytes, uint8_t*
     // above: ~17 GB) would be inflated only in part, with `avail_out == 0` reached early and uninitialised rows behind it.
     // Refused: the caller falls back to the general decoder. 1 GiB is > 100 frames of the path's size.
     if ((stride + 1) * (size_t)H > ((size_t)1 << 30)) return VPS_EARG(9);
-    uint8_t* raw = (uint8_t*)malloc((stride + 1) * (size_t)H);           // filter byte + pixels per scanline
+    uint8_t* raw = t_raw.get((stride + 1) * (size_t)H);                   // filter byte + pixels per scanline (the thread's buffer)
     if (!raw) return VPS_EARG(5);
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
-    if (inflateInit(&zs) != Z_OK) { free(raw); return VPS_EARG(6); }
+    if (inflateInit(&zs) != Z_OK) return VPS_EARG(6);
     zs.next_out = raw;
     zs.avail_out = (uInt)((stride + 1) * (size_t)H);
     int64_t pos = 8;
@@ -76,7 +132,7 @@ extern "C" int vps_png_decode_bgr8(const uint8_t* file, int64_t nbytes, uint8_t*
     }
     const bool complete = zs.avail_out == 0 && (zret == Z_STREAM_END || zret == Z_OK);
     inflateEnd(&zs);
-    if (!complete) { free(raw); return VPS_EARG(7); }
+    if (!complete) return VPS_EARG(7);
     // un-filter in place (PNG specification 9.2: None, Sub, Up, Average, Paeth; bytes of the pixel to the left = C bytes back)
     for (int y = 0; y < H; ++y) {
         uint8_t* cur = raw + (size_t)y * (stride + 1) + 1;
@@ -85,25 +141,22 @@ extern "C" int vps_png_decode_bgr8(const uint8_t* file, int64_t nbytes, uint8_t*
         switch (ft) {
             case 0: break;
             case 1:
-                for (size_t i = C; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - C]);
+                if (C == 3) unfilter_sub<3>(cur, stride); else if (C == 4) unfilter_sub<4>(cur, stride); else unfilter_sub<1>(cur, stride);
                 break;
             case 2:
                 if (up) for (size_t i = 0; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + up[i]);
                 break;
             case 3:
-                for (size_t i = 0; i < stride; ++i) {
-                    const int a = i >= (size_t)C ? cur[i - C] : 0, b = up ? up[i] : 0;
-                    cur[i] = (uint8_t)(cur[i] + ((a + b) >> 1));
-                }
+                if (C == 3) unfilter_avg<3>(cur, up, stride); else if (C == 4) unfilter_avg<4>(cur, up, stride); else unfilter_avg<1>(cur, up, stride);
                 break;
             case 4:
-                for (size_t i = 0; i < stride; ++i) {
-                    const int a = i >= (size_t)C ? cur[i - C] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)C) ? up[i - C] : 0;
-                    cur[i] = (uint8_t)(cur[i] + paeth(a, b, c));
-                }
+                if (!up) {                                   // first row: Paeth degenerates to Sub (b = c = 0 -> predictor a)
+                    if (C == 3) unfilter_sub<3>(cur, stride); else if (C == 4) unfilter_sub<4>(cur, stride); else unfilter_sub<1>(cur, stride);
+                } else if (C == 3) unfilter_paeth<3>(cur, up, stride);
+                else if (C == 4) unfilter_paeth<4>(cur, up, stride);
+                else unfilter_paeth<1>(cur, up, stride);
                 break;
             default:
-                free(raw);
                 return VPS_EARG(8);
         }
         uint8_t* o = out + (size_t)y * W * 3;
@@ -113,6 +166,5 @@ extern "C" int vps_png_decode_bgr8(const uint8_t* file, int64_t nbytes, uint8_t*
             for (int x = 0; x < W; ++x) { o[3 * x] = cur[(size_t)C * x + 2]; o[3 * x + 1] = cur[(size_t)C * x + 1]; o[3 * x + 2] = cur[(size_t)C * x]; }
         }
     }
-    free(raw);
     return 0;
 }
