@@ -4,6 +4,7 @@ container, with the import shims of ref_shims.py (third-party stubs + oracle-bac
 
     python tests/golden/make_golden.py [fusetrack|fuse|track]   # needs /root/reference; writes tests/golden/<variant>_clip.npz
     python tests/golden/make_golden.py fullsize                  # 2 frames at 1024x2048 -> tests/golden/fusetrack_fullsize.npz
+    python tests/golden/make_golden.py fullsize_cond             # the same on the well-conditioned synthetic checkpoint (every stage held to 1e-4)
     python tests/golden/make_golden.py fullsize_sep              # 4 frames at 1024x2048, fitted well-separated box classifier (strict fixture)
     python tests/golden/make_golden.py fullsize_dense            # 6 frames at 1024x2048, fitted dense box classifier (32..53 detections per frame, strict)
     python tests/golden/make_golden.py r101                      # ResNet-101 variant (BASELINE config 5), 2 frames at 128x256
@@ -32,7 +33,7 @@ H, W, NFRAMES, SEED = 128, 256, 3, 0
 FULL_H, FULL_W, FULL_NFRAMES = 1024, 2048, 2          # `fullsize`: the BASELINE frame size (configs[1]), FuseTrack only
 
 
-def main(variant='fusetrack', H=H, W=W, NFRAMES=NFRAMES, out_name=None, full=False, depth=None, seed=SEED, separated=False, head='separated_fc_cls.npz', map_stride=1):
+def main(variant='fusetrack', H=H, W=W, NFRAMES=NFRAMES, out_name=None, full=False, depth=None, seed=SEED, separated=False, head='separated_fc_cls.npz', map_stride=1, conditioned=False):
     """full=True: the 1024x2048 golden — same quantities, the dense stage tensors strided so the file stays a few MB"""
     import ref_shims
     mods = ref_shims.install()
@@ -48,7 +49,12 @@ def main(variant='fusetrack', H=H, W=W, NFRAMES=NFRAMES, out_name=None, full=Fal
     ours = vps_amd.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
     shapes = {k: tuple(v.shape) for k, v in ours.state_dict().items()}
     # separated=True: the box classification layer fitted by search_separated.py (every listing decision has a margin)
-    sd = synth.synth_state_dict(shapes, seed, overrides=synth.separated_overrides(os.path.join(HERE, head)) if separated else None)
+    over = synth.separated_overrides(os.path.join(HERE, head)) if separated else {}
+    if conditioned:
+        # the WELL-CONDITIONED synthetic checkpoint (vps_amd.synth.conditioned_overrides, tools/condition_search.py): fine flow, deformable
+        # offsets and attention logits scaled down so that the fp32 reference arithmetic itself is within ~1e-5 of its float64 evaluation
+        over.update(synth.conditioned_overrides(shapes, seed))
+    sd = synth.synth_state_dict(shapes, seed, overrides=over or None)
 
     # --- the reference detector; its __init__ loads FlowNet2 from cwd/work_dirs/flownet/FlowNet2_checkpoint.pth.tar ---
     tmp = tempfile.mkdtemp(prefix='vps_golden_')
@@ -158,6 +164,9 @@ if __name__ == '__main__':
         # the DENSE strict fixture: 6 frames at 1024x2048, 32..53 well-separated detections per frame (tests/golden/search_dense.py ->
         # dense_fc_cls.npz, chosen by oracle margins only)
         main('fusetrack', FULL_H, FULL_W, 6, 'fusetrack_fullsize_dense.npz', full=True, separated=True, head='dense_fc_cls.npz', map_stride=2)
+    elif v == 'fullsize_cond':
+        # 2 frames at 1024x2048 on the well-conditioned synthetic checkpoint: the fixture on which EVERY stage is held to 1e-4
+        main('fusetrack', FULL_H, FULL_W, FULL_NFRAMES, 'fusetrack_fullsize_cond.npz', full=True, conditioned=True)
     elif v == 'r101':
         main('fusetrack', H, W, 2, 'fusetrack_r101_clip.npz', depth=101)
     elif v == 'config5_sep':

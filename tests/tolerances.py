@@ -27,6 +27,9 @@ kernels included: dense 5e-3 (measured <= 2.6e-3), config5 1e-2 (measured <= 6e-
 
 STAGE = dict(flow=5e-5, fpn=5e-5, neck=1e-3, fcn_score=1e-3, cls_score=1.5e-3, bbox_pred=1.5e-3, score=2e-3)
 STAGE_R101 = dict(neck=6e-3, fcn_score=1e-2, cls_score=1e-2, bbox_pred=1e-2, score=1e-2)      # the stages behind the FPN of the 101-layer model
+# every stage tensor and every detection score on the WELL-CONDITIONED synthetic checkpoint (vps_amd.synth.conditioned_overrides; golden of the
+# real reference: tests/golden/fusetrack_fullsize_cond.npz) - the 1e-4 of BASELINE.md section 3
+CONDITIONED = 1e-4
 MAP = dict(sem=1e-3, pan=1e-3, pan_dense=5e-3, pan_config5=1e-2)
 
 

@@ -25,7 +25,7 @@ constexpr int PMODE = VPS_PREC_F16X3;
 
 template <int TN, bool HAS_RES, int NKU>
 __global__ __launch_bounds__(256, 2)
-void conv_pw_kernel(const vps_conv_desc d, const int M, const int tiles_m, const int tiles_n, const int nk, const int nit, const int ko) {
+void conv_pw_kernel(const vps_conv_desc d, const int M, const int tiles_m, const int tiles_n, const int nk, const int nit) {
     constexpr int TM = 2, WAVES_N = 2;
     constexpr int BN = WAVES_N * TN * 32;
     typedef Split<PMODE> SM;
@@ -79,7 +79,7 @@ void conv_pw_kernel(const vps_conv_desc d, const int M, const int tiles_m, const
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = tm * BM + r0 + 32 * i;
-            const bool ok = tm < tiles_m && m < M && !(ko & 2);
+            const bool ok = tm < tiles_m && m < M;
             unsigned pix = (unsigned)m;
             if (!plain) {
                 const int mm = ok ? m : 0;
@@ -95,7 +95,6 @@ void conv_pw_kernel(const vps_conv_desc d, const int M, const int tiles_m, const
     float amax = 0.f;
 
     auto load_A = [&](const int slot) {
-        if (ko & 32) return;
         const unsigned koff = (unsigned)lk * (BK * 4u);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -108,7 +107,6 @@ void conv_pw_kernel(const vps_conv_desc d, const int M, const int tiles_m, const
     };
     // this thread's 16-byte chunks c = t + 256 j of fragment f = c / 64 = wave + 4 j = (plane * 2 + slab) * (BN/32) + column block
     auto load_B = [&](const int slot) {
-        if (ko & 4) return;
 #pragma unroll
         for (int j = 0; j < NBL; ++j) {
             const int f = wave + 4 * j, bcol = f % (BN / 32), pm = f / (BN / 32);
@@ -118,8 +116,7 @@ void conv_pw_kernel(const vps_conv_desc d, const int M, const int tiles_m, const
     };
     auto store_A = [&](const int i, const int buf, const int slot) {
         x4 sp[NSA];
-        if (ko & 16) { struct two { x4 a, b; }; const two pp = __builtin_bit_cast(two, areg[slot][i]); sp[0] = pp.a; sp[1] = pp.b; }
-        else split_act<PMODE>(areg[slot][i], sp, amax);
+        split_act<PMODE>(areg[slot][i], sp, amax);
         const int row = r0 + 32 * i;
 #pragma unroll
         for (int p = 0; p < NSA; ++p)
@@ -171,7 +168,14 @@ void conv_pw_kernel(const vps_conv_desc d, const int M, const int tiles_m, const
     for (int j = 0; j < NBL; ++j) store_B(j, 0, 0);
     load_B(1);
     load_A(1);
-    load_B(0);
+    if constexpr (NKU == 2) {
+        // two k-steps: the weights of BOTH stay in the two weight buffers for the life of the block (a block keeps its column tile) -
+        // no weight request, no weight staging in the tile loop: half of the loop's vector-memory instructions and LDS stores
+#pragma unroll
+        for (int j = 0; j < NBL; ++j) store_B(j, 1, 1);
+    } else {
+        load_B(0);
+    }
     load_A(0);
     {
         // (distinct offsets past the end of any buffer the launcher admits: identical stores would be merged into one)
@@ -232,13 +236,18 @@ void conv_pw_kernel(const vps_conv_desc d, const int M, const int tiles_m, const
         auto work = [&](const int w) {
             if (w < 4) store_A(w, cur ^ 1, slot);
             else if (w == 4) {
+                if constexpr (NKU != 2) {
 #pragma unroll
-                for (int j = 0; j < (NBL + 1) / 2; ++j) store_B(j, cur ^ 1, slot);
+                    for (int j = 0; j < (NBL + 1) / 2; ++j) store_B(j, cur ^ 1, slot);
+                }
             } else if (w == 5) {
+                if constexpr (NKU != 2) {
 #pragma unroll
-                for (int j = (NBL + 1) / 2; j < NBL; ++j) store_B(j, cur ^ 1, slot);
-            } else if (w == 6) load_B(slot);
-            else load_A(slot);
+                    for (int j = (NBL + 1) / 2; j < NBL; ++j) store_B(j, cur ^ 1, slot);
+                }
+            } else if (w == 6) {
+                if constexpr (NKU != 2) load_B(slot);
+            } else load_A(slot);
         };
         int mf = 0;
 #pragma unroll
@@ -248,7 +257,7 @@ void conv_pw_kernel(const vps_conv_desc d, const int M, const int tiles_m, const
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
-                    if (!(ko & 8)) acc[a][b] = split_mfma<PMODE>(bf[SM::PB[q]][b], af[1][SM::PA[q]][a], acc[a][b]);
+                    acc[a][b] = split_mfma<PMODE>(bf[SM::PB[q]][b], af[1][SM::PA[q]][a], acc[a][b]);
                     ++mf;
 #pragma unroll
                     for (int w = 0; w < NW; ++w) {
@@ -261,7 +270,7 @@ void conv_pw_kernel(const vps_conv_desc d, const int M, const int tiles_m, const
                     }
                 }
         }
-        if (!(ko & 64)) __syncthreads();
+        __syncthreads();
     };
 
     // ---- epilogue on the transposed accumulators (conv_common.h): a lane owns pixel (lane & 31) of its TM sub-tiles and, per
@@ -278,7 +287,7 @@ void conv_pw_kernel(const vps_conv_desc d, const int M, const int tiles_m, const
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             const int m = tm * BM + wm * TM * 32 + a * 32 + prow;
-            const bool inside = tm < tiles_m && m < M && !(ko & 1);
+            const bool inside = tm < tiles_m && m < M;
             ooff[a] = inside ? (unsigned)m * ((unsigned)d.out_ld * 4u) + ocol4 : 0xFFFFFFF0u;
             roff[a] = 0xFFFFFFF0u;
             if constexpr (HAS_RES) {
@@ -412,7 +421,6 @@ int vpsi_launch_conv_pw(const vps_conv_desc& d, int M, int tiles_m, int tiles_n,
                   (size_t)d.N * (d.Ho >> d.res_shift) * (d.Wo >> d.res_shift) * d.res_ld * sizeof(float) >= 0xFFFFFE00ull)) return 0;
     if ((size_t)d.N * d.H * d.W * d.in_ld * sizeof(float) >= 0xFFFFFE00ull) return 0;
     const int tn = d.tile_n == 128 ? 2 : 1;
-    const int ko = getenv("VPS_PW_KO") ? atoi(getenv("VPS_PW_KO")) : 0;
     const int resident = pw_resident(tn);
     const long total = (long)tiles_m * tiles_n;
     const int unit = 8 * tiles_n;                              // a grid is whole groups of (8 XCDs x the column tiles)
@@ -424,7 +432,7 @@ int vpsi_launch_conv_pw(const vps_conv_desc& d, int M, int tiles_m, int tiles_n,
     if (grid > resident) grid = resident / unit * unit;
     const int mper = (int)(grid / unit);
     const int nit = (tiles_m + mper * 8 - 1) / (mper * 8);
-#define VPS_PW_LAUNCH(TNV, RESV, NKV) hipLaunchKernelGGL((conv_pw_kernel<TNV, RESV, NKV>), dim3((unsigned)grid), dim3(256), 0, s, d, M, tiles_m, tiles_n, nk, nit, ko)
+#define VPS_PW_LAUNCH(TNV, RESV, NKV) hipLaunchKernelGGL((conv_pw_kernel<TNV, RESV, NKV>), dim3((unsigned)grid), dim3(256), 0, s, d, M, tiles_m, tiles_n, nk, nit)
 #define VPS_PW_NK(TNV, RESV)                                         \
     do {                                                             \
         if (nk == 2) VPS_PW_LAUNCH(TNV, RESV, 2);                    \
