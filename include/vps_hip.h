@@ -190,6 +190,10 @@ int vps_bfp_gather(const float* const* levels, const int* ld, const int* ratio, 
 /* BFP scatter: out = adaptive_max_pool2d(bsf, (H0/ratio, W0/ratio)) + level. ref: bfp_tcea.py:139-147 */
 int vps_bfp_scatter(const float* bsf, int bsf_ld, const float* level, int lvl_ld, float* out, int out_ld,
                     int N, int H0, int W0, int C, int ratio, void* stream);
+/* the same for ALL levels in one pass over bsf (round 6): level l = adaptive_max_pool2d(bsf, (H0 >> l, W0 >> l)) + levels[l], l < nlevels
+ * (2..5; ratio 2^l), H0 and W0 multiples of 2^(nlevels-1), C a multiple of 32. Bitwise vps_bfp_scatter per level; bsf is read once. */
+int vps_bfp_scatter_all(const float* bsf, int bsf_ld, const float* const* levels, const int* lvl_ld, float* const* outs,
+                        const int* out_ld, int nlevels, int N, int H0, int W0, int C, void* stream);
 /* y = x*a + b elementwise over a slice (used for flow scaling) */
 int vps_axpb(const float* in, int in_ld, int in_coff, float* out, int out_ld, int out_coff,
              int64_t npix, int C, float a, float b, void* stream);

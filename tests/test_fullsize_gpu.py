@@ -280,9 +280,14 @@ def test_full_size_outputs_match_reference_golden(dev, prec_name):
 GOLD_COND = os.path.join(ROOT, 'tests', 'golden', 'fusetrack_fullsize_cond.npz')
 
 
-@pytest.mark.parametrize('prec_name', ['f16x3', 'bf16x6', 'f32'])
+# bf16x3 (bf16 operands, three bf16 MFMAs per product, fp32 accumulate: 2^-16 per product, no range limit) is the bf16-operand scheme
+# BASELINE config 5 words ("bf16 in / fp32 acc") that holds a STATED tolerance: 5e-4 on every stage (measured <= 2.5e-4, scores 9e-6,
+# every detection and proposal matched); plain one-product bf16 is 1e-2 at the FPN and loses the proposal list
+# (profiles/r06_fullsize_conditioned_bf16_bf16x3_report.txt).
+@pytest.mark.parametrize('prec_name', ['f16x3', 'bf16x6', 'f32', 'bf16x3'])
 def test_every_stage_within_1e_4_of_the_reference_on_the_conditioned_checkpoint(dev, prec_name):
     g = np.load(GOLD_COND)
+    tol = T.CONDITIONED_BF16X3 if prec_name == 'bf16x3' else T.CONDITIONED
     gh, gw, n, seed = [int(v) for v in g['meta']]
     assert (gh, gw) == (H, W)
     s1, s2, c5 = [int(v) for v in g['strides']]
@@ -338,7 +343,7 @@ def test_every_stage_within_1e_4_of_the_reference_on_the_conditioned_checkpoint(
                      'panoptic class-map mismatch %.5f%% sem mismatch %.5f%%' % (prec_name, t, {k: '%.2e' % v for k, v in stage.items()}, int((~good).sum()),
                                                                               len(r['panoptic_cls_inds']), len(gc), unmatched, 100 * dcls, 100 * dsem))
         print(lines[-1])
-        fails += ['f%d %s %.2e' % (t, k, v) for k, v in stage.items() if not v < T.CONDITIONED]
+        fails += ['f%d %s %.2e' % (t, k, v) for k, v in stage.items() if not v < tol]
         if unmatched > 1 or int((~good).sum()) > 30:
             fails.append('f%d detections: %d unmatched, proposals %d unmatched' % (t, unmatched, int((~good).sum())))
         if not (dsem < 1e-3 and dcls < (1e-3 if unmatched == 0 else 2e-2)):

@@ -413,6 +413,27 @@ def test_bfp_gather_scatter(dev):
         _cmp(o.to_nchw(), r, rtol=1e-6, atol=1e-6, what='scatter %d' % i)
 
 
+@pytest.mark.parametrize('C,H,W,L', [(256, 64, 128, 5), (32, 16, 48, 5), (64, 24, 40, 4), (32, 8, 12, 3), (96, 2, 6, 2)])
+def test_bfp_scatter_all_levels_in_one_pass_is_bitwise_the_level_launches(dev, C, H, W, L):
+    """vps_bfp_scatter_all (round 6: one pass over the refined map, 2 x 2 maxima level by level through LDS) against vps_bfp_scatter per
+    level (bfp_tcea.py:139-147) - bitwise, values with ties, negative zeros and one -inf included; shapes it does not take are handed back"""
+    g = torch.Generator().manual_seed(C + H)
+    bsf = (torch.randn(1, H, W, C, generator=g) * 4).round() / 4                                # quarter steps: ties between window members
+    bsf[0, 0, 0, :4] = -0.0; bsf[0, 0, 1, :4] = 0.0; bsf[0, 1, 1, 5] = float('-inf')
+    x = nhwc.FMap(bsf.to(dev).contiguous())
+    lv = [nhwc.FMap(torch.randn(1, H >> l, W >> l, C, generator=g).to(dev)) for l in range(L)]
+    ws = nhwc.Workspace(dev)
+    one = [ws.fmap('a%d' % l, 1, H >> l, W >> l, C) for l in range(L)]
+    sep = [nhwc.bfp_scatter(x, lv[l], ws.fmap('b%d' % l, 1, H >> l, W >> l, C)) for l in range(L)]
+    assert nhwc.bfp_scatter_all(x, lv, one) is one
+    torch.cuda.synchronize()
+    for l in range(L):
+        assert torch.equal(one[l].t, sep[l].t), l
+    # not the kernel's shapes: odd cell count / channel count that is no multiple of 32 -> None, nothing launched
+    assert nhwc.bfp_scatter_all(nhwc.FMap(torch.zeros(1, 24, 40, 64, device=dev)), [nhwc.FMap(torch.zeros(1, 24 >> l, 40 >> l, 64, device=dev)) for l in range(5)],
+                                [nhwc.FMap(torch.zeros(1, 24 >> l, 40 >> l, 64, device=dev)) for l in range(5)]) is None
+
+
 @pytest.mark.parametrize('C,H,W,coff', [(256, 16, 24, 0), (256, 9, 7, 64), (64, 5, 33, 4)])
 def test_tcea_temporal_and_modulate(dev, C, H, W, coff):
     """utils/tcea_modules.py:56-66 (per-frame correlation with the centre embedding -> sigmoid -> scale the frame) and :76-77

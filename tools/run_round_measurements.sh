@@ -3,10 +3,13 @@
 #   SKIP_PYTEST=1 skips the GPU test suite (run it in its own call: it takes ~10 of the 90 GPU-minutes), WITH_VPQ=1 adds the two
 #   60-frame VPQ runs (profiles/r04_vpq_attribution.json holds the numbers from tools/vpq_attribution.py)
 # Every command sits under its own `timeout`: a hung counter pass must not take the rest of the call with it.
-mkdir -p gpurun_out; R=$PWD; T=${TAG:-r05}
+mkdir -p gpurun_out; R=$PWD; T=${TAG:-r06}
 if [ -z "$SKIP_PYTEST" ]; then timeout 1500 python -m pytest tests -m gpu -q --tb=short -rf -p no:cacheprovider > gpurun_out/${T}_pytest_gpu.log 2>&1; tail -6 gpurun_out/${T}_pytest_gpu.log; fi
 timeout 900 python bench.py --steps 100 --warmup 5 --conv-table gpurun_out/${T}_conv_table_f16x3.txt > gpurun_out/${T}_bench_default_f16x3.json 2> gpurun_out/${T}_bench.err; head -c 200 gpurun_out/${T}_bench_default_f16x3.json; echo
-timeout 300 python bench.py --model-config configs/viper/fusetrack_r101.py --height 1088 --width 1920 --prec f16x3 --steps 40 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/${T}_bench_config5_r101_1088x1920_f16x3.json 2>> gpurun_out/${T}_bench.err; head -c 200 gpurun_out/${T}_bench_config5_r101_1088x1920_f16x3.json; echo
+# BASELINE config 5 (ResNet-101, 1088x1920): the fp32-grade mode, the bf16-operand mode that holds a stated tolerance (bf16x3) and plain bf16
+for P in f16x3 bf16x3 bf16; do timeout 300 python bench.py --model-config configs/viper/fusetrack_r101.py --height 1088 --width 1920 --prec $P --steps 40 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/${T}_bench_config5_r101_1088x1920_$P.json 2>> gpurun_out/${T}_bench.err; head -c 120 gpurun_out/${T}_bench_config5_r101_1088x1920_$P.json; echo; done
+# the host side of an 8-GPU node: 8 rank processes x 4 decode threads, pinned (tools/bench_input_pipeline.py --node)
+timeout 200 python tools/bench_input_pipeline.py --node 8 --threads 4 --seconds 8 > gpurun_out/${T}_node_decode_8x4.json 2>> gpurun_out/${T}_bench.err
 # the 2-rank clip pipeline, functionally (bench.py launches itself under torch.distributed.run): two processes on the ONE GPU of this box over gloo (NOT RCCL, no scaling number): the
 # streamed records / maps / hand-off with the real DetectorBackend; its clip30 id_checksum must equal the 1-rank run's
 VPS_BENCH_BACKEND=gloo timeout 400 python bench.py --gpus 2 --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/${T}_bench_2rank_gloo_one_gpu.json 2>> gpurun_out/${T}_bench.err

@@ -157,6 +157,61 @@ void bfp_scatter_kernel(const float* __restrict__ bsf, int bsf_ld, const float* 
     }
 }
 
+// The same for ALL levels of the pyramid in one pass (round 6): the five per-level launches read the full-resolution map five times
+// (1.03 GB per frame at 256x512x256); here a block owns a 2^(L-1) x 2^(L-1) cell of it (16 x 16 for five levels) x 32 channels, reads
+// it ONCE, writes level 0 and reduces 2 x 2 windows level by level through LDS - a maximum does not depend on the order it is taken
+// in, so the outputs are bitwise those of bfp_scatter_kernel. Thread = (pixel, 4-channel group) with the group fastest: 8 threads
+// cover the 128 bytes of a pixel's 32 channels.
+struct ScatterAll {
+    const float* lvl[5];
+    float* out[5];
+    int lvl_ld[5], out_ld[5];
+};
+template <int NL>
+__global__ __launch_bounds__(256)
+void bfp_scatter_all_kernel(const float* __restrict__ bsf, int bsf_ld, const ScatterAll a, int N, int H0, int W0, int C) {
+    constexpr int T = 1 << (NL - 1);                 // cell edge at level 0
+    __shared__ f32x4 buf[2][T * T * 8];              // [level parity][cell position][4-channel group]
+    const int t = threadIdx.x, q = t & 7, p0 = t >> 3;
+    const int cgroups = C >> 5, cells_x = W0 / T, cells_y = H0 / T;
+    long b = blockIdx.x;
+    const int cg = (int)(b % cgroups); b /= cgroups;
+    const int cx = (int)(b % cells_x); b /= cells_x;
+    const int cy = (int)(b % cells_y); const int n = (int)(b / cells_y);
+    const int c = cg * 32 + 4 * q;
+    // ---- level 0: T*T pixels, 32 per pass
+    for (int p = p0; p < T * T; p += 32) {
+        const int py = p / T, px = p - py * T;
+        const size_t pix = ((size_t)n * H0 + cy * T + py) * W0 + cx * T + px;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(bsf + pix * bsf_ld + c);
+        const f32x4 l = *reinterpret_cast<const f32x4*>(a.lvl[0] + pix * a.lvl_ld[0] + c);
+        *reinterpret_cast<f32x4*>(a.out[0] + pix * a.out_ld[0] + c) = v + l;
+        buf[0][p * 8 + q] = v;
+    }
+    __syncthreads();
+    int e = T;                                       // edge of the source level inside the cell
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+        const int eo = e >> 1, Hl = H0 >> l, Wl = W0 >> l;
+        const f32x4* __restrict__ src = buf[(l - 1) & 1];
+        f32x4* __restrict__ dst = buf[l & 1];
+        for (int p = p0; p < eo * eo; p += 32) {
+            const int py = p / eo, px = p - py * eo;
+            const f32x4 v0 = src[((2 * py) * e + 2 * px) * 8 + q], v1 = src[((2 * py) * e + 2 * px + 1) * 8 + q];
+            const f32x4 v2 = src[((2 * py + 1) * e + 2 * px) * 8 + q], v3 = src[((2 * py + 1) * e + 2 * px + 1) * 8 + q];
+            f32x4 m;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m[k] = fmaxf(fmaxf(v0[k], v1[k]), fmaxf(v2[k], v3[k]));
+            const size_t pix = ((size_t)n * Hl + cy * eo + py) * Wl + cx * eo + px;
+            const f32x4 lv = *reinterpret_cast<const f32x4*>(a.lvl[l] + pix * a.lvl_ld[l] + c);
+            *reinterpret_cast<f32x4*>(a.out[l] + pix * a.out_ld[l] + c) = m + lv;
+            dst[p * 8 + q] = m;
+        }
+        __syncthreads();
+        e = eo;
+    }
+}
+
 __global__ __launch_bounds__(256)
 void axpb_kernel(const float* __restrict__ in, int in_ld, int in_coff, float* __restrict__ out, int out_ld, int out_coff,
                  long npix, int C, float a, float b) {
@@ -429,6 +484,30 @@ extern "C" int vps_bfp_scatter(const float* bsf, int bsf_ld, const float* level,
         return VPS_EARG(1);
     hipLaunchKernelGGL(bfp_scatter_kernel, dim3(stream_grid((long)N * (H0 / ratio) * (W0 / ratio) * (C >> 2), 256)),
                        dim3(256), 0, (hipStream_t)stream, bsf, bsf_ld, level, lvl_ld, out, out_ld, N, H0, W0, C, ratio);
+    return vps_launch_status();
+}
+
+extern "C" int vps_bfp_scatter_all(const float* bsf, int bsf_ld, const float* const* levels, const int* lvl_ld, float* const* outs,
+                                   const int* out_ld, int nlevels, int N, int H0, int W0, int C, void* stream) {
+    if (!bsf || !levels || !lvl_ld || !outs || !out_ld || N <= 0 || H0 <= 0 || W0 <= 0) return VPS_EARG(1);
+    // level l has ratio 2^l; whole cells; 32-channel groups; float4 rows
+    if (nlevels < 2 || nlevels > 5 || (C & 31) || (bsf_ld & 3) || H0 % (1 << (nlevels - 1)) || W0 % (1 << (nlevels - 1))) return VPS_EARG(2);
+    ScatterAll a;
+    for (int l = 0; l < 5; ++l) {
+        const int k = l < nlevels ? l : nlevels - 1;
+        if (!levels[k] || !outs[k] || (lvl_ld[k] & 3) || (out_ld[k] & 3)) return VPS_EARG(3);
+        a.lvl[l] = levels[k]; a.out[l] = outs[k]; a.lvl_ld[l] = lvl_ld[k]; a.out_ld[l] = out_ld[k];
+    }
+    const int T = 1 << (nlevels - 1);
+    const long nblk = (long)N * (H0 / T) * (W0 / T) * (C >> 5);
+    if (nblk > 0x7fffffffL) return VPS_EARG(4);
+    hipStream_t s = (hipStream_t)stream;
+    switch (nlevels) {
+        case 5: hipLaunchKernelGGL(bfp_scatter_all_kernel<5>, dim3((unsigned)nblk), dim3(256), 0, s, bsf, bsf_ld, a, N, H0, W0, C); break;
+        case 4: hipLaunchKernelGGL(bfp_scatter_all_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, s, bsf, bsf_ld, a, N, H0, W0, C); break;
+        case 3: hipLaunchKernelGGL(bfp_scatter_all_kernel<3>, dim3((unsigned)nblk), dim3(256), 0, s, bsf, bsf_ld, a, N, H0, W0, C); break;
+        default: hipLaunchKernelGGL(bfp_scatter_all_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, s, bsf, bsf_ld, a, N, H0, W0, C); break;
+    }
     return vps_launch_status();
 }
 

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VPS_HIP_LIB: developer override to load an experimental build of the same ABI (kernel A/B timing)
 LIB_PATH = os.environ.get('VPS_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libvpship.so')
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
@@ -23,7 +23,7 @@ PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
 SYMBOLS = [
     'vps_abi_version', 'vps_build_info', 'vps_conv2d', 'vps_resample2d', 'vps_channelnorm', 'vps_correlation',
     'vps_flow_warp', 'vps_nchw_to_nhwc', 'vps_nhwc_to_nchw', 'vps_resize', 'vps_pool3x3s2', 'vps_bfp_gather',
-    'vps_bfp_scatter', 'vps_axpb', 'vps_flow_prep', 'vps_flow_prep_pad', 'vps_flow_stage', 'vps_flow_stage_full', 'vps_groupnorm_relu', 'vps_groupnorm_apply', 'vps_tcea_temporal',
+    'vps_bfp_scatter', 'vps_bfp_scatter_all', 'vps_axpb', 'vps_flow_prep', 'vps_flow_prep_pad', 'vps_flow_stage', 'vps_flow_stage_full', 'vps_groupnorm_relu', 'vps_groupnorm_apply', 'vps_tcea_temporal',
     'vps_tcea_modulate', 'vps_tcea_modulate_ld', 'vps_correlation_f16', 'vps_roi_align', 'vps_nms_batched', 'vps_delta2bbox', 'vps_bbox_overlaps',
     'vps_row_softmax', 'vps_mask_count', 'vps_mask_commit', 'vps_mask_removal', 'vps_mask_removal_dep', 'vps_frame_tail', 'vps_mask_level', 'vps_panoptic_combine',
     'vps_panoptic_combine_dev', 'vps_rpn_select', 'vps_rpn_collect', 'vps_maskroi_select', 'vps_maskroi_finish', 'vps_track_assign', 'vps_pan_instances',
@@ -134,6 +134,8 @@ def load():
                                    c_int, c_int, c_int, c_int, c_void_p]
     lib.vps_bfp_scatter.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                     c_int, c_void_p]
+    lib.vps_bfp_scatter_all.argtypes = [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), POINTER(c_int), c_int, c_int, c_int,
+                                        c_int, c_int, c_void_p]
     lib.vps_axpb.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int64, c_int, c_float, c_float,
                              c_void_p]
     lib.vps_flow_prep.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,

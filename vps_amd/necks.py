@@ -4,12 +4,17 @@ Mirrors mmdet/models/necks/fpn.py:10-139, extra_necks/bfp_tcea.py:13-149, utils/
 flow_modules/flow_modules.py:37-148 (OpticalFlowEstimatorCorr / LiteFlowNetCorr / WarpingLayer) at the
 parameter-name level.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from . import hip, nhwc
 from .base import HipModule
 from .registry import EXTRA_NECKS, NECKS
+
+# VPS_SCATTER_ALL=0: BFP scatter level by level (five passes over the refined map) instead of vps_bfp_scatter_all (A/B; bitwise equal)
+SCATTER_ALL = os.environ.get('VPS_SCATTER_ALL', '1') != '0'
 
 
 class _ConvModule(nn.Module):
@@ -181,8 +186,10 @@ class BFPTcea(HipModule):
         fused = nhwc.tcea_modulate(fea, att, add, T('fused', C))
         ws.release(fa, att, add)
         refined = self._refine(fused, ws=ws, name=tag + 'refined', temp=True)
-        outs = [nhwc.bfp_scatter(refined, lv, ws.fmap('%sout%d' % (tag, i), lv.N, lv.H, lv.W, C))
-                for i, lv in enumerate(levels)]
+        outs = [ws.fmap('%sout%d' % (tag, i), lv.N, lv.H, lv.W, C) for i, lv in enumerate(levels)]
+        if not (SCATTER_ALL and nhwc.bfp_scatter_all(refined, levels, outs)):                  # one pass over `refined` (round 6)
+            for lv, o in zip(levels, outs):
+                nhwc.bfp_scatter(refined, lv, o)
         ws.release(flow_fine, warp2, fused, refined)
         return outs, dict(flow_fine=flow_fine, warp=warp2, fused=fused, refined=refined)
 

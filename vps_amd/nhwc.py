@@ -726,6 +726,20 @@ def bfp_gather(levels, out):
     return out
 
 
+def bfp_scatter_all(bsf, levels, outs):
+    """every level of the pyramid in one pass over `bsf` (vps_bfp_scatter_all); -> outs, or None when the shapes are not the kernel's
+    (level l at ratio 2^l, whole 2^(L-1) cells, C % 32 == 0): the caller then scatters level by level"""
+    L = len(levels)
+    if not (2 <= L <= 5 and bsf.C % 32 == 0 and bsf.coff == 0 and all(lv.coff == 0 and o.coff == 0 for lv, o in zip(levels, outs))
+            and bsf.H % (1 << (L - 1)) == 0 and bsf.W % (1 << (L - 1)) == 0
+            and all(lv.H == bsf.H >> l and lv.W == bsf.W >> l and lv.C == bsf.C for l, lv in enumerate(levels))):
+        return None
+    lp = (ctypes.c_void_p * L)(*[lv.t.data_ptr() for lv in levels]); op = (ctypes.c_void_p * L)(*[o.t.data_ptr() for o in outs])
+    ll = (ctypes.c_int * L)(*[lv.ld for lv in levels]); ol = (ctypes.c_int * L)(*[o.ld for o in outs])
+    hip.check(hip.load().vps_bfp_scatter_all(bsf.ptr(), bsf.ld, lp, ll, op, ol, L, bsf.N, bsf.H, bsf.W, bsf.C, hip.stream_ptr()), 'vps_bfp_scatter_all')
+    return outs
+
+
 def bfp_scatter(bsf, level, out):
     assert bsf.coff == 0 and level.coff == 0 and out.coff == 0
     hip.check(hip.load().vps_bfp_scatter(bsf.ptr(), bsf.ld, level.ptr(), level.ld, out.ptr(), out.ld, bsf.N, bsf.H, bsf.W,
