@@ -413,6 +413,67 @@ def test_bfp_gather_scatter(dev):
         _cmp(o.to_nchw(), r, rtol=1e-6, atol=1e-6, what='scatter %d' % i)
 
 
+@pytest.mark.parametrize('cin,cout,H,W', [(162, 16, 128, 256), (82, 12, 120, 250), (64, 8, 128, 256)])
+def test_transposed_16_column_layer_with_the_four_classes_in_one_block_is_bitwise_the_class_launches(dev, cin, cout, H, W):
+    """conv_mfma_n16t_kernel (round 6: a stride-2 transposed 4x4 layer with <= 16 output channels - FlowNetFusion deconv0 - stages its
+    input patch once for all four parity classes) against the four class launches of conv_mfma_n16_kernel (VPS_N16T=0) - bitwise - and
+    against F.conv_transpose2d; ragged patches, channel counts that are no multiple of 32 / 4 included"""
+    w = _rand(cin, cout, 4, 4, seed=3, scale=(2.0 / (cin * 4)) ** 0.5)
+    b = _rand(cout, seed=4, scale=0.1)
+    x = _rand(1, cin, H, W, seed=5)
+    ref = F.leaky_relu(F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=1), 0.1).float()
+    pc = nhwc.PackedConv(w, b, None, stride=2, padding=1, act=hip.ACT_LEAKY, transposed=True, device=dev, prec=hip.PREC_F16X3)
+    xin = nhwc.from_nchw(x.to(dev))
+    outs = {}
+    old = os.environ.get('VPS_N16T')
+    try:
+        for mode in ('0', '1'):
+            os.environ['VPS_N16T'] = mode
+            pc.__dict__.pop('_dcache', None)
+            o = pc(xin, ws=nhwc.Workspace(dev), name='o')
+            torch.cuda.synchronize()
+            outs[mode] = o.t.clone()
+            _cmp(o.to_nchw(), ref, rtol=2e-5, atol=2e-5 * max(1.0, float(ref.abs().max()) / 4), what='transposed 16-column layer, VPS_N16T=' + mode)
+    finally:
+        if old is None:
+            os.environ.pop('VPS_N16T', None)
+        else:
+            os.environ['VPS_N16T'] = old
+    assert torch.equal(outs['0'], outs['1'])
+
+
+@pytest.mark.parametrize('cin,cout,k,tr,H,W', [(162, 32, 3, False, 128, 256), (100, 20, 3, False, 120, 250), (128, 32, 4, True, 128, 256), (64, 24, 3, False, 128, 256)])
+def test_17_to_32_column_layers_on_the_two_column_block_kernel(dev, cin, cout, k, tr, H, W):
+    """conv_mfma_n32_kernel (round 6: FlowNetFusion's 162->32 3x3 @512x1024 and 128->32 transposed layers - the 16-column structure with two
+    column blocks per wave) against torch in fp64, and against the 32-column halo kernel it replaces (VPS_N32=0) at the fp32-grade tolerance
+    (the two accumulate in different orders); ragged patches and channel counts off the 32 / 16 grid included"""
+    w = _rand(*((cin, cout, k, k) if tr else (cout, cin, k, k)), seed=3, scale=(2.0 / (cin * (4 if tr else 9))) ** 0.5)
+    b = _rand(cout, seed=4, scale=0.1)
+    x = _rand(1, cin, H, W, seed=5)
+    if tr:
+        ref = F.leaky_relu(F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=1), 0.1).float()
+    else:
+        ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), 0.1).float()
+    pc = nhwc.PackedConv(w, b, None, stride=2 if tr else 1, padding=1, act=hip.ACT_LEAKY, transposed=tr, device=dev, prec=hip.PREC_F16X3)
+    xin = nhwc.from_nchw(x.to(dev))
+    outs = {}
+    old = os.environ.get('VPS_N32')
+    try:
+        for mode in ('0', '1'):
+            os.environ['VPS_N32'] = mode
+            pc.__dict__.pop('_dcache', None)
+            o = pc(xin, ws=nhwc.Workspace(dev), name='o')
+            torch.cuda.synchronize()
+            outs[mode] = o.to_nchw().cpu()
+            _cmp(outs[mode], ref, rtol=2e-5, atol=2e-5 * max(1.0, float(ref.abs().max()) / 4), what='17..32-column layer, VPS_N32=' + mode)
+    finally:
+        if old is None:
+            os.environ.pop('VPS_N32', None)
+        else:
+            os.environ['VPS_N32'] = old
+    assert float((outs['0'] - outs['1']).abs().max()) <= 4e-6 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize('C,H,W,L', [(256, 64, 128, 5), (32, 16, 48, 5), (64, 24, 40, 4), (32, 8, 12, 3), (96, 2, 6, 2)])
 def test_bfp_scatter_all_levels_in_one_pass_is_bitwise_the_level_launches(dev, C, H, W, L):
     """vps_bfp_scatter_all (round 6: one pass over the refined map, 2 x 2 maxima level by level through LDS) against vps_bfp_scatter per

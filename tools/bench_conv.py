@@ -33,6 +33,8 @@ SHAPES = [  # name, cin, cout, k, stride, pad, H, W, transposed, deform
     ('flownet predict_flow2 194->2 3x3 @256x512', 194, 2, 3, 1, 1, 256, 512, False, False),
     ('fusion deconv0 162->16 4x4 @512x1024', 162, 16, 4, 2, 1, 512, 1024, True, False),
     ('fusion interconv0 82->16 3x3 @1024x2048', 82, 16, 3, 1, 1, 1024, 2048, False, False),
+    ('fusion interconv1 162->32 3x3 @512x1024', 162, 32, 3, 1, 1, 512, 1024, False, False),
+    ('fusion deconv1 128->32 4x4 @256x512', 128, 32, 4, 2, 1, 256, 512, True, False),
     ('fusion conv1 64->64 3x3s2 @1024x2048', 64, 64, 3, 2, 1, 1024, 2048, False, False),
     ('flownet predict_flow3 386->2 3x3 @128x256', 386, 2, 3, 1, 1, 128, 256, False, False),
     ('fusion predict_flow0 16->2 3x3 @1024x2048', 16, 2, 3, 1, 1, 1024, 2048, False, False),

@@ -26,6 +26,7 @@
 
 int vpsi_launch_conv_q(const vps_conv_desc& d, int M, int tiles_m, int tiles_n, int per_split, long nblk, bool tapmajor, hipStream_t s);
 int vpsi_launch_conv_thin(const vps_conv_desc& d, hipStream_t s);
+void vpsi_launch_conv_n16(const vps_conv_desc& d, long tiles2d8, hipStream_t s);
 void vpsi_launch_conv_h8(const vps_conv_desc& d, int tiles_m8, int tiles_n, int chunks_per_split, long nblk8, hipStream_t s);
 void vpsi_launch_conv_h8s2(const vps_conv_desc& d, int tiles_m8, int tiles_n, int chunks_per_split, long nblk8, int bn, hipStream_t s);
 
@@ -773,209 +774,6 @@ void conv_mfma_bf16h_kernel(const vps_conv_desc d, const int tiles_m, const int 
 }
 
 // ================================================================================================
-// Narrow-output layers (5 <= cout <= 16: the full-resolution FlowNetFusion / FlowNetSD interconv and deconv layers) on the
-// 16x16x32 MFMA shape. A 32-column tile of the 32x32x16 shape spends half of every MFMA and of every weight fragment on zero
-// columns; here the WEIGHT fragment (16 output channels x 32 k) is the A operand and 16 consecutive pixels of a patch row
-// x one whole 32-channel chunk are the B operand, so one MFMA is one (tap, chunk) of 16 pixels with no padding, and the
-// accumulator (col = lane & 15 = pixel, rows 4 (lane >> 4) + r = 4 consecutive channels) is stored as one float4 per lane.
-// Structure of conv_mfma_h8_kernel: 8 waves, an 8 x 32 output patch per block (wave w = patch row w, two 16-pixel groups), the
-// halo tile of the patch staged once per 32-channel chunk (split into the planes of the arithmetic), but the weights of a WHOLE
-// chunk (KH*KW taps x NSB planes x 1 KB) are staged per chunk: barriers per chunk, not per tap (a tap is only 6 MFMAs of 16 cycles
-// per wave). A chunk of this kernel is short (54 MFMAs = 0.9k cycles against ~2k cycles of HBM latency) and a patch has only 3..6
-// chunks, so the latency is hidden by a SECOND BLOCK on the CU rather than by a deeper software pipeline: ONE activation and ONE
-// weight buffer in LDS (76 KB), the next chunk in flight in registers while this one is multiplied, <= 128 VGPRs (the
-// double-buffered first version kept one block per CU and ran at the memory latency: 0.43 ms for 82 -> 16 @1024x2048). The 16-byte chunk index of an LDS row is XOR-ed with (row >> 1) & 3: the 16 lanes of a
-// k-group read 16 consecutive rows, 8 of them cover the 8 distinct 16-byte slots of 128 bytes.
-// The weight fragments come from the SAME packed layout as every other kernel ([plane][32-column block][16-k step][lane][8]):
-// lane l of the 16x16x32 A fragment (channel l & 15, k-group g = l >> 4) is lane (l & 15) + 32 (g & 1) of step 2 s + (g >> 1).
-// ================================================================================================
-__device__ __forceinline__ int lds_swz16(int row) { return (row >> 1) & 3; }
-
-template <int MODE, int KH, int KW>
-__global__ __launch_bounds__(512, 4)
-void conv_mfma_n16_kernel(const vps_conv_desc d, const int tiles_m) {
-    constexpr int NTAP = KH * KW;
-    constexpr int HW = 32 + KW - 1, HH = 8 + KH - 1;   // halo tile of an 8 x 32 patch
-    constexpr int HROWS = HH * HW;
-    constexpr int NLD = (HROWS + 63) / 64;              // staged rows per thread
-    typedef Split<MODE> SM;
-    typedef typename SM::elem elem_t;
-    typedef vec8<elem_t> x8;
-    typedef vec4<elem_t> x4;
-    constexpr int NSA = SM::NSA, NSB = SM::NSB, NT = SM::NT;
-    constexpr int PLANE = NLD * 64 * LDS_LDH;
-    constexpr int ABUF = NSA * PLANE;
-    constexpr int NWF = NTAP * NSB;                     // 1 KB weight fragments of one chunk
-    constexpr int WBUF = NWF * 512;
-    constexpr int NBL = (NWF * 64 + 511) / 512;         // 16-byte weight chunks per thread and chunk
-    static_assert((ABUF + WBUF) * 2 <= 80 * 1024, "two blocks per CU");
-
-    __shared__ __attribute__((aligned(16))) elem_t As[ABUF];
-    __shared__ __attribute__((aligned(16))) elem_t Ws[WBUF];
-
-    const int t = threadIdx.x;
-    int swz = xcd_swizzle(blockIdx.x, gridDim.x);
-    int tile_n, tile_m, cls, split;
-    decode_tile(d, swz, 1, tiles_m, tile_n, tile_m, cls, split);
-
-    const int py = cls / d.os_x, px = cls - py * d.os_x;
-    const int H = d.H, W = d.W, cin_pad = d.cin_pad;
-    const int tiles_x = (d.Qw + 31) >> 5, tiles_y = (d.Qh + 7) >> 3;
-    const int tx = tile_m % tiles_x, tq = tile_m / tiles_x;
-    const int ty = tq % tiles_y, n = tq / tiles_y;
-    const int iy_org = ty * 8 - d.pad_y[py], ix_org = tx * 32 - d.pad_x[px];
-
-    const int k4 = t & 7;
-    const int r0 = t >> 3;
-    const int nchunks = d.kpad / (BK * NTAP);
-
-    const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // patch row
-    const int nbt = d.cout_pad >> 5, kst = d.kpad >> 4;
-    const size_t wplane = (size_t)d.nclass * nbt * kst * 512;
-    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(d.w_split, (unsigned)(wplane * NSB * sizeof(elem_t)));
-    const unsigned wbase = (unsigned)(((size_t)(cls * nbt) * kst * 512) * sizeof(elem_t));
-    // source of this lane's 16 bytes inside the two 32x16 fragments of a 32-k step
-    const unsigned wlane = (unsigned)((((lane >> 5) & 1) * 512 + ((lane & 15) + 32 * ((lane >> 4) & 1)) * 8) * sizeof(elem_t));
-    const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(d.in, (unsigned)((size_t)d.N * H * W * d.in_ld * sizeof(float)));
-    const unsigned ld4 = (unsigned)d.in_ld * 4u;
-
-    f32x4 areg[NLD];
-    x8 wreg[NBL];
-    int achunk = 0;
-    float amax = 0.f;
-
-    unsigned hoff[NLD];
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int hp = r0 + 64 * i;
-        const int hy = hp / HW, hx = hp - hy * HW;
-        const int iy = iy_org + hy, ix = ix_org + hx;
-        const bool ok = hp < HROWS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        hoff[i] = ok ? (unsigned)((n * H + iy) * W + ix) * ld4 + (unsigned)(d.in_coff + k4 * 4) * 4u : 0xFFFFFFF0u;
-    }
-    auto load_A = [&]() {
-        const bool kv = achunk * BK + k4 * 4 < cin_pad;
-        const unsigned coff = (unsigned)achunk * (BK * 4u);
-        ++achunk;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i)
-            areg[i] = buffer_load16<f32x4>(arsrc, (kv && hoff[i] != 0xFFFFFFF0u) ? hoff[i] + coff : 0xFFFFFFF0u, 0u);
-    };
-    auto store_A = [&](int i) {
-        x4 sp[NSA];
-        split_act<MODE>(areg[i], sp, amax);
-        const int row = r0 + 64 * i;
-#pragma unroll
-        for (int p = 0; p < NSA; ++p)
-            *reinterpret_cast<x4*>(&As[p * PLANE + row * LDS_LDH + (((k4 >> 1) ^ lds_swz16(row)) << 3) + ((k4 & 1) << 2)]) = sp[p];
-    };
-    // fragment f = tap * NSB + plane of the chunk: wave-uniform per j
-    auto load_W = [&](int chunk) {
-#pragma unroll
-        for (int j = 0; j < NBL; ++j) {
-            const int f = __builtin_amdgcn_readfirstlane((t + 512 * j) >> 6);
-            if (f < NWF) {
-                const int tap = f / NSB, pl = f - tap * NSB;
-                wreg[j] = buffer_load16<x8>(wrsrc, wlane, wbase + (unsigned)(((size_t)pl * wplane + (size_t)(2 * (chunk * NTAP + tap)) * 512) * sizeof(elem_t)));
-            }
-        }
-    };
-    auto store_W = [&](int j) {
-        if (__builtin_amdgcn_readfirstlane((t + 512 * j) >> 6) < NWF) *reinterpret_cast<x8*>(&Ws[(t + 512 * j) * 8]) = wreg[j];
-    };
-
-    // B operand: pixel x = 16 h + (lane & 15) of patch row `wave`, k-group lane >> 4 = 16-byte chunk of the LDS row
-    const int hbase = wave * HW + (lane & 15);
-    const int kg = lane >> 4;
-    f32x4 acc[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // LDS element offsets of this lane's activation fragments, per (tap, pixel group): loop-invariant (the swizzle depends on the row)
-    int aoff[NTAP][2];
-#pragma unroll
-    for (int tp = 0; tp < NTAP; ++tp)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int hrow = hbase + 16 * h + (tp / KW) * HW + (tp % KW);
-            aoff[tp][h] = hrow * LDS_LDH + ((kg ^ lds_swz16(hrow)) << 3);
-        }
-
-    load_A();
-    load_W(0);
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        // the chunk in the registers -> LDS (the previous chunk's fragment reads are behind the barrier that ended its loop body)
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) store_A(i);
-#pragma unroll
-        for (int j = 0; j < NBL; ++j) store_W(j);
-        if (chunk + 1 < nchunks) {                               // next chunk in flight while this one is multiplied
-            load_A();
-            load_W(chunk + 1);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int tp = 0; tp < NTAP; ++tp) {
-            x8 wf[NSB], af[2][NSA];
-#pragma unroll
-            for (int p = 0; p < NSB; ++p) wf[p] = *reinterpret_cast<const x8*>(&Ws[(tp * NSB + p) * 512 + lane * 8]);
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int p = 0; p < NSA; ++p) af[h][p] = *reinterpret_cast<const x8*>(&As[aoff[tp][h] + p * PLANE]);
-#pragma unroll
-            for (int q = 0; q < NT; ++q)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    if constexpr (MODE == VPS_PREC_F16X3) acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[SM::PB[q]], af[h][SM::PA[q]], acc[h], 0, 0, 0);
-                    else acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[SM::PB[q]], af[h][SM::PA[q]], acc[h], 0, 0, 0);
-                }
-        }
-        __syncthreads();
-    }
-    report_range<MODE>(d, amax);
-
-    // epilogue: lane = pixel (lane & 15) of the group, output channels 4 (lane >> 4) .. + 3
-    const int co = 4 * kg;
-    const int qy = ty * 8 + wave;
-    const bool v4 = !((d.out_ld | d.out_coff | d.cout) & 3) && !((uintptr_t)d.out & 15);
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (co + e < d.cout) {
-            if (d.scale) sc[e] = d.scale[co + e];
-            if (d.shift) sh[e] = d.shift[co + e];
-        }
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int qx = tx * 32 + 16 * h + (lane & 15);
-        if (qy < d.Qh && qx < d.Qw && co < d.cout) {
-            const int oy = qy * d.os_y + py, ox = qx * d.os_x + px;
-            const size_t opix = ((size_t)n * d.Ho + oy) * d.Wo + ox;
-            f32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = acc[h][e] * sc[e] + sh[e];
-            if (d.res) {
-                const int rs = d.res_shift;
-                const float* rp = d.res + (((size_t)n * (d.Ho >> rs) + (oy >> rs)) * (d.Wo >> rs) + (ox >> rs)) * d.res_ld + d.res_coff + co;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (co + e < d.cout) o[e] += rp[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = vps_act(o[e], d.act, d.slope);
-            float* op = d.out + opix * d.out_ld + d.out_coff + co;
-            if (v4) *reinterpret_cast<f32x4*>(op) = o;
-            else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (co + e < d.cout) op[e] = o[e];
-            }
-        }
-    }
-}
-
-// ================================================================================================
 // Narrow-output convolution (cout <= 4: the FlowNet predict_flow / upsampled_flow layers, 2 channels). A 32-column MFMA
 // tile would waste 94 % of the matrix pipe and still stage the whole activation tile through LDS; these layers are
 // pure activation streaming, so they run on the vector ALU in exact fp32: G lanes (G = pow2 >= cin_pad/4, <= 64) share
@@ -1288,12 +1086,13 @@ int launch_conv(const vps_conv_desc& d, int M, hipStream_t s) {
                       tiles2d8 * tiles_n * d.ksplit >= 256 && (d.ksplit == 1 || chunk_split);
     // 5..16 output channels, stride-1 3x3 / 2x2-class layers with enough 8 x 32 patches: the 16x16x32 kernel (VPS_N16=0 switches it off)
     static const bool n16_enabled = !(getenv("VPS_N16") && getenv("VPS_N16")[0] == '0');
-    const bool n16 = n16_enabled && BN == 32 && d.prec == VPS_PREC_F16X3 && halo && d.cout > 4 && d.cout <= 16 && d.cout_pad == 32 && d.ksplit == 1 &&
+    // VPS_N32=0: layers with 17 .. 32 output channels stay on the 32-column halo kernel (A/B; the two-column-block instance is round 6's)
+    const char* const n32_env = getenv("VPS_N32");
+    const int n16_max_cout = (n32_env && n32_env[0] == '0') ? 16 : 32;
+    const bool n16 = n16_enabled && BN == 32 && d.prec == VPS_PREC_F16X3 && halo && d.cout > 4 && d.cout <= n16_max_cout && d.cout_pad == 32 && d.ksplit == 1 &&
                      !d.gn_stats && tiles2d8 * 256 * 2 <= (long)M * 3 && tiles2d8 * d.nclass >= 256;
     if (n16) {
-        const long nblk8 = tiles2d8 * d.nclass;
-        if (d.KH == 3) hipLaunchKernelGGL((conv_mfma_n16_kernel<VPS_PREC_F16X3, 3, 3>), dim3((unsigned)nblk8), dim3(512), 0, s, d, (int)tiles2d8);
-        else hipLaunchKernelGGL((conv_mfma_n16_kernel<VPS_PREC_F16X3, 2, 2>), dim3((unsigned)nblk8), dim3(512), 0, s, d, (int)tiles2d8);
+        vpsi_launch_conv_n16(d, tiles2d8, s);
     } else if (h8s2) {
         vpsi_launch_conv_h8s2(d, (int)tiles2d8, tiles_n, per_split / ntap, (long)tiles2d8 * tiles_n * d.ksplit, BN == 64 ? 64 : 128, s);
     } else if (h8) {
