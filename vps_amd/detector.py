@@ -289,7 +289,7 @@ class PanopticFuseTrack(HipModule):
         if not img.is_cuda:
             raise hip.VpsHipError('PanopticFuseTrack runs on the device only (no CPU path)')
         if prefetch is None and _BOARD and inject is None:
-            prefetch = [p for p in _BOARD if p[0].is_cuda and p[0].shape == img.shape] or None        # (module docstring of dataloader.py)
+            prefetch = [p for p in _BOARD if p[0].is_cuda and p[0].device == img.device and p[0].shape == img.shape] or None        # (module docstring of dataloader.py)
         dev = img.device
         self.ensure_packed(dev)
         ws = self._workspace(dev)
