@@ -413,6 +413,88 @@ def test_bfp_gather_scatter(dev):
         _cmp(o.to_nchw(), r, rtol=1e-6, atol=1e-6, what='scatter %d' % i)
 
 
+def _ab_env(var, fn):
+    """fn() under var=0 and var=1 (the kernel-family switches of round 6 are read per call) -> {'0': tensor, '1': tensor}"""
+    outs, old = {}, os.environ.get(var)
+    try:
+        for mode in ('0', '1'):
+            os.environ[var] = mode
+            outs[mode] = fn()
+    finally:
+        if old is None:
+            os.environ.pop(var, None)
+        else:
+            os.environ[var] = old
+    return outs
+
+
+@pytest.mark.parametrize('cin,cout,stride,H,W,res', [(64, 256, 1, 256, 512, 1), (64, 64, 1, 256, 512, 0), (128, 512, 1, 128, 256, 1), (256, 256, 1, 256, 512, 2),
+                                                      (256, 512, 2, 256, 512, 0), (512, 256, 1, 250, 500, 0), (256, 128, 1, 255, 509, 1)])
+def test_persistent_pointwise_kernel_is_bitwise_the_uniform_lead_kernel(dev, cin, cout, stride, H, W, res):
+    """conv_pw_kernel (round 6: persistent blocks, loads across tile boundaries, counted stores) against conv_mfma_bf16q_kernel (VPS_PW=0):
+    bitwise - two / four / eight / sixteen k-steps, 128- and 64-column tiles, stride 2, residual at the same size (res 1) and upsampled
+    x2 (res 2: the FPN lateral), pixel counts that are no multiple of the tile (masked rows) - and against a fp64 GEMM"""
+    g = torch.Generator().manual_seed(cin + cout)
+    w = torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    pc = nhwc.PackedConv(w, b, None, stride=stride, padding=0, act=hip.ACT_RELU, device=dev, prec=hip.PREC_F16X3)
+    x = nhwc.FMap(torch.randn(1, H, W, cin, generator=g).to(dev), cin, 0)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    rs = 1 if res == 2 else 0
+    r = None
+    if res:
+        assert Ho % (1 << rs) == 0 and Wo % (1 << rs) == 0
+        r = nhwc.FMap(torch.randn(1, Ho >> rs, Wo >> rs, cout, generator=g).to(dev), cout, 0)
+
+    def run():
+        pc.__dict__.pop('_dcache', None)
+        out = nhwc.FMap(torch.full((1, Ho, Wo, cout), 7.0, device=dev), cout, 0)
+        pc(x, out=out, ws=nhwc.Workspace(dev), res=r, res_shift=rs)
+        torch.cuda.synchronize()
+        return out.t.clone()
+    outs = _ab_env('VPS_PW', run)
+    assert torch.equal(outs['0'], outs['1'])
+    ref = x.t[:, ::stride, ::stride].reshape(-1, cin).double() @ w.view(cout, cin).t().double().to(dev) + b.double().to(dev)
+    if r is not None:
+        rr = r.t.repeat_interleave(2, 1).repeat_interleave(2, 2) if rs else r.t
+        ref = ref + rr.reshape(-1, cout).double()
+    ref = ref.clamp_min(0).float().view(1, Ho, Wo, cout)
+    _cmp(outs['1'], ref, rtol=2e-5, atol=2e-5 * max(1.0, float(ref.abs().max()) / 4), what='pointwise conv')
+
+
+@pytest.mark.parametrize('cin,cout,H,W,res', [(256, 256, 128, 256, False), (128, 128, 256, 512, False), (473, 256, 128, 256, False), (256, 256, 250, 500, True),
+                                              (96, 128, 256, 512, False)])
+def test_pipelined_8_wave_halo_kernel_is_bitwise_conv_mfma_h8(dev, cin, cout, H, W, res):
+    """conv_mfma_h8p_kernel (round 6: weights three taps ahead through a ring of three LDS slots with the third plane derived at staging,
+    activation rows half a chunk ahead, fragments one slab ahead across the barrier) against conv_mfma_h8_kernel (VPS_H8P=0): bitwise -
+    3 .. 15 chunks, a channel count off the 32-grid (473: the last chunk is partly padding), ragged 8 x 32 patches, residual - and against
+    F.conv2d in fp64 on a crop"""
+    g = torch.Generator().manual_seed(cin + H)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    pc = nhwc.PackedConv(w, b, None, stride=1, padding=1, act=hip.ACT_LEAKY, device=dev, prec=hip.PREC_F16X3)
+    cp = (cin + 3) // 4 * 4
+    xt = torch.zeros(1, H, W, cp, device=dev)
+    xt[..., :cin] = torch.randn(1, H, W, cin, generator=g).to(dev)
+    x = nhwc.FMap(xt, cin, 0)
+    r = nhwc.FMap(torch.randn(1, H, W, cout, generator=g).to(dev), cout, 0) if res else None
+
+    def run():
+        pc.__dict__.pop('_dcache', None)
+        out = nhwc.FMap(torch.full((1, H, W, cout), 7.0, device=dev), cout, 0)
+        pc(x, out=out, ws=nhwc.Workspace(dev), res=r)
+        torch.cuda.synchronize()
+        return out.t.clone()
+    outs = _ab_env('VPS_H8P', run)
+    assert torch.equal(outs['0'], outs['1'])
+    ch, cw = 40, 72
+    ref = F.conv2d(xt[0, :ch + 1, :cw + 1, :cin].permute(2, 0, 1)[None].double(), w.double().to(dev), b.double().to(dev), padding=1)[0, :, :ch, :cw].permute(1, 2, 0)
+    if r is not None:
+        ref = ref + r.t[0, :ch, :cw].double()
+    ref = F.leaky_relu(ref, 0.1).float()
+    _cmp(outs['1'][0, :ch, :cw], ref, rtol=2e-5, atol=2e-5 * max(1.0, float(ref.abs().max()) / 4), what='3x3 conv, pipelined halo kernel')
+
+
 @pytest.mark.parametrize('cin,cout,H,W', [(162, 16, 128, 256), (82, 12, 120, 250), (64, 8, 128, 256)])
 def test_transposed_16_column_layer_with_the_four_classes_in_one_block_is_bitwise_the_class_launches(dev, cin, cout, H, W):
     """conv_mfma_n16t_kernel (round 6: a stride-2 transposed 4x4 layer with <= 16 output channels - FlowNetFusion deconv0 - stages its
