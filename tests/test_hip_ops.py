@@ -58,6 +58,11 @@ CONV_CASES = [
     (386, 2, 3, 1, 1, 16, 24, 'none', False, False),    # predict_flow3: two channel slots per lane
     (1026, 2, 3, 1, 1, 8, 13, 'none', False, False),    # predict_flow5: five slots, 76 KB of weights in LDS, ragged run
     (64, 3, 3, 1, 1, 16, 24, 'leaky', False, False),    # cout 3
+    # narrow 1x1 / strided layers: the batched vector kernel (eight loads per lane in flight, 8 | 16 | 1 lanes per pixel, several rounds per wavefront)
+    (256, 3, 1, 1, 0, 64, 99, 'none', False, False),    # RPN objectness
+    (1024, 4, 1, 1, 0, 9, 13, 'relu', True, True),      # 32 slots over 16 lanes... four batches per pixel, BN + residual epilogue
+    (6, 2, 3, 2, 1, 41, 57, 'leaky', False, False),     # stride 2, 2 lanes per pixel, ragged
+    (2, 2, 5, 1, 2, 40, 56, 'none', False, False),      # one lane per pixel, 25 taps: four batches, the last one partly masked
     # whole 8x16 output patches, stride 1, 3x3, chunk-major k: the halo-staged kernel in the split-bf16 modes
     (64, 64, 3, 1, 1, 16, 32, 'relu', True, True),      # tile_n 64, residual
     (82, 16, 3, 1, 1, 24, 48, 'leaky', False, False),   # fusion conv (cin pad 84 -> 3 chunks, tile_n 32)
@@ -153,7 +158,9 @@ def test_conv_writes_into_concat_window_and_reads_padded_window(dev):
                                                 # 16 output channels, 4 classes x 153 patches of 8x32: the 16x16x32 kernel (f16x3)
                                                 (162, 16, 4, 1, 130, 260),
                                                 # 64 output channels, 4 classes x 72 patches of 8x32 (4-wave halo kernel, ragged width)
-                                                (96, 64, 4, 1, 64, 260)])
+                                                (96, 64, 4, 1, 64, 260),
+                                                # the 2-channel up-flow layer on a map with several rounds per wavefront (batched narrow kernel, 4 classes in LDS)
+                                                (2, 2, 4, 1, 130, 258), (34, 3, 4, 1, 20, 31)])
 def test_conv_transpose_matches_torch_cpu(dev, cin, cout, k, pad, H, W, prec, tol):
     x = _rand(2 if k == 2 else 1, cin, H, W, seed=1)
     w = _rand(cin, cout, k, k, seed=2, scale=(1.0 / (cin * k)) ** 0.5)

@@ -38,6 +38,12 @@ SHAPES = [  # name, cin, cout, k, stride, pad, H, W, transposed, deform
     ('fusion conv1 64->64 3x3s2 @1024x2048', 64, 64, 3, 2, 1, 1024, 2048, False, False),
     ('flownet predict_flow3 386->2 3x3 @128x256', 386, 2, 3, 1, 1, 128, 256, False, False),
     ('fusion predict_flow0 16->2 3x3 @1024x2048', 16, 2, 3, 1, 1, 1024, 2048, False, False),
+    ('rpn_cls narrow 256->3 1x1 @256x512', 256, 3, 1, 1, 0, 256, 512, False, False),
+    ('rpn_cls narrow 256->3 1x1 @128x256', 256, 3, 1, 1, 0, 128, 256, False, False),
+    ('rpn_cls narrow 256->3 1x1 @32x64', 256, 3, 1, 1, 0, 32, 64, False, False),
+    ('upflow narrow 2->2 4x4 @512x1024', 2, 2, 4, 2, 1, 512, 1024, True, False),
+    ('upflow narrow 2->2 4x4 @128x256', 2, 2, 4, 2, 1, 128, 256, True, False),
+    ('upflow narrow 2->2 4x4 @16x32', 2, 2, 4, 2, 1, 16, 32, True, False),
     ('upsnet dcn 256->256 3x3 @256x512', 256, 256, 3, 1, 1, 256, 512, False, True),
     ('upsnet dcn 128->128 3x3 @256x512', 128, 128, 3, 1, 1, 256, 512, False, True),
     ('bbox fc 12544->1024 M=1000', 12544, 1024, 1, 1, 0, 1, 1000, False, False),
@@ -65,7 +71,7 @@ def main():
         out = pc(x, ws=ws, name='bench_out', offset=off)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
-        reps = 5
+        reps = int(os.environ.get('BENCH_CONV_REPS', '5'))
         e0.record()
         for _ in range(reps):
             pc(x, out=out, ws=ws, offset=off)

@@ -843,6 +843,95 @@ void conv_small_kernel(const vps_conv_desc d, const int M, const int G, const in
     }
 }
 
+// The same layers organised for the memory pipe (round 6): in conv_small_kernel a lane has ONE activation load in flight and the 64 lanes
+// of a 256-channel pixel pay 6 shuffle steps per output channel for 4 multiply-adds each - the RPN objectness layer (256 -> 3, 1x1,
+// 256 x 512) ran at 1.4 TB/s, the 2 -> 2 up-flow layers at four dependent latencies per pixel. Here the (tap, channel slot) pairs of a
+// lane are flattened into one index and requested EIGHT at a time before the first is used (buffer-addressed: out-of-image taps, channel
+// pads and idle lanes are masked by the offset), G is chosen by the host so that a lane carries about eight loads (256 -> 3: 8 lanes per
+// pixel, 8 pixels per wavefront, 3 shuffle steps), and the CO x kpad weights of every parity class sit in LDS (<= 48 KB, else the
+// kernel above). Per lane the order of accumulation is the one of conv_small_kernel with the same G.
+template <int CO>
+__global__ __launch_bounds__(256)
+void conv_small_batched_kernel(const vps_conv_desc d, const int M, const int G, const int logG, const int nslot) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];   // [nclass][CO][kpad]
+    const int kpad = d.kpad;
+    for (int i = threadIdx.x * 4; i < d.nclass * CO * kpad; i += 256 * 4) {
+        const int row = i / kpad, k = i - row * kpad;
+        const int cls = row / CO, co = row - cls * CO;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(&wsm[i]) = co < d.cout_pad ? *reinterpret_cast<const f32x4*>(d.w + ((size_t)cls * d.cout_pad + co) * kpad + k) : z;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (G - 1);
+    const int ppw = 64 >> logG;
+    const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    const long total = (long)d.nclass * M;
+    const int H = d.H, W = d.W, KW = d.KW, cin_pad = d.cin_pad, ntap = d.KH * d.KW;
+    const int c4n = cin_pad >> 2;
+    const int nj = ntap * nslot;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(d.in, (unsigned)((size_t)d.N * H * W * d.in_ld * sizeof(float)));
+    const unsigned ld4 = (unsigned)d.in_ld * 4u;
+    for (long base = wave_id * ppw; base < total; base += nwaves * ppw) {
+        const long idx = base + (lane >> logG);
+        const bool pv = idx < total;
+        const int cls = pv ? (int)(idx / M) : 0;
+        const int m = pv ? (int)(idx - (long)cls * M) : 0;
+        const int py = cls / d.os_x, px = cls - py * d.os_x;
+        const int qx = m % d.Qw;
+        const int tq = m / d.Qw;
+        const int qy = tq % d.Qh;
+        const int n = tq / d.Qh;
+        const int iy0 = qy * d.stride - d.pad_y[py], ix0 = qx * d.stride - d.pad_x[px];
+        const float* __restrict__ wcls = wsm + cls * CO * kpad;
+        float acc[CO];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+        int tap = 0, slot = 0;
+        for (int j0 = 0; j0 < nj; j0 += 8) {
+            f32x4 a[8];
+            int kk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ky = tap / KW, kx = tap - ky * KW;
+                const int iy = iy0 + ky, ix = ix0 + kx;
+                const int c4 = sub + (slot << logG);
+                const bool ok = pv && j0 + u < nj && c4 < c4n && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const int ci = ok ? 4 * c4 : 0;
+                a[u] = buffer_load16<f32x4>(rsrc, ok ? (unsigned)((n * H + iy) * W + ix) * ld4 + (unsigned)(d.in_coff + ci) * 4u : 0xFFFFFFF0u, 0u);
+                kk[u] = ok ? (d.korder == 0 ? tap * cin_pad + ci : ((ci >> 5) * ntap + tap) * 32 + (ci & 31)) : 0;   // a masked load is zeros: any weight will do
+                if (++slot == nslot) { slot = 0; ++tap; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                for (int c = 0; c < CO; ++c) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wcls + c * kpad + kk[u]);
+                    acc[c] += a[u][0] * wv[0] + a[u][1] * wv[1] + a[u][2] * wv[2] + a[u][3] * wv[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CO; ++c)
+            for (int off = G >> 1; off >= 1; off >>= 1) acc[c] += __shfl_xor(acc[c], off, 64);
+        if (pv && sub == 0) {
+            const int oy = qy * d.os_y + py, ox = qx * d.os_x + px;
+            const size_t opix = ((size_t)n * d.Ho + oy) * d.Wo + ox;
+            const int rs = d.res_shift;
+            const size_t rpix = ((size_t)n * (d.Ho >> rs) + (oy >> rs)) * (d.Wo >> rs) + (ox >> rs);
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+                if (c < d.cout) {
+                    float v = acc[c] * (d.scale ? d.scale[c] : 1.f) + (d.shift ? d.shift[c] : 0.f);
+                    if (d.res) v += d.res[rpix * d.res_ld + d.res_coff + c];
+                    d.out[opix * d.out_ld + d.out_coff + c] = vps_act(v, d.act, d.slope);
+                }
+            }
+        }
+    }
+}
+
 // Narrow-output 3x3 stride-1 convolution (the predict_flow layers): same arithmetic as conv_small_kernel, organised for the
 // memory pipe. The CO x kpad weights sit in LDS (loaded once per workgroup); every G-lane group walks a horizontal run of
 // RUN output pixels whose RUN+2 input columns (float4 channel slices of 3 rows) are all requested up front, so each
@@ -1210,6 +1299,23 @@ extern "C" int vps_conv2d(const vps_conv_desc* dp, void* stream) {
             return vps_launch_status();
         }
         const long total = (long)d.nclass * M;
+        {   // eight loads per lane in flight, weights in LDS: conv_small_batched_kernel (VPS_SMALL_BATCHED=0: the one-load-per-step kernel, which also keeps
+            // the layers with fewer than eight loads per pixel - the 2 -> 2 up-flow layers measured 31 us there against 36 us here)
+            const char* e = getenv("VPS_SMALL_BATCHED");
+            const size_t wb = (size_t)d.nclass * (d.cout <= 2 ? 2 : 4) * d.kpad * sizeof(float);
+            if (!(e && e[0] == '0') && (d.cin_pad >> 2) * d.KH * d.KW >= 8 && wb <= 48 * 1024 && (d.cout <= 2 || d.cout_pad >= 4) && (size_t)d.N * d.H * d.W * d.in_ld * sizeof(float) < 0xFFFFFFF0ull) {
+                const int c4n = d.cin_pad >> 2, ntap = d.KH * d.KW;
+                int Gb = 1, logGb = 0;
+                while (Gb < 64 && Gb * 8 < c4n * ntap && Gb < c4n) { Gb <<= 1; ++logGb; }
+                const int nslot = (c4n + Gb - 1) >> logGb;
+                const int ppw = 64 >> logGb;
+                const long waves = (total + ppw - 1) / ppw;
+                long blocks = (waves + 3) / 4; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;   // 8 blocks per CU: one resident round
+                if (d.cout <= 2) hipLaunchKernelGGL((conv_small_batched_kernel<2>), dim3((unsigned)blocks), dim3(256), wb, s, d, M, Gb, logGb, nslot);
+                else hipLaunchKernelGGL((conv_small_batched_kernel<4>), dim3((unsigned)blocks), dim3(256), wb, s, d, M, Gb, logGb, nslot);
+                return vps_launch_status();
+            }
+        }
         long waves = (total + (64 >> logG) - 1) / (64 >> logG);
         long blocks = (waves + 3) / 4; if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
         if (d.cout <= 2) hipLaunchKernelGGL((conv_small_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, d, M, G, logG);
