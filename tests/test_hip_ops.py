@@ -327,7 +327,10 @@ def test_channelnorm(dev):
 
 
 @pytest.mark.parametrize('C,H,W,md,s2', [(256, 12, 20, 20, 2), (256, 16, 24, 4, 1), (64, 9, 11, 4, 1), (256, 10, 16, 20, 2),
-                                          (128, 7, 24, 20, 2), (256, 6, 8, 4, 1)])
+                                          (128, 7, 24, 20, 2), (256, 6, 8, 4, 1),
+                                          # stride 1 on the half-wavefront kernel (corr_half.hip): one / two float4 per lane, a channel count
+                                          # that leaves lanes idle, enough groups for several rounds per wavefront
+                                          (128, 9, 12, 4, 1), (200, 10, 16, 4, 1), (256, 70, 132, 4, 1)])
 def test_correlation_matches_oracle(dev, C, H, W, md, s2):
     a = _rand(1, C, H, W, seed=1); b = _rand(1, C, H, W, seed=2)
     ref = F.leaky_relu(O.correlation(a, b, md, 1, md, 1, s2), 0.1)

@@ -37,7 +37,7 @@ def main():
     out = {'kernels': {}, 'note': 'busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / %d XCDs * %d SIMDs); conv family only' % (NXCD, NSIMD)}
     tb = ta = 0.0
     for k, (n, busy, act) in sorted(per.items(), key=lambda kv: -kv[1][2]):
-        if 'conv_mfma' not in k and 'conv_thin' not in k:
+        if 'conv_mfma' not in k and 'conv_thin' not in k and 'conv_pw' not in k:
             continue
         out['kernels'][k] = {'dispatches': n, 'mfma_busy_cycles': busy, 'gui_active_cycles': act, 'mfma_busy_frac': round(busy / max(act * NSIMD, 1.0), 4)}
         tb += busy; ta += act

@@ -13,7 +13,7 @@ import os
 import re
 import sys
 
-CONV = re.compile(r'conv_mfma_\w+_kernel|conv_thin_kernel|conv_small\w*_kernel')
+CONV = re.compile(r'conv_mfma_\w+_kernel|conv_thin_kernel|conv_small\w*_kernel|conv_pw_kernel')
 
 
 def dispatches(directory, counter):

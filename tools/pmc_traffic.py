@@ -12,32 +12,43 @@ The third argument is the number of frames the profiled command ran: warmup + st
 frames of bench.py's single-stream section (7 for `--steps 1 --warmup 1`; 5 up to round 5's committed measurement, which ran one
 instrumented frame)."""
 import csv
+import re
 import glob
 import json
 import os
 import sys
 
 
-def total(directory, counter, match):
-    tot, n = 0.0, 0
+# every kernel of the vps_conv2d family, whatever translation unit it lives in. Round 6 found the list of names that stood here missing the
+# kernels added since (conv_mfma_h8p_kernel, conv_pw_kernel, the n16t / n32 instances: a substring test on 'conv_mfma_h8_kernel' does not see
+# 'conv_mfma_h8p_kernel') - the first r06 figure (23.8 GB) left their traffic out. A pattern cannot fall behind the sources.
+CONV = re.compile(r'conv_(mfma_\w+|thin|small\w*|pw|splitk_reduce)_kernel')
+
+
+def totals(directory, counter):
+    """{short kernel name: [sum of the counter, dispatches]} over the conv family"""
+    acc = {}
     for fn in glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True):
         for row in csv.DictReader(open(fn)):
-            if row['Counter_Name'] == counter and match in row['Kernel_Name']:
-                tot += float(row['Counter_Value']); n += 1
-    return tot, n
+            if row['Counter_Name'] != counter:
+                continue
+            m = CONV.search(row['Kernel_Name'])
+            if m:
+                a = acc.setdefault(m.group(0), [0.0, 0])
+                a[0] += float(row['Counter_Value']); a[1] += 1
+    return acc
 
 
 def main():
     fetch_dir, write_dir, frames = sys.argv[1], sys.argv[2], int(sys.argv[3])
     out = {'frames': frames, 'kernels': {}}
-    for name in ('conv_mfma_h8_kernel', 'conv_mfma_h8s2_kernel', 'conv_mfma_n16_kernel', 'conv_mfma_bf16h_kernel', 'conv_mfma_bf16p_kernel', 'conv_mfma_bf16q_kernel', 'conv_thin_kernel', 'conv_mfma_bf16s_kernel', 'conv_mfma_f32_kernel', 'conv_small3x3_kernel',
-                 'conv_small_kernel', 'conv_splitk_reduce_kernel'):
-        f, nf = total(fetch_dir, 'FETCH_SIZE', name)
-        w, nw = total(write_dir, 'WRITE_SIZE', name)
-        if nf or nw:
-            out['kernels'][name] = {'launches_per_frame': nf / frames, 'fetch_bytes_per_frame': 2.0 * f * 1024 / frames,
-                                    'write_bytes_per_frame': w * 1024 / frames,
-                                    'raw': {'FETCH_SIZE_KiB_sum': f, 'fetch_dispatches': nf, 'WRITE_SIZE_KiB_sum': w, 'write_dispatches': nw}}
+    fetch, write = totals(fetch_dir, 'FETCH_SIZE'), totals(write_dir, 'WRITE_SIZE')
+    for name in sorted(set(fetch) | set(write)):
+        f, nf = fetch.get(name, (0.0, 0))
+        w, nw = write.get(name, (0.0, 0))
+        out['kernels'][name] = {'launches_per_frame': nf / frames, 'fetch_bytes_per_frame': 2.0 * f * 1024 / frames,
+                                'write_bytes_per_frame': w * 1024 / frames,
+                                'raw': {'FETCH_SIZE_KiB_sum': f, 'fetch_dispatches': nf, 'WRITE_SIZE_KiB_sum': w, 'write_dispatches': nw}}
     out['conv_hbm_bytes_per_frame'] = sum(k['fetch_bytes_per_frame'] + k['write_bytes_per_frame'] for k in out['kernels'].values())
     # which kernel sources this was measured on: bench.py attaches the newest committed measurement to its line and says whether the
     # library it runs was built from the same sources (VERDICT r3 hygiene)

@@ -165,150 +165,21 @@ void conv_small_batched_kernel(const vps_conv_desc d, const int M, const int G, 
     }
 }
 
-// Narrow-output 3x3 stride-1 convolution (the predict_flow layers): same arithmetic as conv_small_kernel, organised for the
-// memory pipe. The CO x kpad weights sit in LDS (loaded once per workgroup); every G-lane group walks a horizontal run of
-// RUN output pixels whose RUN+2 input columns (float4 channel slices of 3 rows) are all requested up front, so each
-// activation is loaded 4.5 times instead of 9 and a run costs one memory latency instead of 9 per pixel (the layer is
-// pure activation streaming: latency and load count are the cost). Round 3: one weight read per tap and output channel shared by the
-// RUN pixels instead of weights held in registers (round 6: 3 waves per SIMD, 152 VGPRs, and a scheduling fence behind the loads),
-// buffer-addressed loads (out-of-image taps / idle lanes masked by the offset: 18 selects per run instead of 72), an fmaf
-// chain straight into the accumulator (288 instead of 360 VALU per run) and a folding butterfly for the G-lane reduction of the
-// 8 accumulators (7 + log2(G/8) shuffles instead of 8 log2 G).
-template <int CO, int RUN>
-__global__ __launch_bounds__(256, 3)
-void conv_small3x3_kernel(const vps_conv_desc d, const int G, const int logG, const int runs_per_row, const long total_runs) {
-    extern __shared__ __attribute__((aligned(16))) float wlds[];   // [CO][kpad]
-    constexpr int NV = RUN * CO;                                   // accumulators per lane: 8
-    static_assert(NV == 8, "the butterfly below folds 8 values over 3 lane bits");
-    const int t = threadIdx.x;
-    const int kpad = d.kpad;
-    for (int i = t * 4; i < CO * kpad; i += 256 * 4) {
-        const int co = i / kpad, k = i - co * kpad;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(&wlds[i]) = co < d.cout_pad ? *reinterpret_cast<const f32x4*>(d.w + (size_t)co * kpad + k) : z;
-    }
-    __syncthreads();
-
-    const int lane = t & 63;
-    const int sub = lane & (G - 1);
-    const int ppw = 64 >> logG;
-    const long group = ((long)blockIdx.x * 4 + (t >> 6)) * ppw + (lane >> logG);
-    const long ngroups = (long)gridDim.x * 4 * ppw;
-    const int H = d.H, W = d.W, cin_pad = d.cin_pad, c4n = cin_pad >> 2;
-    const int nslot = (c4n + G - 1) >> logG;
-    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(d.in, (unsigned)((size_t)d.N * H * W * d.in_ld * sizeof(float)));
-    const unsigned ld4 = (unsigned)d.in_ld * 4u;
-
-    for (long run = group; run - (lane >> logG) < total_runs; run += ngroups) {   // whole wavefronts iterate together (shuffles below)
-        const bool rv = run < total_runs;
-        const long rr = rv ? run : 0;
-        const int x0 = (int)(rr % runs_per_row) * RUN;
-        const long ty = rr / runs_per_row;
-        const int y = (int)(ty % H), n = (int)(ty / H);
-        float acc[RUN][CO];
-#pragma unroll
-        for (int xi = 0; xi < RUN; ++xi)
-#pragma unroll
-            for (int c = 0; c < CO; ++c) acc[xi][c] = 0.f;
-
-        for (int slot = 0; slot < nslot; ++slot) {
-            const int c4 = sub + (slot << logG);
-            const bool cv = rv && c4 < c4n;
-            const int ci = cv ? 4 * c4 : 0;
-            const int kbase = d.korder == 0 ? ci : ((ci >> 5) * 9) * 32 + (ci & 31);
-            const int kstep = d.korder == 0 ? cin_pad : 32;
-            const unsigned coff = (unsigned)(d.in_coff + ci) * 4u;
-            // all RUN+2 columns of the 3 rows are requested before the first value is used; out-of-image taps, channel pads and
-            // idle lanes are masked by the ADDRESS (an offset beyond the buffer reads zeros): one select per load, none per value
-            f32x4 col[RUN + 2][3];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int iy = y + ky - 1;
-                const bool rok = cv && (unsigned)iy < (unsigned)H;
-                const unsigned rowoff = (unsigned)((n * H + iy) * W) * ld4 + coff;
-#pragma unroll
-                for (int j = 0; j < RUN + 2; ++j) {
-                    const int x = x0 - 1 + j;
-                    const bool ok = rok && (unsigned)x < (unsigned)W;
-                    col[j][ky] = buffer_load16<f32x4>(rsrc, ok ? rowoff + (unsigned)x * ld4 : 0xFFFFFFF0u, 0u);
-                }
-            }
-            // (round 6) without this fence the scheduler sinks the loads towards their uses - 4 + 2 + 2 + ... with vmcnt(0) / vmcnt(1) in between,
-            // eight memory round trips per slot instead of one: `194->2 @256x512` ran at 1.9 TB/s
-            __builtin_amdgcn_sched_barrier(0);
-            // one weight read per (tap, output channel), used by the RUN pixels of the run
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int k = kbase + (ky * 3 + kx) * kstep;
-#pragma unroll
-                    for (int c = 0; c < CO; ++c) {
-                        const f32x4 wv = *reinterpret_cast<const f32x4*>(&wlds[c * kpad + k]);
-#pragma unroll
-                        for (int xi = 0; xi < RUN; ++xi) {
-                            const f32x4 a = col[xi + kx][ky];
-                            acc[xi][c] = __builtin_fmaf(a[3], wv[3], __builtin_fmaf(a[2], wv[2], __builtin_fmaf(a[1], wv[1], __builtin_fmaf(a[0], wv[0], acc[xi][c]))));
-                        }
-                    }
-                }
-        }
-        // reduction over the G lanes of the group
-        float v[NV];
-#pragma unroll
-        for (int xi = 0; xi < RUN; ++xi)
-#pragma unroll
-            for (int c = 0; c < CO; ++c) v[xi * CO + c] = acc[xi][c];
-        int mine = 0;                      // index of the value this lane ends up holding (G >= 8)
-        if (G >= 8) {
-            // folding butterfly: over lane bits 0..2 every exchange halves the number of values a lane carries (8 -> 4 -> 2 -> 1:
-            // 7 shuffles instead of 24), then plain exchanges of the single value over the remaining bits
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const int off = 1 << s, half = (NV >> 1) >> s;
-                const bool up = lane & off;
-#pragma unroll
-                for (int i = 0; i < half; ++i) {
-                    const float send = up ? v[i] : v[i + half];
-                    const float keep = up ? v[i + half] : v[i];
-                    v[i] = keep + __shfl_xor(send, off, 64);
-                }
-                mine += up ? half : 0;
-            }
-            for (int off = 8; off < G; off <<= 1) v[0] += __shfl_xor(v[0], off, 64);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NV; ++i)
-                for (int off = G >> 1; off >= 1; off >>= 1) v[i] += __shfl_xor(v[i], off, 64);
-        }
-        const int rs = d.res_shift;
-        auto put = [&](const int xi, const int c, const float a) {
-            const int x = x0 + xi;
-            if (x < W && c < d.cout) {
-                const size_t opix = ((size_t)n * d.Ho + y) * d.Wo + x;
-                float o = a * (d.scale ? d.scale[c] : 1.f) + (d.shift ? d.shift[c] : 0.f);
-                if (d.res) o += d.res[(((size_t)n * (d.Ho >> rs) + (y >> rs)) * (d.Wo >> rs) + (x >> rs)) * d.res_ld + d.res_coff + c];
-                d.out[opix * d.out_ld + d.out_coff + c] = vps_act(o, d.act, d.slope);
-            }
-        };
-        if (G >= 8) {
-            if (rv && sub < 8) put(mine / CO, mine % CO, v[0]);
-        } else if (rv && sub == 0) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i) put(i / CO, i % CO, v[i]);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// conv_small3x3_kernel rebuilt around its instruction count (round 6). The kernel above issues ~1000 wave instructions per run for 144
-// packed FMAs: 64-bit run / row decoding by division (~360), the loads sunk towards their uses (fenced now), weight pairs assembled with
-// moves, G a run-time value in the reduction, scale / shift / residual pointers tested and loaded per stored value. A SIMD issues one
-// vector instruction per 4 cycles whatever the occupancy: `194->2 @256x512` = 32 runs per SIMD x 1000 x 4 cycles = 53 us - what it
-// measured (55 us; 101 MB at 1.9 TB/s). Here: 32-bit run index advanced incrementally (one division per thread, none per run), G a
-// template parameter, the CO weights of a k side by side in LDS so that a 16-byte read feeds packed FMAs directly, one base offset per
-// run + row / column strides, scale / shift of the lane's values read once, the folding butterfly for every G. Same accumulation order
-// per lane and, for G >= 8, the same reduction tree as the kernel above: bitwise equal there.
+// Narrow-output 3x3 stride-1 convolution (the predict_flow layers): same arithmetic as conv_small_kernel, organised for the memory pipe
+// AND for its instruction count. The CO x kpad weights sit in LDS (loaded once per workgroup, the CO weights of a k side by side so that
+// a 16-byte read feeds packed multiply-adds directly); every G-lane group walks a horizontal run of RUN output pixels whose RUN+2 input
+// columns (float4 channel slices of 3 rows) are all requested up front - each activation is loaded 4.5 times instead of 9 and a run costs
+// one memory latency instead of 9 per pixel. Out-of-image taps, channel pads and idle lanes are masked by the ADDRESS (an offset beyond
+// the buffer reads zeros). The G-lane reduction is a folding butterfly (every exchange halves the values a lane carries).
+// Round 6 rebuilt it around the instruction count: its predecessor issued ~1000 wave instructions per run for 144 packed multiply-adds
+// (64-bit run / row decoding by division ~360; the loads sunk towards their uses by the scheduler - 4 + 2 + 2 ... with vmcnt(0) in
+// between; `?:` on the accumulator array turned into indexed extracts = chains of 8 compares + selects per value; G a run-time value;
+// scale / shift pointers tested and read per stored value). A SIMD issues one vector instruction per 4 cycles whatever the occupancy:
+// `194->2 @256x512` = 32 runs per SIMD x 1000 x 4 cycles = 53 us, what it measured (55 us; 101 MB at 1.9 TB/s). Now: 32-bit run index
+// advanced incrementally (one division per thread, none per run), G a template parameter, one base offset per run + row / column
+// strides, a scheduling fence behind the load block, bit selects in the folds, scale / shift of the lane's values read once: ~520
+// instructions per run, 55 -> 35 us (`16->2 @1024x2048` 71 -> 42 us), frame +0.45 % (A/B in one call). 3 waves per SIMD (154 VGPRs).
 // ------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float bit_select(const unsigned m, const float a, const float b) {   // m all ones: a, zero: b
@@ -466,7 +337,8 @@ void vpsi_launch_conv_small(const vps_conv_desc& d, const int M, hipStream_t s) 
     while (G < 64 && G < (d.cin_pad >> 2)) { G <<= 1; ++logG; }
     const size_t wbytes = (size_t)(d.cout <= 2 ? 2 : 4) * d.kpad * sizeof(float);
     if (d.KH == 3 && d.KW == 3 && d.stride == 1 && d.nclass == 1 && d.pad_y[0] == 1 && d.pad_x[0] == 1 && d.Ho == d.H && d.Wo == d.W &&
-        wbytes <= 150 * 1024 && (d.cout <= 2 || d.cout_pad >= 4) && (size_t)d.N * d.H * d.W * d.in_ld * sizeof(float) < 0xFFFFFFF0ull) {
+        wbytes <= 150 * 1024 && (d.cout <= 2 || d.cout_pad >= 4) && (size_t)d.N * d.H * d.W * d.in_ld * sizeof(float) < 0xFFFFFFF0ull &&
+        (long)d.N * d.H * d.W < 0x7fffffffL) {               // 32-bit run index
         constexpr int RUN = 4;
         const int run = d.cout <= 2 ? RUN : RUN / 2;
         const int runs_per_row = (d.W + run - 1) / run;
@@ -474,36 +346,22 @@ void vpsi_launch_conv_small(const vps_conv_desc& d, const int M, hipStream_t s) 
         const int ppw = 64 >> logG;
         long blocks = (total_runs + 4 * ppw - 1) / (4 * ppw);
         if (blocks > 768) blocks = 768;               // 3 blocks of 4 waves per CU (152 VGPRs: all 18 loads of a run in flight): one resident round, the weights are staged once per block
-        {   // the instruction-lean instance (VPS_SMALL3X3_V=0 in the environment: the kernel it replaces, A/B runs)
-            const char* e = getenv("VPS_SMALL3X3_V");
-            if (!(e && e[0] == '0') && total_runs < 0x7fffffffL) {
-#define VPS_S3V(LG)                                                                                                                        \
-                do {                                                                                                                       \
-                    static bool attr_v = false;                                                                                            \
-                    if (!attr_v) {                                                                                                         \
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small3x3v_kernel<2, RUN, LG>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);     \
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small3x3v_kernel<4, RUN / 2, LG>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
-                        attr_v = true;                                                                                                     \
-                    }                                                                                                                      \
-                    if (d.cout <= 2) hipLaunchKernelGGL((conv_small3x3v_kernel<2, RUN, LG>), dim3((unsigned)blocks), dim3(256), wbytes, s, d, runs_per_row, (int)total_runs);      \
-                    else hipLaunchKernelGGL((conv_small3x3v_kernel<4, RUN / 2, LG>), dim3((unsigned)blocks), dim3(256), wbytes, s, d, runs_per_row, (int)total_runs);           \
-                } while (0)
-                switch (logG) {
-                    case 0: VPS_S3V(0); break; case 1: VPS_S3V(1); break; case 2: VPS_S3V(2); break; case 3: VPS_S3V(3); break;
-                    case 4: VPS_S3V(4); break; case 5: VPS_S3V(5); break; default: VPS_S3V(6); break;
-                }
+#define VPS_S3V(LG)                                                                                                                            \
+        do {                                                                                                                               \
+            static bool attr_v = false;                                                                                                    \
+            if (!attr_v) {                                                                                                                 \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small3x3v_kernel<2, RUN, LG>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);     \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small3x3v_kernel<4, RUN / 2, LG>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+                attr_v = true;                                                                                                             \
+            }                                                                                                                              \
+            if (d.cout <= 2) hipLaunchKernelGGL((conv_small3x3v_kernel<2, RUN, LG>), dim3((unsigned)blocks), dim3(256), wbytes, s, d, runs_per_row, (int)total_runs);      \
+            else hipLaunchKernelGGL((conv_small3x3v_kernel<4, RUN / 2, LG>), dim3((unsigned)blocks), dim3(256), wbytes, s, d, runs_per_row, (int)total_runs);           \
+        } while (0)
+        switch (logG) {
+            case 0: VPS_S3V(0); break; case 1: VPS_S3V(1); break; case 2: VPS_S3V(2); break; case 3: VPS_S3V(3); break;
+            case 4: VPS_S3V(4); break; case 5: VPS_S3V(5); break; default: VPS_S3V(6); break;
+        }
 #undef VPS_S3V
-                return;
-            }
-        }
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small3x3_kernel<2, RUN>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small3x3_kernel<4, RUN / 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            attr_set = true;
-        }
-        if (d.cout <= 2) hipLaunchKernelGGL((conv_small3x3_kernel<2, RUN>), dim3((unsigned)blocks), dim3(256), wbytes, s, d, G, logG, runs_per_row, total_runs);
-        else hipLaunchKernelGGL((conv_small3x3_kernel<4, RUN / 2>), dim3((unsigned)blocks), dim3(256), wbytes, s, d, G, logG, runs_per_row, total_runs);
         return;
     }
     const long total = (long)d.nclass * M;

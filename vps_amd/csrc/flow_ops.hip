@@ -700,6 +700,8 @@ extern "C" int vps_channelnorm(vps_tensor4 in, vps_tensor4 out, int B, int C, in
     return vps_launch_status();
 }
 
+bool vpsi_launch_corr4h(const float* in1, int ld1, int coff1, const float* in2, int ld2, int coff2, float* out, int out_ld, int out_coff,
+                        int N, int H, int W, int C, int r, int stride2, int act, float slope, hipStream_t s);
 int vpsi_launch_corr_mfma(const float* in1, int ld1, int coff1, const float* in2, int ld2, int coff2, float* out, int out_ld, int out_coff,
                           int N, int H, int W, int C, int max_disp, int stride2, int act, float slope, int32_t* status, hipStream_t s);
 
@@ -752,6 +754,8 @@ extern "C" int vps_correlation(const float* in1, int ld1, int coff1, const float
         return vps_launch_status();
     }
     if (stride2 == 2 && r == 10 && (W % 8) == 0 && C <= 256) { CORR4_LAUNCH(2, 10, 1); return vps_launch_status(); }
+    // stride 1, radius 4 (LiteFlowNetCorr): half a wavefront per dot product, two displacement rows per wavefront (corr_half.hip, round 6)
+    if (vpsi_launch_corr4h(in1, ld1, coff1, in2, ld2, coff2, out, out_ld, out_coff, N, H, W, C, r, stride2, act, slope, s)) return vps_launch_status();
     if (stride2 == 1 && r == 4 && (W % 4) == 0 && C <= 256) { CORR4_LAUNCH(1, 4, 1); return vps_launch_status(); }
 #undef CORR4_LAUNCH
 #define CORR_LAUNCH(NC4)                                                                                        \
