@@ -168,18 +168,18 @@ void conv_small_batched_kernel(const vps_conv_desc d, const int M, const int G, 
 // ------------------------------------------------------------------------------------------------
 // Narrow-output 3x3 stride-1 convolution (the predict_flow layers): same arithmetic as conv_small_kernel, organised for the memory pipe
 // AND for its instruction count. The CO x kpad weights sit in LDS (loaded once per workgroup, the CO weights of a k side by side so that
-// a 16-byte read feeds packed multiply-adds directly); every G-lane group walks a horizontal run of RUN output pixels whose RUN+2 input
+// a 16-byte read holds the CO weights of two consecutive k); every G-lane group walks a horizontal run of RUN output pixels whose RUN+2 input
 // columns (float4 channel slices of 3 rows) are all requested up front - each activation is loaded 4.5 times instead of 9 and a run costs
 // one memory latency instead of 9 per pixel. Out-of-image taps, channel pads and idle lanes are masked by the ADDRESS (an offset beyond
 // the buffer reads zeros). The G-lane reduction is a folding butterfly (every exchange halves the values a lane carries).
-// Round 6 rebuilt it around the instruction count: its predecessor issued ~1000 wave instructions per run for 144 packed multiply-adds
+// Round 6 rebuilt it around the instruction count: its predecessor issued ~1150 wave instructions per run for 288 multiply-adds
 // (64-bit run / row decoding by division ~360; the loads sunk towards their uses by the scheduler - 4 + 2 + 2 ... with vmcnt(0) in
 // between; `?:` on the accumulator array turned into indexed extracts = chains of 8 compares + selects per value; G a run-time value;
 // scale / shift pointers tested and read per stored value). A SIMD issues one vector instruction per 4 cycles whatever the occupancy:
-// `194->2 @256x512` = 32 runs per SIMD x 1000 x 4 cycles = 53 us, what it measured (55 us; 101 MB at 1.9 TB/s). Now: 32-bit run index
+// `194->2 @256x512` = 32 runs per SIMD x 1150 x 4 cycles = 61 us at 2.4 GHz; it measured 55 us (101 MB at 1.9 TB/s). Now: 32-bit run index
 // advanced incrementally (one division per thread, none per run), G a template parameter, one base offset per run + row / column
-// strides, a scheduling fence behind the load block, bit selects in the folds, scale / shift of the lane's values read once: ~520
-// instructions per run, 55 -> 35 us (`16->2 @1024x2048` 71 -> 42 us), frame +0.45 % (A/B in one call). 3 waves per SIMD (154 VGPRs).
+// strides, a scheduling fence behind the load block, bit selects in the folds, scale / shift of the lane's values read once: ~650
+// instructions per run (the library is built without packed FP32, DESIGN.md 3.3: the two-channel FMAs below are two v_fmac each), 55 -> 35 us (`16->2 @1024x2048` 71 -> 42 us), frame +0.45 % (A/B in one call). 3 waves per SIMD (154 VGPRs).
 // ------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float bit_select(const unsigned m, const float a, const float b) {   // m all ones: a, zero: b

@@ -5,16 +5,16 @@
 // correlation4_kernel gives a dot product of 256 channels to the 64 lanes of a wavefront: 4 multiply-adds per lane and output, then a
 // 6-step reduction - per displacement row 144 multiply-adds among ~690 wave instructions. A SIMD issues one vector instruction per 4
 // cycles whatever the occupancy, so the kernel runs at its instruction count: 273 us for 2.7 G multiply-adds (the HBM floor is 40 us).
-// Here 32 lanes own a dot product (two float4 per lane, packed multiply-adds, one horizontal add) and the two halves of a wavefront
-// work on two displacement ROWS of the same four pixels: the folding butterfly (bit selects, not `?:` on the register array - that
-// becomes an indexed extract) reduces both rows at once over 5 lane bits and leaves two neighbouring pixels of one displacement per lane.
-// Per pair of rows: 24 loads, 36 x 5 packed operations, ~190 reduction instructions.
+// Here 32 lanes own a dot product (two float4 per lane: 8 multiply-adds per lane and output) and the two halves of a wavefront work on
+// two displacement ROWS of the same four pixels: the folding butterfly (bit selects, not `?:` on the register array - that becomes an
+// indexed extract) reduces both rows at once over 5 lane bits and leaves two neighbouring pixels of one displacement per lane.
+// Per pair of rows: 24 loads, 36 x 8 multiply-adds, ~190 reduction instructions: ~750 instead of ~1380 (the library is built without
+// packed FP32: DESIGN.md 3.3).
 #include "common.h"
 #include "conv_common.h"
 
 namespace {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float bit_select(const unsigned m, const float a, const float b) {   // m all ones: a, zero: b
     return __uint_as_float((m & __float_as_uint(a)) | (~m & __float_as_uint(b)));
 }
@@ -89,14 +89,15 @@ void correlation4h_kernel(const float* __restrict__ in1, int ld1, int coff1, con
                     for (int p = 0; p < 4; ++p) {
                         const int ti = uu - p;
                         if (ti < 0 || ti >= D) continue;
-                        f32x2 s2 = f32x2{a[p][0][0], a[p][0][1]} * f32x2{b[du][0][0], b[du][0][1]};
-                        s2 = __builtin_elementwise_fma(f32x2{a[p][0][2], a[p][0][3]}, f32x2{b[du][0][2], b[du][0][3]}, s2);
+                        float acc = a[p][0][0] * b[du][0][0];
+                        acc = __builtin_fmaf(a[p][0][1], b[du][0][1], acc);
+                        acc = __builtin_fmaf(a[p][0][2], b[du][0][2], acc);
+                        acc = __builtin_fmaf(a[p][0][3], b[du][0][3], acc);
 #pragma unroll
-                        for (int q = 1; q < NQ; ++q) {
-                            s2 = __builtin_elementwise_fma(f32x2{a[p][q][0], a[p][q][1]}, f32x2{b[du][q][0], b[du][q][1]}, s2);
-                            s2 = __builtin_elementwise_fma(f32x2{a[p][q][2], a[p][q][3]}, f32x2{b[du][q][2], b[du][q][3]}, s2);
-                        }
-                        v[ti * 4 + p] = s2[0] + s2[1];
+                        for (int q = 1; q < NQ; ++q)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc = __builtin_fmaf(a[p][q][e], b[du][q][e], acc);
+                        v[ti * 4 + p] = acc;
                     }
                 }
             }
