@@ -315,6 +315,20 @@ int vps_mask_removal_dep(const float* logits, int S, const int32_t* boxes, const
                          int n, int ncls, int H, int W, uint8_t* occ, double thr, int32_t* flags, int32_t* done,
                          int32_t* status, void* stream);
 
+/* the same decisions WITHOUT a dependency chain (round 6, the detector's default): rank[n] = position of box i among the boxes of its
+ * class in the score-sorted walk, max_rank = its largest value (<= 126: at most 127 boxes per class; ncls <= 32, n <= 256). One pass over
+ * the frame gives every pixel its per-class pattern of covering boxes (per-box pixel counts by wavefront ballots, patterns with >= 2
+ * bits counted in a per-class hash table), then one wavefront per class walks its boxes over the distinct patterns: overlap_i = sum of
+ * count(P) over the patterns P with bit i and a kept earlier bit (mask_removal.py:75-88). A class with more than 64 boxes takes a second
+ * pass for its ranks 64..126 (key = their pattern + "covered by a kept box of ranks 0..63"). scratch: 8-byte aligned,
+ * (n rounded up to 2) int32 + (ncls + groups * ncls * 4096) 64-bit words with groups = 1 + (max_rank >= 64), zeroed by the call.
+ * status: bit 2 (value 4) is OR-ed in when a hash table (2048 distinct overlap patterns per class and group) is full: the flags of that
+ * call are not valid - the caller repeats the walk with vps_mask_level, as for vps_mask_removal_dep. No occupancy plane, no
+ * cross-workgroup wait. */
+int vps_mask_removal_hist(const float* logits, int S, const int32_t* boxes, const int32_t* cls0, const int32_t* mask_idx,
+                          const int32_t* rank, int max_rank, int n, int ncls, int H, int W, int32_t* scratch, size_t scratch_bytes,
+                          double thr, int32_t* flags, int32_t* status, void* stream);
+
 /* one dependency LEVEL of the MaskRemoval loop (count launch + commit launch): `level` = nlevel indices (device) into the
  * score-sorted box arrays whose boxes are mutually independent (no earlier same-class box of the same level intersects
  * them); counts [n][2] and occ must have been zeroed by the caller before the first level; max_area = largest clipped

@@ -84,17 +84,22 @@ def test_more_than_244_instances_is_refused_loudly(dev, model):
     m._cache = None; m.reset_tracker()
 
 
-def test_mask_removal_expired_dependency_wait_is_recovered_not_raised(dev, model):
+@pytest.mark.parametrize('mode', ['dep', 'hist'])
+def test_mask_removal_expired_dependency_wait_is_recovered_not_raised(dev, model, mode):
     """VERDICT r5 next #5 / ADVICE r5: when a box of the one-launch MaskRemoval gives up waiting for a box it depends on (status bit 2
     of vps_mask_removal_dep), the detector repeats MaskRemoval + combine through the per-level launches instead of raising. The expiry
     is forced (VPS_MR_SPIN_LIMIT=0: a box that finds a dependency unfinished at its first poll gives up) on the golden case with 20
-    same-class overlapping detections; results must equal the golden of the REAL reference like the undisturbed run's."""
+    same-class overlapping detections; results must equal the golden of the REAL reference like the undisturbed run's. `hist` (round 6
+    default): the same recovery after a full pattern table of vps_mask_removal_hist (forced: a table of one entry)."""
     from vps_amd import panoptic_ops as P
     m, sd, frames, x, g = model
     case = 'overlap_skip'
     old = os.environ.get('VPS_MR_SPIN_LIMIT')
     os.environ['VPS_MR_SPIN_LIMIT'] = '0'
+    os.environ['VPS_MR_HIST_CAP'] = '1'         # ... or, in `hist` mode (round 6 default), finds its pattern table full
     before = P.MR_RECOVERIES[0]
+    old_mode = P.MASK_REMOVAL_MODE
+    P.MASK_REMOVAL_MODE = mode
     try:
         m._cache = None; m.reset_tracker()
         for t, inj in enumerate(IC.frames_of(case)):
@@ -110,9 +115,11 @@ def test_mask_removal_expired_dependency_wait_is_recovered_not_raised(dev, model
                                  np.asarray(hd['det_obj_ids']), m._aux['keep_inds'], r, [int(k) for k in out[0].keys()],
                                  r['panoptic_outputs'], r['fcn_outputs'], score_tol=1e-6, comp_tol=2e-3, map_tol=1e-3)
     finally:
+        P.MASK_REMOVAL_MODE = old_mode
+        os.environ.pop('VPS_MR_HIST_CAP', None)
         if old is None:
             os.environ.pop('VPS_MR_SPIN_LIMIT', None)
         else:
             os.environ['VPS_MR_SPIN_LIMIT'] = old
-    assert P.MR_RECOVERIES[0] > before, 'the forced expiry did not happen: the test exercised nothing'
+    assert P.MR_RECOVERIES[0] > before, 'the forced failure did not happen: the test exercised nothing'
     m._cache = None; m.reset_tracker()

@@ -844,16 +844,17 @@ def test_mask_removal_device_resize_equals_torch_bilinear(dev, box):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('n,seed', [(1, 0), (12, 1), (60, 2), (100, 3), (100, 4)])
+@pytest.mark.parametrize('n,seed', [(1, 0), (12, 1), (60, 2), (100, 3), (100, 4), (100, 5)])
 def test_mask_removal_one_launch_equals_the_level_launches(dev, n, seed):
-    """vps_mask_removal_dep (one workgroup per box, waits on the boxes it depends on; round 5 default) against the per-level launches
-    (vps_mask_level) and the one-workgroup-per-class walk (vps_mask_removal): identical kept lists and instance tables on crowded
-    lists (up to 100 boxes of 2..8 classes, long same-class overlap chains, boxes overhanging every edge, 1-pixel boxes)"""
+    """vps_mask_removal_hist (round 6 default: per-pixel box patterns, one wavefront per class, no chain) and vps_mask_removal_dep (one
+    workgroup per box, waits on the boxes it depends on; round 5) against the per-level launches (vps_mask_level) and the
+    one-workgroup-per-class walk (vps_mask_removal): identical kept lists and instance tables on crowded lists (up to 100 boxes of 2..8
+    classes, long same-class overlap chains, boxes overhanging every edge, 1-pixel boxes; 100 boxes of ONE class: the two-pass walk of ranks 0..63 | 64..99)"""
     import ctypes
     from vps_amd import panoptic_ops as P
     H, W, S = 1024, 2048, 28
     rg = np.random.default_rng(seed)
-    ncls = 2 if seed % 2 else 8
+    ncls = 1 if seed == 5 else 2 if seed % 2 else 8
     cx = rg.uniform(0, W, n); cy = rg.uniform(0, H, n)
     bw = np.exp(rg.uniform(np.log(2), np.log(900), n)); bh = np.exp(rg.uniform(np.log(2), np.log(600), n))
     rows = np.zeros((n, 8), dtype=np.float32)
@@ -869,8 +870,10 @@ def test_mask_removal_one_launch_equals_the_level_launches(dev, n, seed):
     cm = {c: 10 + c for c in range(1, ncls + 1)}
     res = {}
     old = P.MASK_REMOVAL_MODE, P.MASK_REMOVAL_SINGLE_LAUNCH
+    old_pairs = P.HIST_MAX_PAIRS
+    P.HIST_MAX_PAIRS = 10 ** 9           # every list through the pattern kernels here (the detector keeps lists with > 200 intersecting pairs on `dep`)
     try:
-        for mode in ('dep', 'level', 'single'):
+        for mode in ('hist', 'dep', 'level', 'single'):
             P.MASK_REMOVAL_MODE, P.MASK_REMOVAL_SINGLE_LAUNCH = mode, mode == 'single'
             ws = nhwc.Workspace(dev)
             out = P.MaskRemoval(0.3)(rows, rows_d, masks, (H, W), ws, cm)
@@ -879,14 +882,54 @@ def test_mask_removal_one_launch_equals_the_level_launches(dev, n, seed):
             assert kinfo[2] == 0, (mode, kinfo)
             k = int(kinfo[0])
             res[mode] = (k, out['keep'][:k].cpu().numpy().copy(), bytes(out['inst'].cpu().numpy()[:k * ctypes.sizeof(hip.PanInst)]),
-                         ws.bufs['mr.occ'].ne(0).cpu().numpy().copy())
+                         ws.bufs['mr.occ'].ne(0).cpu().numpy().copy(), 'mr.hist' in ws.bufs)
     finally:
         P.MASK_REMOVAL_MODE, P.MASK_REMOVAL_SINGLE_LAUNCH = old
+        P.HIST_MAX_PAIRS = old_pairs
     for mode in ('level', 'single'):
         assert res['dep'][0] == res[mode][0], (mode, res['dep'][0], res[mode][0])
         assert np.array_equal(res['dep'][1], res[mode][1]) and res['dep'][2] == res[mode][2], mode
         assert np.array_equal(res['dep'][3], res[mode][3]), mode                   # the occupancy planes (as "occupied or not")
+    assert res['hist'][0] == res['level'][0] and np.array_equal(res['hist'][1], res['level'][1]) and res['hist'][2] == res['level'][2]
+    assert res['hist'][4], 'the pattern kernels ran (<= 127 boxes per class)'
     assert 1 <= res['dep'][0] <= n
+
+
+@pytest.mark.gpu
+def test_mask_removal_patterns_table_full_status_and_bounds(dev):
+    """vps_mask_removal_hist: a full pattern table raises status bit 2 (forced: VPS_MR_HIST_CAP=1 on a list with several distinct overlap
+    patterns) - the bit the detector recovers from; the undisturbed call on the same list keeps box 0 only (every later box overlaps it
+    entirely); argument bounds (scratch too small, more than 32 classes)"""
+    import ctypes
+    lib = hip.load()
+    H, W, n, S = 256, 512, 24, 28
+    boxes = torch.tensor([[10 + i, 10 + i, 200 + i, 200 + i] for i in range(n)], dtype=torch.int32, device=dev)
+    cls0 = torch.zeros(n, dtype=torch.int32, device=dev)
+    midx = torch.arange(n, dtype=torch.int32, device=dev)
+    rank = torch.arange(n, dtype=torch.int32, device=dev)
+    scratch = torch.zeros(n + 2 + 2 * 4096, dtype=torch.int32, device=dev)
+    flags = torch.full((n,), 7, dtype=torch.int32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    lg = torch.ones(n, S, S, device=dev)
+    call = lambda ncls=1, nbytes=None, mr=n - 1: lib.vps_mask_removal_hist(hip.ptr(lg), S, hip.ptr(boxes), hip.ptr(cls0), hip.ptr(midx), hip.ptr(rank), mr, n, ncls, H, W,
+                                                                  hip.ptr(scratch), scratch.numel() * 4 if nbytes is None else nbytes, ctypes.c_double(0.3),
+                                                                  hip.ptr(flags), hip.ptr(status), hip.stream_ptr())
+    assert call(33) == -1001 and call(1, 64) == -1002 and call(1, None, 127) == -1003
+    assert call() == 0
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0 and int(flags[0].item()) == 1 and int(flags[1:].sum().item()) == 0
+    assert int(scratch[0].item()) == 191 * 191                                       # mask_sum of box 0: its whole clipped rectangle
+    old = os.environ.get('VPS_MR_HIST_CAP')
+    os.environ['VPS_MR_HIST_CAP'] = '1'
+    try:
+        assert call() == 0
+        torch.cuda.synchronize()
+    finally:
+        if old is None:
+            os.environ.pop('VPS_MR_HIST_CAP', None)
+        else:
+            os.environ['VPS_MR_HIST_CAP'] = old
+    assert int(status.item()) & 4
 
 
 @pytest.mark.gpu

@@ -97,6 +97,12 @@ class _RecordingLib:
             (ctypes.c_int32 * 1).from_address(flags.value + 4 * i)[0] = 1
         return 0
 
+    def _vps_mask_removal_hist(self, *a):
+        flags, n = a[14], a[7]
+        for i in range(n):
+            (ctypes.c_int32 * 1).from_address(flags.value + 4 * i)[0] = 1
+        return 0
+
     def _vps_mask_level(self, *a):
         flags, nlevel, level = a[-2], a[6], a[5]
         lv = (ctypes.c_int32 * nlevel).from_address(level.value)

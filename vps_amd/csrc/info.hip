@@ -1,7 +1,7 @@
 // Library identification for the ctypes loader.
 #include "common.h"
 
-#define VPS_ABI_VERSION 17
+#define VPS_ABI_VERSION 18
 
 extern "C" int vps_abi_version(void) { return VPS_ABI_VERSION; }
 

@@ -316,6 +316,147 @@ void mask_removal_dep_kernel(const float* __restrict__ logits, int S, const int*
 }
 
 // ------------------------------------------------------------------------------------------------
+// MaskRemoval WITHOUT a dependency chain (round 6): the decision of box i depends on the earlier boxes only through
+//   mask_sum_i = #{p : p in mask_i},   overlap_i = #{p in mask_i : p in mask_j for a KEPT earlier box j of the class}
+// (mask_removal.py:75-88: the occupancy plane of a class is the union of the kept masks). Give every box the bit `rank` = its position
+// among the boxes of its class in the score-sorted walk (<= 64 per class) and every pixel, per class, the PATTERN of the boxes whose
+// binary mask covers it. Then overlap_i = sum over the distinct patterns P with bit i of count(P) * [P & kept & (2^i - 1) != 0]:
+//   * mask_pattern_kernel - one pass over the frame in 32 x 8 tiles: a workgroup bins the boxes that touch its tile, a thread builds
+//     the patterns of its pixel, wavefront ballots add the per-box pixel counts (mask_sum), the patterns with two or more bits
+//     (overlap regions) are counted in a per-class hash table in global memory (one atomic pair per distinct pattern and wavefront);
+//   * mask_decide_kernel - one wavefront per class walks its boxes in order over the few hundred distinct patterns: no memory round
+//     trip between two dependent boxes (the one-launch dependency kernel spent ~18 us per link of the chain: 365 us per frame), no
+//     workgroup waits for another one, no occupancy plane (a 16 MB memset per frame).
+// Integer counts, the same resized_logit > 0 test per pixel, the same double-precision threshold: decisions identical to the walk.
+// A full hash table raises status bit 2 (value 4) like an expired wait of the dependency kernel: the caller repeats through vps_mask_level.
+// ------------------------------------------------------------------------------------------------
+constexpr int MH_HT = 2048;              // hash-table entries (64-bit key, 64-bit count) per class and group
+
+// A class with more than 64 boxes (the synthetic bench frames: 97 of 100 detections in one class) is walked in two GROUPS of ranks:
+// group 0 = ranks 0..63 exactly as above; group 1 = ranks 64..126 in a second pass once group 0 is decided - its pixel key is the
+// pattern of the group-1 boxes plus bit 63 = "covered by a KEPT group-0 box" (the group-0 masks are evaluated again for the pixels
+// that a group-1 mask covers). GRP selects the pass.
+template <int GRP>
+__global__ __launch_bounds__(256)
+void mask_pattern_kernel(const float* __restrict__ logits, int S, const int* __restrict__ boxes, const int* __restrict__ cls0,
+                         const int* __restrict__ mask_idx, const int* __restrict__ rank, int n, int ncls, int H, int W,
+                         int* __restrict__ area, unsigned long long* __restrict__ table, const unsigned long long* __restrict__ kept0,
+                         int* __restrict__ status, const int ht) {
+    __shared__ int list[256];
+    __shared__ int nlist;
+    __shared__ unsigned clsmask;
+    const int t = threadIdx.x, lane = t & 63;
+    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 8;
+    if (t == 0) { nlist = 0; clsmask = 0; }
+    __syncthreads();
+    for (int b = t; b < n; b += 256) {
+        const BoxGeom g = box_geom(boxes[4 * b], boxes[4 * b + 1], boxes[4 * b + 2], boxes[4 * b + 3], H, W);
+        if ((rank[b] >> 6) <= GRP && g.x0 < tx0 + 32 && tx0 < g.x1 && g.y0 < ty0 + 8 && ty0 < g.y1) {
+            list[atomicAdd(&nlist, 1)] = b;
+            if ((rank[b] >> 6) == GRP) atomicOr(&clsmask, 1u << cls0[b]);   // classes with a box of THIS group on the tile
+        }
+    }
+    __syncthreads();
+    const int nl = nlist;
+    const unsigned cm = clsmask;
+    if (cm == 0) return;
+    // a table is full (another workgroup said so): the call's result is void, later workgroups do not add to the damage
+    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4) return;
+    const int x = tx0 + (t & 31), y = ty0 + (t >> 5);
+    auto covers = [&](const int b) -> bool {
+        const BoxGeom g = box_geom(boxes[4 * b], boxes[4 * b + 1], boxes[4 * b + 2], boxes[4 * b + 3], H, W);
+        if (!(x >= g.x0 && x < g.x1 && y >= g.y0 && y < g.y1)) return false;
+        return resized_logit(logits + (size_t)mask_idx[b] * S * S, S, x - g.bx1, y - g.by1, g.w, g.h) > 0.f;
+    };
+    for (int c = 0; c < ncls; ++c) {
+        if (!(cm >> c & 1)) continue;
+        unsigned long long pat = 0;
+        for (int k = 0; k < nl; ++k) {
+            const int b = list[k];
+            if (cls0[b] != c || (rank[b] >> 6) != GRP) continue;         // uniform
+            const bool pos = covers(b);
+            const unsigned long long m = __ballot(pos);
+            if (pos) pat |= 1ull << (rank[b] & 63);
+            if (lane == 0 && m) atomicAdd(&area[b], __popcll(m));
+        }
+        bool multi = (pat & (pat - 1)) != 0;
+        if (GRP == 1) {
+            if (__ballot(pat != 0)) {                                    // a kept group-0 box over a pixel that a group-1 mask covers?
+                const unsigned long long k0 = kept0[c];
+                bool occ = false;
+                for (int k = 0; k < nl; ++k) {
+                    const int b = list[k];
+                    if (cls0[b] != c || (rank[b] >> 6) != 0 || !(k0 >> rank[b] & 1ull)) continue;   // uniform
+                    if (pat != 0 && !occ && covers(b)) occ = true;
+                }
+                if (occ) { pat |= 1ull << 63; multi = true; }
+            }
+        }
+        // overlap regions: one (key, count) update per distinct pattern of the wavefront
+        unsigned long long todo = __ballot(multi);
+        unsigned long long* __restrict__ tab = table + (size_t)c * MH_HT * 2;  // the first `ht` entries are used (ht = MH_HT but in tests)
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const unsigned long long p0 = ((unsigned long long)(unsigned)__shfl((int)(pat >> 32), leader, 64) << 32) | (unsigned)__shfl((int)pat, leader, 64);
+            const unsigned long long same = __ballot(multi && pat == p0);
+            if (lane == leader) {
+                unsigned h = (unsigned)((p0 * 0x9E3779B97F4A7C15ull) >> 53) & (unsigned)(ht - 1);
+                const int nprobe = ht < 64 ? ht : 64;                    // a run of 64 taken entries = the table is (as good as) full
+                int probe = 0;
+                for (; probe < nprobe; ++probe, h = (h + 1) & (unsigned)(ht - 1)) {
+                    const unsigned long long key = atomicCAS(&tab[2 * h], 0ull, p0);
+                    if (key == 0ull || key == p0) { atomicAdd(&tab[2 * h + 1], (unsigned long long)__popcll(same)); break; }
+                }
+                if (probe == nprobe) atomicOr(status, 4);
+            }
+            todo &= ~same;
+        }
+    }
+}
+
+template <int GRP>
+__global__ __launch_bounds__(64)
+void mask_decide_kernel(const int* __restrict__ cls0, const int* __restrict__ rank, int n, const int* __restrict__ area,
+                        const unsigned long long* __restrict__ table, unsigned long long* __restrict__ kept0, double thr,
+                        int* __restrict__ flags) {
+    __shared__ unsigned long long keys[MH_HT];
+    __shared__ unsigned cnts[MH_HT];
+    __shared__ int box_of_rank[64];
+    __shared__ int ne, kc;
+    const int c = blockIdx.x, lane = threadIdx.x;
+    box_of_rank[lane] = -1;
+    if (lane == 0) { ne = 0; kc = 0; }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64)
+        if (cls0[i] == c && (rank[i] >> 6) == GRP) { box_of_rank[rank[i] & 63] = i; atomicMax(&kc, (rank[i] & 63) + 1); }
+    const unsigned long long* __restrict__ tab = table + (size_t)c * MH_HT * 2;
+    for (int e = lane; e < MH_HT; e += 64) {
+        const unsigned long long key = tab[2 * e];
+        if (key) { const int slot = atomicAdd(&ne, 1); keys[slot] = key; cnts[slot] = (unsigned)tab[2 * e + 1]; }
+    }
+    __syncthreads();
+    const int nent = ne, nbox = kc;
+    unsigned long long kept = 0;
+    for (int r = 0; r < nbox; ++r) {
+        const int i = box_of_rank[r];
+        if (i < 0) continue;                                             // (ranks are dense: not reached)
+        // patterns that count: bit r and an earlier kept bit of this group - or, in group 1, bit 63 (a kept group-0 box)
+        const unsigned long long earlier = (kept & ((1ull << r) - 1ull)) | (GRP == 1 ? 1ull << 63 : 0ull);
+        int ov = 0;
+        for (int e = lane; e < nent; e += 64) {
+            const unsigned long long key = keys[e];
+            if ((key >> r & 1ull) && (key & earlier)) ov += (int)cnts[e];
+        }
+        for (int off = 32; off >= 1; off >>= 1) ov += __shfl_xor(ov, off, 64);
+        const int ms = area[i];
+        const int keep = (ms != 0 && !((double)ov / (double)ms > thr)) ? 1 : 0;
+        kept |= (unsigned long long)keep << r;
+        if (lane == 0) flags[i] = keep;
+    }
+    if (GRP == 0 && lane == 0) kept0[c] = kept;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused panoptic combine. For every full-resolution pixel:
 //   fcn_output[c] = bilinear x4 (align_corners=False) of fcn_score[c]           (upsnetFPN.py:81)
 //   sem = argmax_c fcn_output[c]                                                 (panoptic_fusetrack.py:593)
@@ -480,6 +621,42 @@ extern "C" int vps_mask_removal_dep(const float* logits, int S, const int32_t* b
     if (e != hipSuccess) return -(int)e;
     hipLaunchKernelGGL(mask_removal_dep_kernel, dim3(n), dim3(MR_THREADS), 0, s, logits, S, boxes, cls0, mask_idx, n, H, W,
                        reinterpret_cast<unsigned*>(occ), thr, flags, done, status, spin_limit);
+    return vps_launch_status();
+}
+
+extern "C" int vps_mask_removal_hist(const float* logits, int S, const int32_t* boxes, const int32_t* cls0, const int32_t* mask_idx,
+                                     const int32_t* rank, int max_rank, int n, int ncls, int H, int W, int32_t* scratch, size_t scratch_bytes,
+                                     double thr, int32_t* flags, int32_t* status, void* stream) {
+    if (!logits || !boxes || !cls0 || !mask_idx || !rank || !scratch || !flags || !status || S < 2 || n < 0 || n > 256 || ncls <= 0 || ncls > 32 ||
+        H <= 0 || W <= 0)
+        return VPS_EARG(1);
+    if (max_rank < 0 || max_rank > 126) return VPS_EARG(3);                              // two groups: ranks 0..63 | 64..126 (+ bit 63)
+    const int ngrp = max_rank >= 64 ? 2 : 1;
+    // area[n] | kept0[ncls] | table[ngrp][ncls][MH_HT][2], 64-bit words behind the int32 area
+    const size_t area_bytes = ((size_t)n * sizeof(int32_t) + 7) & ~(size_t)7;
+    const size_t tab_words = (size_t)ncls * MH_HT * 2;
+    const size_t need = area_bytes + ((size_t)ncls + ngrp * tab_words) * sizeof(unsigned long long);
+    if (scratch_bytes < need || ((uintptr_t)scratch & 7)) return VPS_EARG(2);
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) return 0;
+    const hipError_t e = hipMemsetAsync(scratch, 0, need, s);
+    if (e != hipSuccess) return -(int)e;
+    unsigned long long* kept0 = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(scratch) + area_bytes);
+    unsigned long long* table = kept0 + ncls;
+    // VPS_MR_HIST_CAP=c in the environment (a power of two <= 2048, read per call): entries of a class's pattern table that are used - tests
+    // force the table-full status with a tiny table
+    int ht = MH_HT;
+    if (const char* const hc = getenv("VPS_MR_HIST_CAP")) { const int v = atoi(hc); if (v >= 1 && v <= MH_HT && !(v & (v - 1))) ht = v; }
+    const dim3 tiles((W + 31) / 32, (H + 7) / 8);
+    hipLaunchKernelGGL(mask_pattern_kernel<0>, tiles, dim3(256), 0, s, logits, S, boxes, cls0, mask_idx, rank, n, ncls, H, W, scratch, table,
+                       (const unsigned long long*)kept0, status, ht);
+    hipLaunchKernelGGL(mask_decide_kernel<0>, dim3(ncls), dim3(64), 0, s, cls0, rank, n, scratch, (const unsigned long long*)table, kept0, thr, flags);
+    if (ngrp == 2) {
+        hipLaunchKernelGGL(mask_pattern_kernel<1>, tiles, dim3(256), 0, s, logits, S, boxes, cls0, mask_idx, rank, n, ncls, H, W, scratch,
+                           table + tab_words, (const unsigned long long*)kept0, status, ht);
+        hipLaunchKernelGGL(mask_decide_kernel<1>, dim3(ncls), dim3(64), 0, s, cls0, rank, n, scratch, (const unsigned long long*)(table + tab_words), kept0,
+                           thr, flags);
+    }
     return vps_launch_status();
 }
 

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VPS_HIP_LIB: developer override to load an experimental build of the same ABI (kernel A/B timing)
 LIB_PATH = os.environ.get('VPS_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libvpship.so')
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
@@ -25,7 +25,7 @@ SYMBOLS = [
     'vps_flow_warp', 'vps_nchw_to_nhwc', 'vps_nhwc_to_nchw', 'vps_resize', 'vps_pool3x3s2', 'vps_bfp_gather',
     'vps_bfp_scatter', 'vps_bfp_scatter_all', 'vps_axpb', 'vps_flow_prep', 'vps_flow_prep_pad', 'vps_flow_stage', 'vps_flow_stage_full', 'vps_groupnorm_relu', 'vps_groupnorm_apply', 'vps_tcea_temporal',
     'vps_tcea_modulate', 'vps_tcea_modulate_ld', 'vps_correlation_f16', 'vps_roi_align', 'vps_nms_batched', 'vps_delta2bbox', 'vps_bbox_overlaps',
-    'vps_row_softmax', 'vps_mask_count', 'vps_mask_commit', 'vps_mask_removal', 'vps_mask_removal_dep', 'vps_frame_tail', 'vps_mask_level', 'vps_panoptic_combine',
+    'vps_row_softmax', 'vps_mask_count', 'vps_mask_commit', 'vps_mask_removal', 'vps_mask_removal_dep', 'vps_mask_removal_hist', 'vps_frame_tail', 'vps_mask_level', 'vps_panoptic_combine',
     'vps_panoptic_combine_dev', 'vps_rpn_select', 'vps_rpn_collect', 'vps_maskroi_select', 'vps_maskroi_finish', 'vps_track_assign', 'vps_pan_instances',
     'vps_unify_hist', 'vps_unify_tables', 'vps_unify_write', 'vps_image_prep', 'vps_resize_u8', 'vps_segment_stats', 'vps_segment_paint', 'vps_pair_count',
     'vps_png_info', 'vps_png_decode_bgr8',
@@ -169,6 +169,8 @@ def load():
                                      c_double, c_void_p, c_void_p]
     lib.vps_mask_removal_dep.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                          c_double, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.vps_mask_removal_hist.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, ctypes.c_size_t,
+                                          c_double, c_void_p, c_void_p, c_void_p]
     lib.vps_frame_tail.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.vps_mask_level.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                    c_void_p, c_double, c_void_p, c_void_p]

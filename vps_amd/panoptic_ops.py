@@ -16,11 +16,14 @@ import os
 
 from . import hip
 
-# MaskRemoval's box walk on the device: 'dep' (default, round 5) = ONE launch, one workgroup per box waiting for the boxes it depends
-# on (vps_mask_removal_dep); 'level' = the round-3 schedule, one count + one commit launch per dependency level (~20 levels per frame);
+# MaskRemoval's box walk on the device: 'hist' (default, round 6) = no chain at all: per-pixel box patterns counted in one pass, one
+# wavefront per class decides its boxes over the distinct patterns (vps_mask_removal_hist; a class with 65..127 boxes takes two passes, more: 'dep');
+# 'dep' (round 5) = ONE launch, one workgroup per box waiting for the boxes it depends on (vps_mask_removal_dep); 'level' = the round-3
+# schedule, one count + one commit launch per dependency level (~20 levels per frame: the recovery path of the two above);
 # 'single' = one workgroup per class walking its boxes in order (slowest; kept as the simplest statement of the loop)
-MASK_REMOVAL_MODE = os.environ.get('VPS_MASK_REMOVAL', 'dep')
+MASK_REMOVAL_MODE = os.environ.get('VPS_MASK_REMOVAL', 'hist')
 MASK_REMOVAL_SINGLE_LAUNCH = MASK_REMOVAL_MODE == 'single'
+HIST_MAX_PAIRS = int(os.environ.get('VPS_MR_HIST_PAIRS', '200'))     # intersecting same-class box pairs up to which 'hist' is used
 # frames whose one-launch MaskRemoval reported an expired dependency wait and were finished through the per-level launches (detector.py)
 MR_RECOVERIES = [0]
 
@@ -133,10 +136,31 @@ class MaskRemoval(nn.Module):
         x0 = np.maximum(sb[:, 0], 0); x1 = np.minimum(sb[:, 2] + 1, W); y0 = np.maximum(sb[:, 1], 0); y1 = np.minimum(sb[:, 3] + 1, H)
         area = np.maximum(x1 - x0, 0) * np.maximum(y1 - y0, 0)
         # (force_level: the detector's second pass after an expired dependency wait of the one-launch kernel)
-        dep_mode = MASK_REMOVAL_MODE == 'dep' and W % 4 == 0 and n <= MaskROI.KCAP and S <= 32 and not force_level
+        # rank of a box among the boxes of its class in walk order (the bit it owns in the pixel patterns of vps_mask_removal_hist)
+        rank = np.zeros(n, dtype=np.int64)
+        per_cls = np.zeros(1, dtype=np.int64)
+        hist_mode = MASK_REMOVAL_MODE == 'hist' and n <= MaskROI.KCAP and ncls <= 32 and int(sc.min()) >= 0 and not force_level
+        if hist_mode:
+            by_cls = np.argsort(sc, kind='stable')
+            per_cls = np.bincount(sc)
+            rank[by_cls] = np.arange(n) - (np.cumsum(per_cls) - per_cls)[sc[by_cls]]
+            hist_mode = int(rank.max()) <= 126
+        if hist_mode and int((per_cls * (per_cls - 1) // 2).sum()) > HIST_MAX_PAIRS:
+            # the pattern tables hold 2048 distinct overlap patterns per class: lists whose same-class rectangles intersect in very many
+            # pairs (the random-weight bench frames: 97 boxes of one class, 420..500 intersecting pairs, tables overflow) stay on the
+            # dependency kernel; street-scene lists have tens (the crowded synthetic test lists: 6..130). A class of more than 64 boxes
+            # with that many possible pairs is not examined further; else one vectorised n x n rectangle test (~0.1 ms of host time for
+            # 100 boxes - only lists with > HIST_MAX_PAIRS possible pairs pay it).
+            if int(per_cls.max()) > 64:
+                hist_mode = False
+            else:
+                inter = ((sc[:, None] == sc[None, :]) & (x0[:, None] < x1[None, :]) & (x0[None, :] < x1[:, None])
+                         & (y0[:, None] < y1[None, :]) & (y0[None, :] < y1[:, None]))
+                hist_mode = (int(np.count_nonzero(inter)) - n) // 2 <= HIST_MAX_PAIRS
+        dep_mode = (MASK_REMOVAL_MODE in ('dep', 'hist') and not hist_mode and W % 4 == 0 and n <= MaskROI.KCAP and S <= 32 and not force_level)
         lvl = np.zeros(n, dtype=np.int64)
         single = MASK_REMOVAL_SINGLE_LAUNCH and not force_level
-        if not dep_mode and not single:
+        if not dep_mode and not single and not hist_mode:
             # (the one-launch kernel finds a box's dependencies itself: this O(n^2) host loop sat on the frame's critical path with the
             # GPU idle - 0.26 ms in the traced frame, profiles/r05_frame_occupancy_traced.json before / after)
             for i in range(1, n):
@@ -146,13 +170,22 @@ class MaskRemoval(nn.Module):
         order = np.argsort(lvl, kind='stable')
         nlv = int(lvl.max()) + 1
         starts = np.searchsorted(lvl[order], np.arange(nlv + 1))
-        host = np.concatenate([sb.reshape(-1), sc, sorted_inds, order]).astype(np.int32)
+        host = np.concatenate([sb.reshape(-1), sc, sorted_inds, order, rank]).astype(np.int32)
         meta = torch.from_numpy(host).to(dev, non_blocking=True)
         counts = ws.get('mr.counts', (max(n, 1), 2), dtype=torch.int32, zero=False)
-        if not dep_mode:
+        if not dep_mode and not hist_mode:
             occ.zero_(); counts.zero_()             # (the one-launch entries zero what they use themselves)
         base = meta.data_ptr()
-        if dep_mode:
+        if hist_mode:
+            scratch = ws.get('mr.hist', (MaskROI.KCAP + 2 * (32 + 2 * 32 * 4096),), dtype=torch.int32, zero=False)
+            # status word = kinfo[2] (read with the frame's end-of-frame read; bit 2: a pattern table was full -> the detector repeats
+            # the walk through the level launches, as for an expired wait of the dependency kernel)
+            hip.check(lib.vps_mask_removal_hist(hip.ptr(mp), S, ctypes.c_void_p(base), ctypes.c_void_p(base + 16 * n), ctypes.c_void_p(base + 20 * n),
+                                                ctypes.c_void_p(base + 28 * n), int(rank.max()), n, ncls, H, W, hip.ptr(scratch), scratch.numel() * 4,
+                                                float(self.fraction_threshold), hip.ptr(flags), ctypes.c_void_p(kinfo.data_ptr() + 8), sp),
+                      'vps_mask_removal_hist')
+            nlv = 0
+        elif dep_mode:
             done = ws.get('mr.done', (MaskROI.KCAP,), dtype=torch.int32, zero=False)
             # status word = kinfo[2] (read with the frame's end-of-frame read; bit 2: a dependency wait expired)
             hip.check(lib.vps_mask_removal_dep(hip.ptr(mp), S, ctypes.c_void_p(base), ctypes.c_void_p(base + 16 * n), ctypes.c_void_p(base + 20 * n),
